@@ -1,0 +1,223 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own modules (this container only).
+
+    python oracle/gen_golden.py            # needs /root/reference; CPU only
+
+The reference cannot travel to the GPU box, so its outputs on seeded inputs are
+committed as small fixtures; the seeded inputs/weights are regenerated in the
+tests from ``reid_amd.synth`` (same seed -> same numpy arrays).
+
+How the reference classes are made importable (nothing was denied):
+  * ``torchvision`` is absent: an empty stub module is injected (the name
+    ``models`` is imported at SERes18_IBN.py:3 but never used at run time).
+  * ``torch.hub.load("XingangPan/IBN-Net", "resnet18_ibn_a")`` needs network:
+    it is patched to return the skeleton below, written from the published
+    IBN-Net architecture (resnet_ibn.py): conv1/bn1/relu/maxpool and
+    layer1..4 of BasicBlock_IBN with ibn_cfg=('a','a','a',None).  Child
+    registration order (conv1, bn1, relu, conv2, bn2, downsample) matters
+    because SEBasicBlock slices named_children() (SERes18_IBN.py:108-114).
+    IBN-Net is un-pinned by the reference (hub default branch): that boundary
+    is "parity unpinned"; everything above it is the reference's own code.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+# ---------------------------------------------------------------- IBN-Net skeleton [external]
+class _IBN(nn.Module):
+    def __init__(self, planes, ratio=0.5):
+        super().__init__()
+        self.half = int(planes * ratio)
+        self.IN = nn.InstanceNorm2d(self.half, affine=True)
+        self.BN = nn.BatchNorm2d(planes - self.half)
+
+    def forward(self, x):
+        split = torch.split(x, self.half, 1)
+        return torch.cat((self.IN(split[0].contiguous()), self.BN(split[1].contiguous())), 1)
+
+
+class _BasicBlockIBN(nn.Module):
+    def __init__(self, inplanes, planes, ibn=None, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = _IBN(planes) if ibn == "a" else nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.IN = None
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        out += residual
+        return self.relu(out)
+
+
+class _ResNet18IBNa(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cfg = ("a", "a", "a", None)
+        self.layer1 = self._make(64, 1, cfg[0])
+        self.layer2 = self._make(128, 2, cfg[1])
+        self.layer3 = self._make(256, 2, cfg[2])
+        self.layer4 = self._make(512, 2, cfg[3])
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512, 1000)
+
+    def _make(self, planes, stride, ibn):
+        ds = None
+        if stride != 1 or self.inplanes != planes:
+            ds = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        layers = [_BasicBlockIBN(self.inplanes, planes, ibn, stride, ds)]
+        self.inplanes = planes
+        layers.append(_BasicBlockIBN(planes, planes, ibn))
+        return nn.Sequential(*layers)
+
+
+def _install_stubs():
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.models", tv.models)
+    torch.hub.load = lambda *a, **k: _ResNet18IBNa()
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "reid"))
+
+
+def _sample(t):
+    """Small deterministic slice of an activation for stage-level localisation."""
+    t = t.detach()
+    if t.dim() == 4:
+        n, c, h, w = t.shape
+        return t[:, :: max(1, c // 8), :: max(1, h // 8), :: max(1, w // 4)].contiguous().numpy()
+    return t.numpy()
+
+
+def gen_seres18():
+    from reid_amd import synth
+    from reid.backbones.SERes18_IBN import seres18_ibn  # the reference's own class
+
+    for tag, seed, n, crops_fn in (("seed0", 0, 3, synth.crops_u8), ("smooth1", 1, 5, synth.smooth_crops_u8)):
+        sd_np = synth.seres18_state_dict(seed)
+        model = seres18_ibn(num_classes=751, loss="triplet")
+        missing = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        model.eval()
+        crops = crops_fn(n, seed)
+        x = torch.from_numpy(crops).float().div(255.0).sub(0.5).div(0.5).permute(0, 3, 1, 2).contiguous()
+        taps = {}
+        hooks = []
+        for name in ["bn0", "pooling0"] + [b[0] for b in synth.SERES18_BLOCKS] + ["avgpooling"]:
+            hooks.append(getattr(model, name).register_forward_hook(
+                lambda m, i, o, name=name: taps.__setitem__(name, o.detach().clone())))
+        with torch.no_grad():
+            emb, logits = model(x)
+        for h in hooks:
+            h.remove()
+        with torch.no_grad():
+            emb1, _ = model(x[:1])          # N=1 path (squeeze() also drops the batch dim)
+        out = {"seed": np.int64(seed), "n": np.int64(n), "emb": emb.numpy(), "logits": logits.numpy(),
+               "emb_single0": emb1.numpy()}
+        for k, v in taps.items():
+            out["tap_" + k] = _sample(v)
+            out["mean_" + k] = np.float64(v.double().mean().item())
+            out["absmean_" + k] = np.float64(v.double().abs().mean().item())
+        np.savez_compressed(os.path.join(OUT, "seres18_%s.npz" % tag), **out)
+        print("seres18", tag, "emb", emb.shape, "|emb| row0", float(emb[0].norm()))
+
+
+def gen_matching():
+    from reid_amd import synth
+    from reid.losses.utils import euclidean_dist, cosine_dist
+    from reid.evaluate import evaluate_all
+    from modification_deepsort.iou_matching import iou
+
+    rng = np.random.default_rng(7)
+    x = rng.normal(0, 1, (37, 64)).astype(np.float32)
+    y = rng.normal(0, 1, (53, 64)).astype(np.float32)
+    y[5] = x[3]                      # exact duplicate -> clamp(1e-12) branch
+    out = {"x": x, "y": y,
+           "euclid": euclidean_dist(torch.from_numpy(x), torch.from_numpy(y)).numpy(),
+           "cosine": cosine_dist(torch.from_numpy(x), torch.from_numpy(y)).numpy()}
+
+    # retrieval: small Market-like problem incl. junk (same pid+cam), pid==-1 rows and a query with no good match
+    qf, ql, qc, gf, gl, gc = synth.clustered_embeddings(40, 300, d=32, n_ids=12, n_cams=3, seed=11)
+    gl[::17] = -1
+    ql[7] = 999                      # no match at all -> skipped but still in the denominator
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        cmc, ap = evaluate_all(torch.from_numpy(qf), torch.from_numpy(ql), torch.from_numpy(qc),
+                               torch.from_numpy(gf), torch.from_numpy(gl), torch.from_numpy(gc))
+    out.update({"ev_qf": qf, "ev_ql": ql, "ev_qc": qc, "ev_gf": gf, "ev_gl": gl, "ev_gc": gc,
+                "ev_cmc": cmc.numpy(), "ev_map": np.float64(ap)})
+
+    # DIoU: the file's own demo vector (iou_matching.py:50-53) + random/edge boxes
+    demo = iou(np.asarray([10, 12, 8, 9]), np.asarray([[9, 10, 9, 9], [8, 12, 9, 10], [10, 12, 9, 8]]))
+    boxes = rng.uniform(0, 200, (24, 4))
+    boxes[:, 2:] = rng.uniform(5, 80, (24, 2))
+    cands = rng.uniform(0, 200, (31, 4))
+    cands[:, 2:] = rng.uniform(5, 80, (31, 2))
+    cands[0] = boxes[0]                                   # identical
+    cands[1] = [boxes[1, 0] + 2, boxes[1, 1] + 2, boxes[1, 2] / 4, boxes[1, 3] / 4]   # contained
+    cands[2] = [boxes[2, 0] + 500, boxes[2, 1] + 500, 10, 10]                          # disjoint
+    out.update({"diou_demo": demo, "diou_boxes": boxes, "diou_cands": cands,
+                "diou": np.stack([iou(b, cands) for b in boxes], 0)})
+    np.savez_compressed(os.path.join(OUT, "matching.npz"), **out)
+    print("matching: demo diou", demo)
+
+
+def gen_factory():
+    """Pins get_model_name / load_pretrained_weights behaviour (reid_model_factory.py:122-126,158-210)."""
+    import io, contextlib, json, tempfile
+    from pathlib import Path
+    sys.path.insert(0, os.path.join(REF, "modification_tracking"))
+    import reid_model_factory as rmf
+
+    names = ["osnet_x0_25_msmt17.pt", "resnet50_market1501.pt", "swin_transformer_market.pt", "vit_duke.pt",
+             "seres18_ibn.pt", "mobilenetv2_x1_4_dukemtmcreid.pt", "osnet_ain_x1_0_msmt17.pt", "unknown.pt",
+             "osnet_x1_0"]
+    res = {"get_model_name": {n: rmf.get_model_name(Path(n)) for n in names},
+           "is_model_in_model_types": {n: rmf.is_model_in_model_types(Path(n)) for n in names},
+           "get_model_url": {n: rmf.get_model_url(Path(n)) for n in names}}
+
+    lin = nn.Sequential(nn.Linear(4, 3), nn.Linear(3, 2))
+    ck = {"state_dict": {"module.0.weight": torch.ones(3, 4), "module.0.bias": torch.zeros(3),
+                         "1.weight": torch.ones(5, 5), "junk": torch.ones(1)}}
+    with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+        torch.save(ck, f.name)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            rmf.load_pretrained_weights(lin, f.name)
+    res["load_pretrained"] = {"w0_is_ones": bool((lin[0].weight == 1).all()), "stdout": buf.getvalue()}
+    with open(os.path.join(OUT, "factory.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    print("factory:", res["get_model_name"])
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    _install_stubs()
+    gen_matching()
+    gen_factory()
+    gen_seres18()

@@ -1,0 +1,142 @@
+"""Seeded synthetic weights and crops (no checkpoint or dataset is reachable offline).
+
+The reference's weights live on Google Drive (REID_EVAL.md:1) and its datasets
+are not in the container, so benchmarks and parity tests use random-init
+weights of the exact architecture.  Everything here is driven by
+``numpy.random.default_rng(seed)`` in a fixed key order, so the same seed gives
+the same ``state_dict`` on every machine (this container, the GPU box).
+
+``seres18_state_dict`` emits exactly the keys/shapes of
+``SERse18_IBN().state_dict()`` (reid/backbones/SERes18_IBN.py:186-248; key list
+in SURVEY.md Appendix A).  ``oracle/gen_golden.py`` loads it into the
+reference's own class with ``strict=True`` which pins the key layout.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+# (name, channels, has_ibn, has_downsample, in_channels)
+SERES18_BLOCKS = [
+    ("basicBlock11", 64, True, False, 64),
+    ("basicBlock12", 64, True, False, 64),
+    ("basicBlock21", 128, True, True, 64),
+    ("basicBlock22", 128, True, False, 128),
+    ("basicBlock31", 256, True, True, 128),
+    ("basicBlock32", 256, True, False, 256),
+    ("basicBlock41", 512, False, True, 256),
+    ("basicBlock42", 512, False, False, 512),
+]
+
+
+def se_mid(c):
+    """SE bottleneck width, reid/backbones/SERes18_IBN.py:17."""
+    return max(8, c // 16)
+
+
+def _bn(rng, sd, prefix, c):
+    sd[prefix + ".weight"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    sd[prefix + ".bias"] = rng.normal(0.0, 0.1, c).astype(np.float32)
+    sd[prefix + ".running_mean"] = rng.normal(0.0, 0.1, c).astype(np.float32)
+    sd[prefix + ".running_var"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    sd[prefix + ".num_batches_tracked"] = np.asarray(0, dtype=np.int64)
+
+
+def _conv(rng, cout, cin, k, gain=2.0):
+    std = np.sqrt(gain / (cin * k * k))
+    return rng.normal(0.0, std, (cout, cin, k, k)).astype(np.float32)
+
+
+def seres18_state_dict(seed=0, num_class=751, num_cams=6, gem_p=None):
+    """numpy ``state_dict`` for SERse18_IBN (default ctor: gem pooling, se_lbn=True).
+
+    Running stats, affine terms and (optionally) the GeM exponent are
+    randomised so that a folding/ordering bug shows up in the outputs.
+    """
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    sd["cam_bias"] = rng.normal(0.0, 0.02, (num_cams, 512)).astype(np.float32)
+    sd["conv0.weight"] = _conv(rng, 64, 3, 7)
+    _bn(rng, sd, "bn0", 64)
+    for name, c, ibn, ds, cin in SERES18_BLOCKS:
+        pre = name + ".block_pre"
+        sd[pre + ".conv1.weight"] = _conv(rng, c, cin, 3)
+        if ibn:
+            half = c // 2
+            sd[pre + ".bn1.IN.weight"] = rng.uniform(0.5, 1.5, half).astype(np.float32)
+            sd[pre + ".bn1.IN.bias"] = rng.normal(0.0, 0.1, half).astype(np.float32)
+            _bn(rng, sd, pre + ".bn1.BN", c - half)
+        else:
+            _bn(rng, sd, pre + ".bn1", c)
+        sd[pre + ".conv2.weight"] = _conv(rng, c, c, 3, gain=1.0)
+        _bn(rng, sd, pre + ".bn2", c)
+        if ds:
+            sd[name + ".block_post.conv.weight"] = _conv(rng, c, cin, 1, gain=1.0)
+            _bn(rng, sd, name + ".block_post.bn", c)
+        mid = se_mid(c)
+        sd[name + ".seblock.fc1.weight"] = rng.normal(0.0, np.sqrt(2.0 / c), (mid, c, 1, 1)).astype(np.float32)
+        # the SE norm layer exists in the state_dict but is never applied
+        # (SERes18_IBN.py:36 is commented out): LBN_1D for layers 1-3, BatchNorm1d for layer 4
+        if ibn:
+            h = mid // 2
+            sd[name + ".seblock.bn.LN.weight"] = np.ones(h, np.float32)
+            sd[name + ".seblock.bn.LN.bias"] = np.zeros(h, np.float32)
+            _bn(rng, sd, name + ".seblock.bn.BN", mid - h)
+        else:
+            _bn(rng, sd, name + ".seblock.bn", mid)
+        sd[name + ".seblock.fc2.weight"] = rng.normal(0.0, np.sqrt(2.0 / mid), (c, mid)).astype(np.float32)
+    p = float(rng.uniform(2.5, 3.5)) if gem_p is None else float(gem_p)
+    sd["avgpooling.p"] = np.asarray([p], dtype=np.float32)
+    _bn(rng, sd, "bnneck", 512)
+    sd["classifier.0.weight"] = rng.normal(0.0, 0.05, (num_class, 512)).astype(np.float32)
+    return sd
+
+
+def crops_u8(n, seed=0, h=256, w=128):
+    """``uint8[n,h,w,3]`` uniform crops already at the extractor's (128, 256) size."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+
+
+def smooth_crops_u8(n, seed=0, h=256, w=128):
+    """Low-frequency crops: separable colour gradients + blobs, so that different
+    crops give clearly different embeddings (rank tests need non-trivial gaps)."""
+    rng = np.random.default_rng(seed)
+    yy = np.linspace(0, 1, h, dtype=np.float32)[:, None, None]
+    xx = np.linspace(0, 1, w, dtype=np.float32)[None, :, None]
+    out = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        a = rng.uniform(0, 255, (1, 1, 3)).astype(np.float32)
+        b = rng.uniform(-200, 200, (1, 1, 3)).astype(np.float32)
+        c = rng.uniform(-200, 200, (1, 1, 3)).astype(np.float32)
+        f = rng.uniform(1, 6, 2)
+        img = a + b * yy + c * xx + 60 * np.sin(2 * np.pi * f[0] * yy) * np.cos(2 * np.pi * f[1] * xx)
+        img = img + rng.normal(0, 12, (h, w, 3)).astype(np.float32)
+        out[i] = np.clip(img, 0, 255).astype(np.uint8)
+    return out
+
+
+def ragged_crops_u8(n, seed=0):
+    """Crops of different sizes (h in [40,400], w = h*U(0.3,0.5)), SURVEY §8d config 4."""
+    rng = np.random.default_rng(seed)
+    crops = []
+    for _ in range(n):
+        h = int(np.exp(rng.uniform(np.log(40), np.log(400))))
+        w = max(8, int(h * rng.uniform(0.3, 0.5)))
+        crops.append(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    return crops
+
+
+def clustered_embeddings(nq, ng, d=512, n_ids=751, n_cams=6, seed=4, sigma=0.3):
+    """L2-normalised embeddings around ``n_ids`` centroids + Market-like labels."""
+    rng = np.random.default_rng(seed)
+    cent = rng.normal(0, 1, (n_ids, d)).astype(np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    ql = rng.integers(1, n_ids, nq).astype(np.int64)
+    gl = rng.integers(0, n_ids, ng).astype(np.int64)  # pid 0 = distractors
+    qc = rng.integers(0, n_cams, nq).astype(np.int64)
+    gc = rng.integers(0, n_cams, ng).astype(np.int64)
+    qf = cent[ql] + sigma * rng.normal(0, 1, (nq, d)).astype(np.float32) / np.sqrt(d)
+    gf = cent[gl] + sigma * rng.normal(0, 1, (ng, d)).astype(np.float32) / np.sqrt(d)
+    qf = (qf / np.linalg.norm(qf, axis=1, keepdims=True)).astype(np.float32)
+    gf = (gf / np.linalg.norm(gf, axis=1, keepdims=True)).astype(np.float32)
+    return qf, ql, qc, gf, gl, gc

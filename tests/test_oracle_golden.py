@@ -1,0 +1,100 @@
+"""Pins oracle/ (the CPU restatement) against fixtures produced by the REFERENCE's own
+modules (oracle/gen_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import matching, seres18
+from reid_amd import synth
+
+
+def _sample(t):
+    n, c, h, w = t.shape
+    return t[:, :: max(1, c // 8), :: max(1, h // 8), :: max(1, w // 4)].numpy()
+
+
+TAP_MAP = {"bn0": "stem", "pooling0": "pool0", "avgpooling": "gem"}
+
+
+@pytest.mark.parametrize("tag,crops_fn", [("seed0", synth.crops_u8), ("smooth1", synth.smooth_crops_u8)])
+def test_seres18_oracle_matches_reference(golden_dir, tag, crops_fn):
+    g = np.load(os.path.join(golden_dir, "seres18_%s.npz" % tag))
+    seed, n = int(g["seed"]), int(g["n"])
+    sd = synth.seres18_state_dict(seed)
+    crops = crops_fn(n, seed)
+    taps = {}
+    emb, logits = seres18.forward(sd, seres18.preprocess_u8(crops), taps)
+    # eval-mode semantics; tolerance: fp32 conv summation order only
+    np.testing.assert_allclose(emb.numpy(), g["emb"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=2e-4, atol=2e-3)
+    cos = (emb.numpy() * g["emb"]).sum(1) / np.linalg.norm(emb.numpy(), axis=1) / np.linalg.norm(g["emb"], axis=1)
+    assert (1 - cos).max() < 1e-6
+    for k in g.files:
+        if not k.startswith("tap_"):
+            continue
+        name = k[4:]
+        mine = taps[TAP_MAP.get(name, name)]
+        if mine.dim() == 2:
+            mine = mine[:, :, None, None]
+        got = _sample(mine)
+        np.testing.assert_allclose(got, g[k].reshape(got.shape), rtol=2e-4, atol=2e-4, err_msg=name)
+        assert abs(float(mine.double().mean()) - float(g["mean_" + name])) < 1e-4 * max(1, abs(float(g["mean_" + name])))
+    # N=1 path
+    emb1, _ = seres18.forward(sd, seres18.preprocess_u8(crops[:1]))
+    np.testing.assert_allclose(emb1.numpy(), g["emb_single0"], rtol=2e-4, atol=2e-4)
+
+
+def test_distances_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "matching.npz"))
+    np.testing.assert_allclose(matching.euclidean_dist(g["x"], g["y"]), g["euclid"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(matching.cosine_dist(g["x"], g["y"]), g["cosine"], rtol=1e-5, atol=1e-6)
+    assert g["euclid"][3, 5] < 1e-2          # duplicate row: clamp(1e-12).sqrt() branch region
+    # rank parity
+    assert (matching.euclidean_dist(g["x"], g["y"]).argmin(1) == g["euclid"].argmin(1)).all()
+
+
+def test_evaluate_all_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "matching.npz"))
+    cmc, ap = matching.evaluate_all(g["ev_qf"], g["ev_ql"], g["ev_qc"], g["ev_gf"], g["ev_gl"], g["ev_gc"])
+    np.testing.assert_array_equal(cmc, g["ev_cmc"])
+    assert abs(ap - float(g["ev_map"])) < 1e-12
+
+
+def test_diou_matches_reference_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "matching.npz"))
+    demo = matching.diou([10, 12, 8, 9], [[9, 10, 9, 9], [8, 12, 9, 10], [10, 12, 9, 8]])
+    np.testing.assert_array_equal(demo, g["diou_demo"])
+    # the reference file's own __main__ prints these (iou_matching.py:50-53)
+    np.testing.assert_allclose(demo, [0.55627998, 0.62386364, 0.79691358], atol=5e-9)
+    got = np.stack([matching.diou(b, g["diou_cands"]) for b in g["diou_boxes"]], 0)
+    np.testing.assert_array_equal(got, g["diou"])
+    np.testing.assert_array_equal(1.0 - got, matching.diou_cost(g["diou_boxes"], g["diou_cands"]))
+
+
+def test_knn_contract():
+    rng = np.random.default_rng(0)
+    xb = rng.normal(size=(50, 16)).astype(np.float32)
+    xq = xb[:7] + 0.01 * rng.normal(size=(7, 16)).astype(np.float32)
+    d, i = matching.knn_l2sqr(xq, xb, 5)
+    assert (i[:, 0] == np.arange(7)).all() and (np.diff(d, axis=1) >= 0).all() and i.dtype == np.int32
+
+
+def test_preprocess_known_answers():
+    # (i) identity when the crop is already 128x256: 2*(x/255)-1 transposed to CHW (feature_extractor.py:40-46)
+    c = synth.crops_u8(2, 3)
+    out = matching.preprocess(list(c))
+    ref = np.transpose((c.astype(np.float32) / np.float32(255) - np.float32(0.5)) / np.float32(0.5), (0, 3, 1, 2))
+    np.testing.assert_array_equal(out, ref)
+    np.testing.assert_array_equal(out, seres18.preprocess_u8(c).numpy())
+    # (ii) half-pixel-centre bilinear 2x2 -> 4x4 ramp (hand-computed: taps 0.25/0.75, edges clamped)
+    img = np.asarray([[0.0, 1.0], [2.0, 3.0]], np.float32)[:, :, None]
+    got = matching.resize_bilinear(img, (4, 4))[:, :, 0]
+    row = np.asarray([0.0, 0.25, 0.75, 1.0], np.float32)
+    exp = np.asarray([row, row + 0.5, row + 1.5, row + 2.0], np.float32)
+    np.testing.assert_allclose(got, exp, atol=1e-7)
+    # (iii) downscale 4 -> 2 without antialias: samples at 0.5 and 2.5 -> mean of neighbours
+    ramp = np.arange(4, dtype=np.float32)[None, :, None].repeat(4, 0)
+    np.testing.assert_allclose(matching.resize_bilinear(ramp, (2, 2))[:, :, 0], [[0.5, 2.5], [0.5, 2.5]], atol=1e-7)
