@@ -1,0 +1,151 @@
+/*
+ * reid_hip.h - C ABI of the MI355X (gfx950) re-ID embedding-and-matching engine.
+ *
+ * The reference (SuperbTUM/real-time-ReID-tracking) is pure Python and has no FFI
+ * of its own; the entry points below are what a binding for its DeepSORT hot
+ * path needs.  Each one cites the reference interface it
+ * replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - every function returns 0 (REID_OK) or a negative reid_status; the message
+ *     for the calling thread is available from reid_last_error().
+ *   - "host" entry points take plain host pointers, stage through library-owned
+ *     device buffers and return after the result is in the caller's memory.
+ *   - "_dev" entry points take device pointers (hipMalloc / torch.Tensor.data_ptr()),
+ *     enqueue on the context's stream and return without synchronising.
+ *   - outputs are caller-allocated; the library never frees caller memory.
+ *   - one context per (process, device); a context is not thread-safe (the
+ *     reference's caller is single-threaded: feature_extractor.py:48-53).
+ *   - layouts: crops are NHWC uint8 (the DeepSORT caller's HxWx3 arrays);
+ *     float images are NCHW fp32 (torch convention of the plugin surface);
+ *     matrices are row-major fp32.
+ */
+#ifndef REID_HIP_H
+#define REID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct reid_ctx reid_ctx;
+
+enum reid_status {
+    REID_OK = 0,
+    REID_ERR_ARG = -1,     /* bad argument (null pointer, bad size, unknown metric) */
+    REID_ERR_HIP = -2,     /* a HIP runtime call failed */
+    REID_ERR_STATE = -3,   /* e.g. embed before weights were loaded */
+    REID_ERR_NOMEM = -4
+};
+
+/* distance definitions (metric argument) */
+enum reid_metric {
+    REID_METRIC_L2 = 0,        /* sqrt(clamp(|x|^2+|y|^2-2x.y, 1e-12))   reid/losses/utils.py:21-35 euclidean_dist */
+    REID_METRIC_L2SQR = 1,     /* |x|^2+|y|^2-2x.y                        faiss METRIC_L2, reid/faiss_utils.py:56-118 */
+    REID_METRIC_COS_HALF = 2,  /* (1 - x.y/(|x||y|))/2                    reid/losses/utils.py:12-18 cosine_dist */
+    REID_METRIC_COS = 3,       /* 1 - x.y/(|x||y|)                        DeepSORT nn_matching cosine (MAX_DIST, deep_sort.yaml:3) */
+    REID_METRIC_DOT = 4        /* x.y (similarity)                        reid/evaluate.py:58 score = gf @ q */
+};
+
+/* kernel classes for reid_profile_get() */
+enum reid_kernel_kind {
+    REID_K_CONV_GEMM = 0,   /* implicit-GEMM convolutions (the dominant kernel of the embed path) */
+    REID_K_DIST_GEMM = 1,   /* N x M distance-matrix GEMM */
+    REID_K_ELEMENTWISE = 2, /* norm / SE / pool / combine kernels */
+    REID_K_SELECT = 3,      /* argmin / top-k / rank counting */
+    REID_K_COUNT = 4
+};
+
+/* ---- runtime ---------------------------------------------------------------------------- */
+const char* reid_last_error(void);
+int reid_device_count(int* n);
+/* one context per process and device; replaces `self.device` / `.to(device)` of feature_extractor.py:17,22 */
+int reid_ctx_create(int device, reid_ctx** out);
+int reid_ctx_destroy(reid_ctx* ctx);
+/* run on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own stream */
+int reid_ctx_set_stream(reid_ctx* ctx, void* hip_stream);
+int reid_ctx_sync(reid_ctx* ctx);
+/* crops per pass through the network (activation working set = chunk * 3.2 MB, kept inside the 256 MiB Infinity Cache) */
+int reid_ctx_set_chunk(reid_ctx* ctx, int crops_per_pass);
+/* arithmetic of the convolution GEMMs: 0 = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = fp16 inputs / fp32 accumulate */
+int reid_ctx_set_precision(reid_ctx* ctx, int mode);
+
+/* device memory for hosts without torch */
+int reid_malloc(reid_ctx* ctx, size_t bytes, void** dptr);
+int reid_free(reid_ctx* ctx, void* dptr);
+int reid_memcpy_h2d(reid_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int reid_memcpy_d2h(reid_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* HIP-event timing on the context's stream (bench.py) */
+int reid_timer_start(reid_ctx* ctx);
+int reid_timer_stop(reid_ctx* ctx, float* elapsed_ms);      /* records, synchronises, returns elapsed */
+/* per-kernel-class timing: when enabled every launch of the class is bracketed by HIP events */
+int reid_profile_enable(reid_ctx* ctx, int on);
+int reid_profile_reset(reid_ctx* ctx);
+int reid_profile_get(reid_ctx* ctx, int kind, double* total_ms, long long* launches, double* flops, double* bytes);
+
+/* ---- weights ----------------------------------------------------------------------------- */
+/* Packed ResNet18-IBN-SE weights (reid_amd.weights.pack_seres18): one fp32 blob plus a text manifest of
+ * "name offset count" lines.  Replaces torch.load + load_state_dict(strict=False), feature_extractor.py:18-19,
+ * and load_pretrained_weights, modification_tracking/reid_model_factory.py:158-210. */
+int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floats, const char* manifest);
+int reid_seres18_dims(reid_ctx* ctx, int* embed_dim, int* num_class);
+
+/* ---- embedding: Extractor.__call__, feature_extractor.py:48-53; SERse18_IBN.forward, SERes18_IBN.py:250-276 */
+/* n crops already at 128x256: uint8[n][256][128][3] -> emb fp32[n][512] (BNNeck output), logits fp32[n][num_class] or NULL */
+int reid_embed_u8(reid_ctx* ctx, const uint8_t* crops_nhwc, int n, float* emb, float* logits);
+int reid_embed_u8_dev(reid_ctx* ctx, const uint8_t* d_crops_nhwc, int n, float* d_emb, float* d_logits);
+/* crops of arbitrary size (feature_extractor.py:31-46 _preprocess: /255, bilinear resize to 128x256, (x-0.5)/0.5):
+ * packed = concatenated HxWx3 uint8 images, offsets[i] = byte offset of crop i, hw[2i],hw[2i+1] = its height,width */
+int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
+                         float* emb, float* logits);
+/* normalised float images, fp32[n][3][256][128] NCHW: the model(im_batch) call of the plugin surface
+ * (modification_tracking/models/__init__.py:93-121 returned object) */
+int reid_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, float* emb, float* logits);
+int reid_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, float* d_emb, float* d_logits);
+/* intermediate activation of the last embed call, for stage-level parity tests:
+ * stage 0 = stem conv+BN [n][128][64][64], 1 = maxpool [n][64][32][64], 2..9 = SE blocks 11..42 (NHWC), 10 = GeM [n][512].
+ * Only valid when n <= chunk and after reid_ctx_set_debug_keep(ctx, 1).  Copies up to max_floats and returns the stage's element count in *count. */
+int reid_ctx_set_debug_keep(reid_ctx* ctx, int on);   /* give every stage its own buffer (tests only) */
+int reid_debug_stage(reid_ctx* ctx, int stage, float* out_host, size_t max_floats, size_t* count);
+
+/* ---- matching ----------------------------------------------------------------------------- */
+/* out[m][n] = metric(x[m][d], y[n][d])        reid/losses/utils.py:12-35, reid/evaluate.py:58 */
+int reid_distmat(reid_ctx* ctx, const float* x, int m, const float* y, int n, int d, int metric, float* out);
+int reid_distmat_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric, float* d_out);
+/* per-row minimum of the distance matrix without returning the matrix; ties -> lowest column index */
+int reid_argmin_rows(reid_ctx* ctx, const float* x, int m, const float* y, int n, int d, int metric,
+                     int32_t* idx, float* val);
+int reid_argmin_rows_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric,
+                         int32_t* d_idx, float* d_val);
+/* brute-force squared-L2 k-NN: D fp32[nq][k] ascending, I int32[nq][k]; ties -> lowest index.
+ * search_raw_array_pytorch / IndexFlatL2.search, reid/faiss_utils.py:56-139 */
+int reid_knn(reid_ctx* ctx, const float* xq, int nq, const float* xb, int nb, int d, int k, float* D, int32_t* I);
+int reid_knn_dev(reid_ctx* ctx, const float* d_xq, int nq, const float* d_xb, int nb, int d, int k,
+                 float* d_D, int32_t* d_I);
+/* DIoU of one tlwh box against m candidates, fp64, bit-exact with numpy   modification_deepsort/iou_matching.py:5-47 */
+int reid_diou(reid_ctx* ctx, const double* box4, const double* cand_m4, int m, double* out_m);
+/* cost[t][m] = 1 - DIoU(tracks[t], dets[m])   ([external] deep_sort iou_cost loop over iou()) */
+int reid_diou_cost(reid_ctx* ctx, const double* tracks_t4, int t, const double* dets_m4, int m, double* out_tm);
+/* retrieval evaluation, reid/evaluate.py:33-105: for every query the ranks of its good gallery items among
+ * non-junk items (descending similarity gf@q).  cmc_sum int32[ng] = sum over valid queries of the CMC step,
+ * ap double[nq], valid int32[nq] (0 when the query has no good item). */
+int reid_rank_eval(reid_ctx* ctx, const float* qf, const int64_t* ql, const int64_t* qc, int nq,
+                   const float* gf, const int64_t* gl, const int64_t* gc, int ng, int d,
+                   int32_t* cmc_sum, double* ap, int32_t* valid);
+
+/* ---- single operators (unit tests and reuse by other backbones) --------------------------- */
+/* NHWC convolution, weights [Cout][R][S][Cin], optional per-channel scale/shift, residual (same shape as out), ReLU */
+int reid_conv2d_nhwc(reid_ctx* ctx, const float* x, int n, int h, int w, int cin, const float* wgt, int cout, int r,
+                     int s, int stride, int pad, const float* scale, const float* shift, const float* residual,
+                     int relu, float* out);
+/* C[m][n] = A[m][k] . B[n][k]^T (+ bias[n]) */
+int reid_gemm_nt(reid_ctx* ctx, const float* a, int m, const float* b, int n, int k, const float* bias, float* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REID_HIP_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of libreid_hip.so (C ABI: include/reid_hip.h).
+
+``cffi`` is not installed in the target image; ctypes speaks the same C ABI.
+There is no CPU fallback: if the shared library is missing the import of this
+module raises, and so does every product entry point built on it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libreid_hip.so")
+
+METRIC_L2, METRIC_L2SQR, METRIC_COS_HALF, METRIC_COS, METRIC_DOT = range(5)
+K_CONV_GEMM, K_DIST_GEMM, K_ELEMENTWISE, K_SELECT = range(4)
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_SIGS = {
+    "reid_last_error": (C.c_char_p, []),
+    "reid_device_count": (_i, [C.POINTER(_i)]),
+    "reid_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "reid_ctx_destroy": (_i, [_vp]),
+    "reid_ctx_set_stream": (_i, [_vp, _vp]),
+    "reid_ctx_sync": (_i, [_vp]),
+    "reid_ctx_set_chunk": (_i, [_vp, _i]),
+    "reid_ctx_set_precision": (_i, [_vp, _i]),
+    "reid_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "reid_free": (_i, [_vp, _vp]),
+    "reid_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "reid_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "reid_timer_start": (_i, [_vp]),
+    "reid_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "reid_profile_enable": (_i, [_vp, _i]),
+    "reid_profile_reset": (_i, [_vp]),
+    "reid_profile_get": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
+                              C.POINTER(C.c_double)]),
+    "reid_seres18_load": (_i, [_vp, _vp, _sz, C.c_char_p]),
+    "reid_seres18_dims": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "reid_embed_u8": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "reid_embed_u8_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "reid_embed_ragged_u8": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "reid_embed_f32_nchw": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "reid_embed_f32_nchw_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "reid_ctx_set_debug_keep": (_i, [_vp, _i]),
+    "reid_debug_stage": (_i, [_vp, _i, _vp, _sz, C.POINTER(_sz)]),
+    "reid_distmat": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "reid_distmat_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "reid_argmin_rows": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "reid_argmin_rows_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "reid_knn": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "reid_knn_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "reid_diou": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "reid_diou_cost": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "reid_rank_eval": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "reid_conv2d_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "reid_gemm_nt": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+}
+EXPORTS = tuple(sorted(_SIGS))
+
+_lib = None
+
+
+class ReidHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libreid_hip.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ReidHipError(
+                "HIP extension missing: %s (build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C real-time-reid-tracking_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        msg = lib().reid_last_error()
+        raise ReidHipError("libreid_hip status %d: %s" % (status, msg.decode() if msg else "?"))

@@ -1,0 +1,802 @@
+// C ABI of libreid_hip.so (include/reid_hip.h): context, weights, the ResNet18-IBN-SE launch sequence,
+// distance / selection entry points.  No torch types, no CPU compute fallback: every result comes from a HIP kernel.
+#include "reid_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <sstream>
+
+static thread_local char g_err[1024] = "";
+
+void reid_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* reid_last_error(void) { return g_err; }
+
+extern "C" int reid_device_count(int* n) {
+    ARG_CHECK(n);
+    HIP_TRY(hipGetDeviceCount(n));
+    return REID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ context
+extern "C" int reid_ctx_create(int device, reid_ctx** out) {
+    ARG_CHECK(out);
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) {
+        reid_set_error("reid_ctx_create: device %d not available (%d visible)", device, n);
+        return REID_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    reid_ctx* c = new reid_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipEventCreate(&c->t0));
+    HIP_TRY(hipEventCreate(&c->t1));
+    *out = c;
+    return REID_OK;
+}
+
+extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
+    if (!ctx) return REID_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->ws) hipFree(kv.second.first);
+    if (ctx->se18.blob) hipFree(ctx->se18.blob);
+    for (auto& e : ctx->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& p : ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    hipEventDestroy(ctx->t0);
+    hipEventDestroy(ctx->t1);
+    hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return REID_OK;
+}
+
+extern "C" int reid_ctx_set_stream(reid_ctx* ctx, void* s) {
+    ARG_CHECK(ctx);
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return REID_OK;
+}
+
+extern "C" int reid_ctx_sync(reid_ctx* ctx) {
+    ARG_CHECK(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+extern "C" int reid_ctx_set_chunk(reid_ctx* ctx, int n) {
+    ARG_CHECK(ctx && n >= 1 && n <= 1024);
+    ctx->chunk = n;
+    return REID_OK;
+}
+
+extern "C" int reid_ctx_set_precision(reid_ctx* ctx, int mode) {
+    ARG_CHECK(ctx);
+    if (mode != 0) {
+        reid_set_error("reid_ctx_set_precision: only mode 0 (exact fp32 MFMA) is built in this version");
+        return REID_ERR_ARG;
+    }
+    ctx->precision = mode;
+    return REID_OK;
+}
+
+extern "C" int reid_ctx_set_debug_keep(reid_ctx* ctx, int on) {
+    ARG_CHECK(ctx);
+    ctx->debug_keep = on != 0;
+    return REID_OK;
+}
+
+int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out) {
+    auto it = ctx->ws.find(name);
+    if (it != ctx->ws.end() && it->second.second >= bytes) {
+        *out = it->second.first;
+        return REID_OK;
+    }
+    if (it != ctx->ws.end()) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(it->second.first));
+        ctx->ws.erase(it);
+    }
+    void* p = nullptr;
+    size_t cap = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) {
+        reid_set_error("hipMalloc(%zu) for workspace '%s' failed: %s", cap, name, hipGetErrorString(e));
+        return REID_ERR_NOMEM;
+    }
+    ctx->ws[name] = {p, cap};
+    *out = p;
+    return REID_OK;
+}
+
+extern "C" int reid_malloc(reid_ctx* ctx, size_t bytes, void** dptr) {
+    ARG_CHECK(ctx && dptr);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        reid_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return REID_ERR_NOMEM;
+    }
+    return REID_OK;
+}
+extern "C" int reid_free(reid_ctx* ctx, void* dptr) {
+    ARG_CHECK(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(dptr));
+    return REID_OK;
+}
+extern "C" int reid_memcpy_h2d(reid_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ARG_CHECK(ctx && dst && src);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+extern "C" int reid_memcpy_d2h(reid_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ARG_CHECK(ctx && dst && src);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ timing
+extern "C" int reid_timer_start(reid_ctx* ctx) {
+    ARG_CHECK(ctx);
+    HIP_TRY(hipEventRecord(ctx->t0, ctx->stream));
+    return REID_OK;
+}
+extern "C" int reid_timer_stop(reid_ctx* ctx, float* ms) {
+    ARG_CHECK(ctx && ms);
+    HIP_TRY(hipEventRecord(ctx->t1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->t1));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+    return REID_OK;
+}
+
+void prof_begin(reid_ctx* ctx, int kind, double flops, double bytes) {
+    if (!ctx->profile) return;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!ctx->ev_pool.empty()) {
+        ev = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+    } else {
+        hipEventCreate(&ev.first);
+        hipEventCreate(&ev.second);
+    }
+    hipEventRecord(ev.first, ctx->stream);
+    ctx->pending.push_back({kind, ev.first, ev.second, flops, bytes});
+}
+void prof_end(reid_ctx* ctx) {
+    if (!ctx->profile || ctx->pending.empty()) return;
+    hipEventRecord(ctx->pending.back().b, ctx->stream);
+}
+static int prof_drain(reid_ctx* ctx) {
+    if (ctx->pending.empty()) return REID_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto& p : ctx->pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        ProfSlot& s = ctx->prof[p.kind];
+        s.ms += ms;
+        s.flops += p.flops;
+        s.bytes += p.bytes;
+        s.launches += 1;
+        ctx->ev_pool.push_back({p.a, p.b});
+    }
+    ctx->pending.clear();
+    return REID_OK;
+}
+extern "C" int reid_profile_enable(reid_ctx* ctx, int on) {
+    ARG_CHECK(ctx);
+    REID_TRY(prof_drain(ctx));
+    ctx->profile = on != 0;
+    return REID_OK;
+}
+extern "C" int reid_profile_reset(reid_ctx* ctx) {
+    ARG_CHECK(ctx);
+    REID_TRY(prof_drain(ctx));
+    for (auto& s : ctx->prof) s = ProfSlot();
+    return REID_OK;
+}
+extern "C" int reid_profile_get(reid_ctx* ctx, int kind, double* ms, long long* launches, double* flops, double* bytes) {
+    ARG_CHECK(ctx && kind >= 0 && kind < REID_K_COUNT);
+    REID_TRY(prof_drain(ctx));
+    if (ms) *ms = ctx->prof[kind].ms;
+    if (launches) *launches = ctx->prof[kind].launches;
+    if (flops) *flops = ctx->prof[kind].flops;
+    if (bytes) *bytes = ctx->prof[kind].bytes;
+    return REID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+static const int kBlkC[8] = {64, 64, 128, 128, 256, 256, 512, 512};
+static const int kBlkCin[8] = {64, 64, 64, 128, 128, 256, 256, 512};
+static const int kBlkStride[8] = {1, 1, 2, 1, 2, 1, 1, 1};  // block41: last stride forced to 1 (SERes18_IBN.py:99-101)
+static const int kBlkIbn[8] = {1, 1, 1, 1, 1, 1, 0, 0};
+static const int kBlkDs[8] = {0, 0, 1, 0, 1, 0, 1, 0};
+static const char* kBlkName[8] = {"b11", "b12", "b21", "b22", "b31", "b32", "b41", "b42"};
+
+extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floats, const char* manifest) {
+    ARG_CHECK(ctx && blob && manifest && n_floats > 0);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::map<std::string, std::pair<size_t, size_t>> tab;
+    {
+        std::istringstream in(manifest);
+        std::string name;
+        size_t off, cnt;
+        while (in >> name >> off >> cnt) {
+            if (off + cnt > n_floats) {
+                reid_set_error("manifest entry '%s' [%zu,+%zu) exceeds blob of %zu floats", name.c_str(), off, cnt, n_floats);
+                return REID_ERR_ARG;
+            }
+            if (off % 4 != 0) {
+                reid_set_error("manifest entry '%s' is not 16-byte aligned", name.c_str());
+                return REID_ERR_ARG;
+            }
+            tab[name] = {off, cnt};
+        }
+    }
+    Se18Weights& w = ctx->se18;
+    if (w.blob) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(w.blob));
+        w = Se18Weights();
+    }
+    HIP_TRY(hipMalloc((void**)&w.blob, n_floats * sizeof(float)));
+    HIP_TRY(hipMemcpy(w.blob, blob, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    w.n_floats = n_floats;
+    bool missing = false;
+    std::string first_missing;
+    auto get = [&](const std::string& name, size_t expect) -> const float* {
+        auto it = tab.find(name);
+        if (it == tab.end() || (expect && it->second.second != expect)) {
+            if (!missing) first_missing = name;
+            missing = true;
+            return nullptr;
+        }
+        return w.blob + it->second.first;
+    };
+    w.stem_w = get("stem.w", 64 * 192);
+    w.stem_scale = get("stem.scale", 64);
+    w.stem_shift = get("stem.shift", 64);
+    for (int i = 0; i < 8; ++i) {
+        Se18Block& b = w.blk[i];
+        const std::string n = kBlkName[i];
+        b.c = kBlkC[i]; b.cin = kBlkCin[i]; b.stride = kBlkStride[i]; b.ibn = kBlkIbn[i]; b.ds = kBlkDs[i];
+        b.mid = b.c / 16 > 8 ? b.c / 16 : 8;  // SERes18_IBN.py:17
+        const int half = b.ibn ? b.c / 2 : 0;
+        b.conv1_w = get(n + ".conv1.w", (size_t)b.c * 9 * b.cin);
+        b.in_gamma = b.ibn ? get(n + ".n1.in_gamma", half) : nullptr;
+        b.in_beta = b.ibn ? get(n + ".n1.in_beta", half) : nullptr;
+        b.bn1_scale = get(n + ".n1.bn_scale", b.c - half);
+        b.bn1_shift = get(n + ".n1.bn_shift", b.c - half);
+        b.conv2_w = get(n + ".conv2.w", (size_t)b.c * 9 * b.c);
+        b.bn2_scale = get(n + ".bn2.scale", b.c);
+        b.bn2_shift = get(n + ".bn2.shift", b.c);
+        b.ds_w = b.ds ? get(n + ".ds.w", (size_t)b.c * b.cin) : nullptr;
+        b.ds_scale = b.ds ? get(n + ".ds.scale", b.c) : nullptr;
+        b.ds_shift = b.ds ? get(n + ".ds.shift", b.c) : nullptr;
+        b.se_w1 = get(n + ".se.w1", (size_t)b.mid * b.c);
+        b.se_w2 = get(n + ".se.w2", (size_t)b.c * b.mid);
+    }
+    w.gem_p = get("gem.p", 1);
+    w.neck_scale = get("neck.scale", 512);
+    w.neck_shift = get("neck.shift", 512);
+    auto cls = tab.find("cls.w");
+    if (cls != tab.end() && cls->second.second % 512 == 0) {
+        w.cls_w = w.blob + cls->second.first;
+        w.num_class = (int)(cls->second.second / 512);
+    } else {
+        w.cls_w = nullptr;
+        w.num_class = 0;
+    }
+    if (missing) {
+        reid_set_error("reid_seres18_load: manifest entry '%s' missing or of unexpected size", first_missing.c_str());
+        HIP_TRY(hipFree(w.blob));
+        w = Se18Weights();
+        return REID_ERR_ARG;
+    }
+    w.loaded = true;
+    return REID_OK;
+}
+
+extern "C" int reid_seres18_dims(reid_ctx* ctx, int* embed_dim, int* num_class) {
+    ARG_CHECK(ctx);
+    if (!ctx->se18.loaded) {
+        reid_set_error("no weights loaded");
+        return REID_ERR_STATE;
+    }
+    if (embed_dim) *embed_dim = 512;
+    if (num_class) *num_class = ctx->se18.num_class;
+    return REID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+static const int IMG_H = 256, IMG_W = 128;
+
+static int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
+                     int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
+                     const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats,
+                     float* out) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = x;
+    p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.Ho = (H + 2 * pad - R) / stride + 1;
+    p.Wo = (W + 2 * pad - S) / stride + 1;
+    p.a_scale = a_scale; p.a_shift = a_shift; p.a_relu = a_relu;
+    p.B = wgt; p.ldb = Kpad;
+    p.M = n * p.Ho * p.Wo; p.N = Cout; p.K = Kpad;
+    p.C = out; p.ldc = Cout;
+    p.col_scale = col_scale; p.col_shift = col_shift; p.residual = residual; p.relu = relu; p.stats = stats;
+    const double ktrue = (double)R * S * Cin;
+    const double flops = 2.0 * p.M * Cout * ktrue;
+    const double in_bytes = (double)n * H * W * Cin * (amode == A_STEM_U8 ? 1.0 : 4.0);
+    const double bytes = in_bytes + ((double)p.M * Cout + (double)Cout * ktrue) * 4.0 + (residual ? (double)p.M * Cout * 4.0 : 0.0);
+    return launch_gemm_f32(ctx, amode, E_CONV, p, REID_K_CONV_GEMM, flops, bytes);
+}
+
+struct Se18Bufs {
+    float *stem, *pool, *t[4], *stats, *a_scale, *a_shift, *se, *gem;
+    float* stage[11];
+};
+
+// x: uint8 NHWC crops (is_u8) or fp32 NHWC, both [n][256][128][3] on the device
+static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, float* d_emb, float* d_logits) {
+    Se18Weights& w = ctx->se18;
+    if (!w.loaded) {
+        reid_set_error("reid_embed_*: call reid_seres18_load first");
+        return REID_ERR_STATE;
+    }
+    Se18Bufs b;
+    const size_t per = 131072;  // largest block tensor per crop (64 x 32 x 64)
+    const bool keep = ctx->debug_keep;
+    REID_TRY(ctx_ws(ctx, "se18.stem", (size_t)n * 524288 * 4, (void**)&b.stem));
+    REID_TRY(ctx_ws(ctx, "se18.pool", (size_t)n * per * 4, (void**)&b.pool));
+    const int nt = keep ? 1 : 4;
+    float* tbase = nullptr;
+    REID_TRY(ctx_ws(ctx, "se18.t", (size_t)n * per * 4 * (keep ? 4 * 8 : 4), (void**)&tbase));
+    REID_TRY(ctx_ws(ctx, "se18.stats", (size_t)n * 2048 * 4, (void**)&b.stats));
+    REID_TRY(ctx_ws(ctx, "se18.ascale", (size_t)n * 512 * 4, (void**)&b.a_scale));
+    REID_TRY(ctx_ws(ctx, "se18.ashift", (size_t)n * 512 * 4, (void**)&b.a_shift));
+    REID_TRY(ctx_ws(ctx, "se18.se", (size_t)n * 512 * 4, (void**)&b.se));
+    REID_TRY(ctx_ws(ctx, "se18.gem", (size_t)n * 512 * 4, (void**)&b.gem));
+    (void)nt;
+
+    // stem: conv7x7 s2 p3 + BN, no ReLU (SERes18_IBN.py:251-253), then MaxPool2d(3,2,1) (:254)
+    REID_TRY(conv_gemm(ctx, is_u8 ? A_STEM_U8 : A_STEM_F32, x, n, IMG_H, IMG_W, 3, w.stem_w, 64, 7, 7, 2, 3, 192, nullptr,
+                       nullptr, 0, w.stem_scale, w.stem_shift, nullptr, 0, nullptr, b.stem));
+    REID_TRY(launch_maxpool3s2(ctx, b.stem, n, 128, 64, 64, b.pool));
+    b.stage[0] = b.stem;
+    b.stage[1] = b.pool;
+
+    const float* cur = b.pool;
+    int H = 64, W = 32;
+    for (int i = 0; i < 8; ++i) {
+        const Se18Block& k = w.blk[i];
+        // four rotating buffers; in debug-keep mode every block gets its own four
+        float* tb[4];
+        for (int j = 0; j < 4; ++j) tb[j] = tbase + ((size_t)(keep ? i * 4 : 0) + j) * n * per;
+        // pick buffers that do not alias the block input
+        float* free_[3];
+        int nf = 0;
+        for (int j = 0; j < 4 && nf < 3; ++j)
+            if (tb[j] != cur) free_[nf++] = tb[j];
+        float* c1 = free_[0];
+        float* y = free_[1];
+        float* sc = free_[2];
+        const int Ho = (H + 2 - 3) / k.stride + 1, Wo = (W + 2 - 3) / k.stride + 1;
+        const int hw = Ho * Wo, tiles = hw / 128;
+        const int half = k.ibn ? k.c / 2 : 0;
+        // conv1 (raw) + per-(image, channel) sum / sumsq partials for the InstanceNorm half
+        REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr, 0,
+                           nullptr, nullptr, nullptr, 0, b.stats, c1));
+        REID_TRY(launch_norm_finalize(ctx, b.stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift,
+                                      b.a_scale, b.a_shift));
+        // conv2 with IBN/BN + ReLU fused into its loader; BN2 (+ identity residual + ReLU for blocks without
+        // downsample: block_pre is the whole BasicBlock_IBN) and SE average-pool partials in its epilogue
+        REID_TRY(conv_gemm(ctx, A_IM2COL, c1, n, Ho, Wo, k.c, k.conv2_w, k.c, 3, 3, 1, 1, 9 * k.c, b.a_scale, b.a_shift, 1,
+                           k.bn2_scale, k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, b.stats, y));
+        const float* shortcut = cur;
+        if (k.ds) {
+            REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.ds_w, k.c, 1, 1, k.stride, 0, k.cin, nullptr, nullptr, 0,
+                               k.ds_scale, k.ds_shift, nullptr, 0, nullptr, sc));
+            shortcut = sc;
+        }
+        REID_TRY(launch_se_finalize(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, b.se));
+        float* out = c1;  // conv1 output is dead after conv2
+        REID_TRY(launch_se_combine(ctx, y, shortcut, b.se, n, hw, k.c, out));
+        b.stage[2 + i] = out;
+        cur = out;
+        H = Ho;
+        W = Wo;
+    }
+    REID_TRY(launch_gem_neck(ctx, cur, n, H * W, 512, w.gem_p, w.neck_scale, w.neck_shift, b.gem, d_emb));
+    b.stage[10] = b.gem;
+    if (d_logits) {
+        if (!w.cls_w) {
+            reid_set_error("logits requested but the weight blob has no classifier (cls.w)");
+            return REID_ERR_STATE;
+        }
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.A = d_emb; p.lda = 512;
+        p.B = w.cls_w; p.ldb = 512;
+        p.M = n; p.N = w.num_class; p.K = 512;
+        p.C = d_logits; p.ldc = w.num_class;
+        REID_TRY(launch_gemm_f32(ctx, A_DENSE, E_BIAS, p, REID_K_CONV_GEMM, 2.0 * n * w.num_class * 512,
+                                 ((double)n * 512 + (double)w.num_class * 512 + (double)n * w.num_class) * 4.0));
+    }
+    ctx->last_n = n;
+    for (int s = 0; s < 11; ++s) ctx->stage_ptr[s] = b.stage[s];
+    return REID_OK;
+}
+
+static const size_t kStageElems[11] = {524288, 131072, 131072, 131072, 65536, 65536, 32768, 32768, 65536, 65536, 512};
+
+extern "C" int reid_debug_stage(reid_ctx* ctx, int stage, float* out, size_t max_floats, size_t* count) {
+    ARG_CHECK(ctx && stage >= 0 && stage < 11 && out);
+    if (!ctx->debug_keep || ctx->last_n <= 0) {
+        reid_set_error("reid_debug_stage: enable reid_ctx_set_debug_keep before the embed call");
+        return REID_ERR_STATE;
+    }
+    const size_t total = kStageElems[stage] * (size_t)ctx->last_n;
+    if (count) *count = total;
+    const size_t ncopy = total < max_floats ? total : max_floats;
+    HIP_TRY(hipMemcpyAsync(out, ctx->stage_ptr[stage], ncopy * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+extern "C" int reid_embed_u8_dev(reid_ctx* ctx, const uint8_t* d_crops, int n, float* d_emb, float* d_logits) {
+    ARG_CHECK(ctx && d_crops && d_emb && n >= 0);
+    const int nc = ctx->se18.num_class;
+    for (int i = 0; i < n; i += ctx->chunk) {
+        const int m = n - i < ctx->chunk ? n - i : ctx->chunk;
+        REID_TRY(seres18_forward(ctx, d_crops + (size_t)i * IMG_H * IMG_W * 3, true, m, d_emb + (size_t)i * 512,
+                                 d_logits ? d_logits + (size_t)i * nc : nullptr));
+    }
+    return REID_OK;
+}
+
+extern "C" int reid_embed_u8(reid_ctx* ctx, const uint8_t* crops, int n, float* emb, float* logits) {
+    ARG_CHECK(ctx && crops && emb && n >= 0);
+    if (n == 0) return REID_OK;
+    const int nc = ctx->se18.num_class;
+    uint8_t* d_in;
+    float *d_emb, *d_log = nullptr;
+    const size_t crop_b = (size_t)IMG_H * IMG_W * 3;
+    REID_TRY(ctx_ws(ctx, "io.in", (size_t)n * crop_b, (void**)&d_in));
+    REID_TRY(ctx_ws(ctx, "io.emb", (size_t)n * 512 * 4, (void**)&d_emb));
+    if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
+    HIP_TRY(hipMemcpyAsync(d_in, crops, (size_t)n * crop_b, hipMemcpyHostToDevice, ctx->stream));
+    REID_TRY(reid_embed_u8_dev(ctx, d_in, n, d_emb, d_log));
+    HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+extern "C" int reid_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, float* d_emb, float* d_logits) {
+    ARG_CHECK(ctx && d_x && d_emb && n >= 0);
+    const int nc = ctx->se18.num_class;
+    const size_t img = (size_t)IMG_H * IMG_W * 3;
+    for (int i = 0; i < n; i += ctx->chunk) {
+        const int m = n - i < ctx->chunk ? n - i : ctx->chunk;
+        float* nhwc;
+        REID_TRY(ctx_ws(ctx, "se18.in_nhwc", (size_t)m * img * 4, (void**)&nhwc));
+        REID_TRY(launch_nchw_to_nhwc3(ctx, d_x + (size_t)i * img, m, IMG_H, IMG_W, nhwc));
+        REID_TRY(seres18_forward(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_logits ? d_logits + (size_t)i * nc : nullptr));
+    }
+    return REID_OK;
+}
+
+extern "C" int reid_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, float* emb, float* logits) {
+    ARG_CHECK(ctx && x && emb && n >= 0);
+    if (n == 0) return REID_OK;
+    const int nc = ctx->se18.num_class;
+    const size_t img = (size_t)IMG_H * IMG_W * 3;
+    float *d_in, *d_emb, *d_log = nullptr;
+    REID_TRY(ctx_ws(ctx, "io.in", (size_t)n * img * 4, (void**)&d_in));
+    REID_TRY(ctx_ws(ctx, "io.emb", (size_t)n * 512 * 4, (void**)&d_emb));
+    if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
+    HIP_TRY(hipMemcpyAsync(d_in, x, (size_t)n * img * 4, hipMemcpyHostToDevice, ctx->stream));
+    REID_TRY(reid_embed_f32_nchw_dev(ctx, d_in, n, d_emb, d_log));
+    HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
+                                    float* emb, float* logits) {
+    ARG_CHECK(ctx && packed && offsets && hw && emb && n >= 0);
+    if (n == 0) return REID_OK;
+    const int nc = ctx->se18.num_class;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        ARG_CHECK(hw[2 * i] >= 1 && hw[2 * i + 1] >= 1 && offsets[i] >= 0);
+        const size_t end = (size_t)offsets[i] + (size_t)hw[2 * i] * hw[2 * i + 1] * 3;
+        if (end > total) total = end;
+    }
+    uint8_t* d_pk;
+    long long* d_off;
+    int* d_hw;
+    float *d_emb, *d_log = nullptr;
+    REID_TRY(ctx_ws(ctx, "io.in", total, (void**)&d_pk));
+    REID_TRY(ctx_ws(ctx, "io.off", (size_t)n * 8, (void**)&d_off));
+    REID_TRY(ctx_ws(ctx, "io.hw", (size_t)n * 8, (void**)&d_hw));
+    REID_TRY(ctx_ws(ctx, "io.emb", (size_t)n * 512 * 4, (void**)&d_emb));
+    if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
+    HIP_TRY(hipMemcpyAsync(d_pk, packed, total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_hw, hw, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    const size_t img = (size_t)IMG_H * IMG_W * 3;
+    for (int i = 0; i < n; i += ctx->chunk) {
+        const int m = n - i < ctx->chunk ? n - i : ctx->chunk;
+        float* nhwc;
+        REID_TRY(ctx_ws(ctx, "se18.in_nhwc", (size_t)m * img * 4, (void**)&nhwc));
+        REID_TRY(launch_resize_norm(ctx, d_pk, d_off + i, d_hw + 2 * i, m, IMG_H, IMG_W, nhwc));
+        REID_TRY(seres18_forward(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_log ? d_log + (size_t)i * nc : nullptr));
+    }
+    HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ matching
+// pads d to a multiple of 4 when needed (zero columns change neither dot products nor norms)
+static int pad_rows(reid_ctx* ctx, const char* name, const float* d_x, int m, int d, const float** out, int* ld) {
+    if (d % 4 == 0 && ((uintptr_t)d_x % 16) == 0) {
+        *out = d_x;
+        *ld = d;
+        return REID_OK;
+    }
+    const int dp = (d + 3) / 4 * 4;
+    float* buf;
+    REID_TRY(ctx_ws(ctx, name, (size_t)m * dp * 4, (void**)&buf));
+    HIP_TRY(hipMemsetAsync(buf, 0, (size_t)m * dp * 4, ctx->stream));
+    HIP_TRY(hipMemcpy2DAsync(buf, (size_t)dp * 4, d_x, (size_t)d * 4, (size_t)d * 4, m, hipMemcpyDeviceToDevice, ctx->stream));
+    *out = buf;
+    *ld = dp;
+    return REID_OK;
+}
+
+extern "C" int reid_distmat_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric,
+                                float* d_out) {
+    ARG_CHECK(ctx && d_x && d_y && d_out && m >= 0 && n >= 0 && d >= 1);
+    ARG_CHECK(metric >= REID_METRIC_L2 && metric <= REID_METRIC_DOT);
+    if (m == 0 || n == 0) return REID_OK;
+    const float *xp, *yp;
+    int ldx, ldy;
+    REID_TRY(pad_rows(ctx, "dist.xpad", d_x, m, d, &xp, &ldx));
+    REID_TRY(pad_rows(ctx, "dist.ypad", d_y, n, d, &yp, &ldy));
+    float *xx = nullptr, *yy = nullptr;
+    if (metric != REID_METRIC_DOT) {
+        REID_TRY(ctx_ws(ctx, "dist.xx", (size_t)m * 4, (void**)&xx));
+        REID_TRY(ctx_ws(ctx, "dist.yy", (size_t)n * 4, (void**)&yy));
+        REID_TRY(launch_row_sqnorm(ctx, xp, m, ldx, ldx, xx));
+        REID_TRY(launch_row_sqnorm(ctx, yp, n, ldy, ldy, yy));
+    }
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = xp; p.lda = ldx;
+    p.B = yp; p.ldb = ldy;
+    p.M = m; p.N = n; p.K = ldx;
+    p.C = d_out; p.ldc = n;
+    p.row_sq = xx; p.col_sq = yy; p.metric = metric;
+    return launch_gemm_f32(ctx, A_DENSE, E_DIST, p, REID_K_DIST_GEMM, 2.0 * m * n * d,
+                           4.0 * ((double)m * d + (double)n * d + (double)m * n));
+}
+
+struct HostIO {
+    reid_ctx* ctx;
+    float *dx = nullptr, *dy = nullptr;
+    int upload(const float* x, int m, const float* y, int n, int d) {
+        REID_TRY(ctx_ws(ctx, "io.x", (size_t)(m ? m : 1) * d * 4, (void**)&dx));
+        REID_TRY(ctx_ws(ctx, "io.y", (size_t)(n ? n : 1) * d * 4, (void**)&dy));
+        if (m) HIP_TRY(hipMemcpyAsync(dx, x, (size_t)m * d * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (n) HIP_TRY(hipMemcpyAsync(dy, y, (size_t)n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+        return REID_OK;
+    }
+};
+
+extern "C" int reid_distmat(reid_ctx* ctx, const float* x, int m, const float* y, int n, int d, int metric, float* out) {
+    ARG_CHECK(ctx && x && y && out && m >= 0 && n >= 0 && d >= 1);
+    if (m == 0 || n == 0) return REID_OK;
+    HostIO io{ctx};
+    REID_TRY(io.upload(x, m, y, n, d));
+    float* d_out;
+    REID_TRY(ctx_ws(ctx, "io.dist", (size_t)m * n * 4, (void**)&d_out));
+    REID_TRY(reid_distmat_dev(ctx, io.dx, m, io.dy, n, d, metric, d_out));
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)m * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+extern "C" int reid_argmin_rows_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric,
+                                    int32_t* d_idx, float* d_val) {
+    ARG_CHECK(ctx && d_idx && m >= 0 && n >= 1);
+    if (m == 0) return REID_OK;
+    float* dist;
+    REID_TRY(ctx_ws(ctx, "sel.dist", (size_t)m * n * 4, (void**)&dist));
+    REID_TRY(reid_distmat_dev(ctx, d_x, m, d_y, n, d, metric, dist));
+    return launch_argmin_rows(ctx, dist, m, n, n, d_idx, d_val);
+}
+
+extern "C" int reid_argmin_rows(reid_ctx* ctx, const float* x, int m, const float* y, int n, int d, int metric, int32_t* idx,
+                                float* val) {
+    ARG_CHECK(ctx && x && y && idx && m >= 0 && n >= 1 && d >= 1);
+    if (m == 0) return REID_OK;
+    HostIO io{ctx};
+    REID_TRY(io.upload(x, m, y, n, d));
+    int32_t* d_idx;
+    float* d_val;
+    REID_TRY(ctx_ws(ctx, "io.idx", (size_t)m * 4, (void**)&d_idx));
+    REID_TRY(ctx_ws(ctx, "io.val", (size_t)m * 4, (void**)&d_val));
+    REID_TRY(reid_argmin_rows_dev(ctx, io.dx, m, io.dy, n, d, metric, d_idx, d_val));
+    HIP_TRY(hipMemcpyAsync(idx, d_idx, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (val) HIP_TRY(hipMemcpyAsync(val, d_val, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+extern "C" int reid_knn_dev(reid_ctx* ctx, const float* d_xq, int nq, const float* d_xb, int nb, int d, int k, float* d_D,
+                            int32_t* d_I) {
+    ARG_CHECK(ctx && d_D && d_I && nq >= 0 && nb >= 1 && k >= 1);
+    if (nq == 0) return REID_OK;
+    // query tiles bound the scratch matrix to ~1 GiB
+    const int rows_per = (int)((size_t(1) << 28) / (size_t)nb) > 0 ? (int)((size_t(1) << 28) / (size_t)nb) : 1;
+    float* dist;
+    const int tile = nq < rows_per ? nq : rows_per;
+    REID_TRY(ctx_ws(ctx, "sel.dist", (size_t)tile * nb * 4, (void**)&dist));
+    for (int i = 0; i < nq; i += tile) {
+        const int m = nq - i < tile ? nq - i : tile;
+        REID_TRY(reid_distmat_dev(ctx, d_xq + (size_t)i * d, m, d_xb, nb, d, REID_METRIC_L2SQR, dist));
+        REID_TRY(launch_topk_rows(ctx, dist, m, nb, nb, k, d_D + (size_t)i * k, d_I + (size_t)i * k));
+    }
+    return REID_OK;
+}
+
+extern "C" int reid_knn(reid_ctx* ctx, const float* xq, int nq, const float* xb, int nb, int d, int k, float* D, int32_t* I) {
+    ARG_CHECK(ctx && xq && xb && D && I && nq >= 0 && nb >= 1 && d >= 1 && k >= 1);
+    if (nq == 0) return REID_OK;
+    HostIO io{ctx};
+    REID_TRY(io.upload(xq, nq, xb, nb, d));
+    float* d_D;
+    int32_t* d_I;
+    REID_TRY(ctx_ws(ctx, "io.knnD", (size_t)nq * k * 4, (void**)&d_D));
+    REID_TRY(ctx_ws(ctx, "io.knnI", (size_t)nq * k * 4, (void**)&d_I));
+    REID_TRY(reid_knn_dev(ctx, io.dx, nq, io.dy, nb, d, k, d_D, d_I));
+    HIP_TRY(hipMemcpyAsync(D, d_D, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(I, d_I, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+static int reid_diou_cost_impl(reid_ctx* ctx, const double* tracks, int t, const double* dets, int m, double* out,
+                                   int as_cost) {
+    ARG_CHECK(ctx && tracks && dets && out && t >= 0 && m >= 0);
+    if (t == 0 || m == 0) return REID_OK;
+    double *dt, *dd, *dout;
+    REID_TRY(ctx_ws(ctx, "diou.t", (size_t)t * 32, (void**)&dt));
+    REID_TRY(ctx_ws(ctx, "diou.d", (size_t)m * 32, (void**)&dd));
+    REID_TRY(ctx_ws(ctx, "diou.o", (size_t)t * m * 8, (void**)&dout));
+    HIP_TRY(hipMemcpyAsync(dt, tracks, (size_t)t * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dd, dets, (size_t)m * 32, hipMemcpyHostToDevice, ctx->stream));
+    REID_TRY(launch_diou_cost(ctx, dt, t, dd, m, dout, as_cost));
+    HIP_TRY(hipMemcpyAsync(out, dout, (size_t)t * m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+extern "C" int reid_diou(reid_ctx* ctx, const double* box4, const double* cand, int m, double* out) {
+    return reid_diou_cost_impl(ctx, box4, 1, cand, m, out, 0);
+}
+extern "C" int reid_diou_cost(reid_ctx* ctx, const double* tracks, int t, const double* dets, int m, double* out) {
+    return reid_diou_cost_impl(ctx, tracks, t, dets, m, out, 1);
+}
+
+extern "C" int reid_rank_eval(reid_ctx* ctx, const float* qf, const int64_t* ql, const int64_t* qc, int nq, const float* gf,
+                              const int64_t* gl, const int64_t* gc, int ng, int d, int32_t* cmc_sum, double* ap,
+                              int32_t* valid) {
+    ARG_CHECK(ctx && qf && ql && qc && gf && gl && gc && cmc_sum && ap && valid && nq >= 1 && ng >= 1 && d >= 1);
+    HostIO io{ctx};
+    REID_TRY(io.upload(qf, nq, gf, ng, d));
+    long long *dql, *dqc, *dgl, *dgc;
+    int32_t *dhist, *dvalid;
+    double* dap;
+    float* score;
+    REID_TRY(ctx_ws(ctx, "ev.ql", (size_t)nq * 8, (void**)&dql));
+    REID_TRY(ctx_ws(ctx, "ev.qc", (size_t)nq * 8, (void**)&dqc));
+    REID_TRY(ctx_ws(ctx, "ev.gl", (size_t)ng * 8, (void**)&dgl));
+    REID_TRY(ctx_ws(ctx, "ev.gc", (size_t)ng * 8, (void**)&dgc));
+    REID_TRY(ctx_ws(ctx, "ev.hist", (size_t)ng * 4, (void**)&dhist));
+    REID_TRY(ctx_ws(ctx, "ev.valid", (size_t)nq * 4, (void**)&dvalid));
+    REID_TRY(ctx_ws(ctx, "ev.ap", (size_t)nq * 8, (void**)&dap));
+    REID_TRY(ctx_ws(ctx, "sel.dist", (size_t)nq * ng * 4, (void**)&score));
+    HIP_TRY(hipMemcpyAsync(dql, ql, (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dqc, qc, (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dgl, gl, (size_t)ng * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dgc, gc, (size_t)ng * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(dhist, 0, (size_t)ng * 4, ctx->stream));
+    REID_TRY(reid_distmat_dev(ctx, io.dx, nq, io.dy, ng, d, REID_METRIC_DOT, score));
+    REID_TRY(launch_rank_eval(ctx, score, nq, ng, ng, dql, dqc, dgl, dgc, dhist, dap, dvalid));
+    HIP_TRY(hipMemcpyAsync(cmc_sum, dhist, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ap, dap, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(valid, dvalid, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < nq; ++q)
+        if (valid[q] < 0) {
+            reid_set_error("reid_rank_eval: query %d has more than 2048 good gallery items", q);
+            return REID_ERR_ARG;
+        }
+    // histogram of first-good ranks -> summed CMC step functions (cmc[rows_good[0]:] = 1, evaluate.py:95)
+    for (int j = 1; j < ng; ++j) cmc_sum[j] += cmc_sum[j - 1];
+    return REID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ single operators
+extern "C" int reid_conv2d_nhwc(reid_ctx* ctx, const float* x, int n, int h, int w, int cin, const float* wgt, int cout, int r,
+                                int s, int stride, int pad, const float* scale, const float* shift, const float* residual,
+                                int relu, float* out) {
+    ARG_CHECK(ctx && x && wgt && out && n >= 1 && cin % 32 == 0 && (scale == nullptr) == (shift == nullptr));
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - s) / stride + 1;
+    const size_t nin = (size_t)n * h * w * cin, nw = (size_t)cout * r * s * cin, nout = (size_t)n * ho * wo * cout;
+    float *dx, *dw, *dout, *dsc = nullptr, *dsh = nullptr, *dres = nullptr;
+    REID_TRY(ctx_ws(ctx, "op.x", nin * 4, (void**)&dx));
+    REID_TRY(ctx_ws(ctx, "op.w", nw * 4, (void**)&dw));
+    REID_TRY(ctx_ws(ctx, "op.out", nout * 4, (void**)&dout));
+    HIP_TRY(hipMemcpyAsync(dx, x, nin * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dw, wgt, nw * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (scale) {
+        REID_TRY(ctx_ws(ctx, "op.scale", (size_t)cout * 4, (void**)&dsc));
+        REID_TRY(ctx_ws(ctx, "op.shift", (size_t)cout * 4, (void**)&dsh));
+        HIP_TRY(hipMemcpyAsync(dsc, scale, (size_t)cout * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dsh, shift, (size_t)cout * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (residual) {
+        REID_TRY(ctx_ws(ctx, "op.res", nout * 4, (void**)&dres));
+        HIP_TRY(hipMemcpyAsync(dres, residual, nout * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    REID_TRY(conv_gemm(ctx, A_IM2COL, dx, n, h, w, cin, dw, cout, r, s, stride, pad, r * s * cin, nullptr, nullptr, 0, dsc, dsh,
+                       dres, relu, nullptr, dout));
+    HIP_TRY(hipMemcpyAsync(out, dout, nout * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+extern "C" int reid_gemm_nt(reid_ctx* ctx, const float* a, int m, const float* b, int n, int k, const float* bias, float* c) {
+    ARG_CHECK(ctx && a && b && c && m >= 1 && n >= 1 && k >= 1);
+    float *da, *db, *dc, *dbias = nullptr;
+    REID_TRY(ctx_ws(ctx, "op.x", (size_t)m * k * 4, (void**)&da));
+    REID_TRY(ctx_ws(ctx, "op.w", (size_t)n * k * 4, (void**)&db));
+    REID_TRY(ctx_ws(ctx, "op.out", (size_t)m * n * 4, (void**)&dc));
+    HIP_TRY(hipMemcpyAsync(da, a, (size_t)m * k * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db, b, (size_t)n * k * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (bias) {
+        REID_TRY(ctx_ws(ctx, "op.shift", (size_t)n * 4, (void**)&dbias));
+        HIP_TRY(hipMemcpyAsync(dbias, bias, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const float *ap, *bp;
+    int lda, ldb;
+    REID_TRY(pad_rows(ctx, "dist.xpad", da, m, k, &ap, &lda));
+    REID_TRY(pad_rows(ctx, "dist.ypad", db, n, k, &bp, &ldb));
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = ap; p.lda = lda;
+    p.B = bp; p.ldb = ldb;
+    p.M = m; p.N = n; p.K = lda;
+    p.C = dc; p.ldc = n;
+    p.col_shift = dbias;
+    REID_TRY(launch_gemm_f32(ctx, A_DENSE, E_BIAS, p, REID_K_CONV_GEMM, 2.0 * m * n * k,
+                             4.0 * ((double)m * k + (double)n * k + (double)m * n)));
+    HIP_TRY(hipMemcpyAsync(c, dc, (size_t)m * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}

@@ -1,0 +1,295 @@
+// HBM-bound kernels of the embed path: preprocessing, max-pool, InstanceNorm/BatchNorm finalisation,
+// squeeze-excite, SE combine, GeM + BNNeck, row norms.  All NHWC fp32, 16-byte accesses, wave64 shuffles.
+#include "reid_internal.h"
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- NCHW fp32 [n][3][h][w] -> NHWC [n][h][w][3] (plugin surface hands over torch-layout batches)
+__global__ void nchw_to_nhwc3_kernel(const float* __restrict__ x, long long npix, int hw, float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / hw;
+        const int p = (int)(i - img * hw);
+        const float* src = x + img * 3 * hw + p;
+        float* dst = out + i * 3;
+        dst[0] = src[0];
+        dst[1] = src[hw];
+        dst[2] = src[2 * hw];
+    }
+}
+
+// ---- Extractor._preprocess (feature_extractor.py:31-46): u8/255 -> bilinear resize (cv2 INTER_LINEAR: half-pixel
+// centres, edge clamp, no antialias, horizontal then vertical fp32 lerp) -> (x-0.5)/0.5, NHWC out.
+// Unfused mul/add (_rn intrinsics) so the result is bit-identical to the numpy oracle.
+__device__ __forceinline__ void lin_tap(int d, int dst, int src, int& s, float& f) {
+    const double scale = (double)src / (double)dst;
+    float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx = fx - (float)sx;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= src - 1) { sx = src - 1; fx = 0.f; }
+    s = sx;
+    f = fx;
+}
+__global__ void resize_norm_kernel(const uint8_t* __restrict__ packed, const long long* __restrict__ offsets,
+                                   const int* __restrict__ hw, int n, int H, int W, float* __restrict__ out) {
+    const long long total = (long long)n * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(i / (H * W));
+        const int rem = (int)(i - (long long)img * H * W);
+        const int dy = rem / W, dx = rem - dy * W;
+        const int h = hw[2 * img], w = hw[2 * img + 1];
+        const uint8_t* src = packed + offsets[img];
+        int sx, sy;
+        float fx, fy;
+        lin_tap(dx, W, w, sx, fx);
+        lin_tap(dy, H, h, sy, fy);
+        const int sx1 = min(sx + 1, w - 1), sy1 = min(sy + 1, h - 1);
+        const float gx = __fsub_rn(1.0f, fx), gy = __fsub_rn(1.0f, fy);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float p00 = (float)src[((long long)sy * w + sx) * 3 + c] / 255.0f;
+            const float p01 = (float)src[((long long)sy * w + sx1) * 3 + c] / 255.0f;
+            const float p10 = (float)src[((long long)sy1 * w + sx) * 3 + c] / 255.0f;
+            const float p11 = (float)src[((long long)sy1 * w + sx1) * 3 + c] / 255.0f;
+            const float r0 = __fadd_rn(__fmul_rn(p00, gx), __fmul_rn(p01, fx));
+            const float r1 = __fadd_rn(__fmul_rn(p10, gx), __fmul_rn(p11, fx));
+            const float v = __fadd_rn(__fmul_rn(r0, gy), __fmul_rn(r1, fy));
+            out[i * 3 + c] = __fsub_rn(v, 0.5f) / 0.5f;
+        }
+    }
+}
+
+// ---- MaxPool2d(3, 2, 1) on NHWC, c % 4 == 0 (SERes18_IBN.py:254)
+__global__ void maxpool3s2_kernel(const float* __restrict__ x, int n, int h, int w, int c, int ho, int wo,
+                                  float* __restrict__ out) {
+    const int c4n = c >> 2;
+    const long long total = (long long)n * ho * wo * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c4n);
+        long long t = i / c4n;
+        const int ox = (int)(t % wo);
+        t /= wo;
+        const int oy = (int)(t % ho);
+        const int img = (int)(t / ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)w) continue;
+                const f32x4 v = *(const f32x4*)(x + (((long long)img * h + iy) * w + ix) * c + cc * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *(f32x4*)(out + (((long long)img * ho + oy) * wo + ox) * c + cc * 4) = m;
+    }
+}
+
+// ---- IBN finalisation (SERes18_IBN.py:88-93): per-(image, channel) affine that the NEXT conv's loader applies.
+// channels [0, half): InstanceNorm2d(affine) from the conv epilogue's per-tile sum / sumsq partials (biased variance,
+// eps 1e-5); channels [half, c): eval BatchNorm folded on the host.  Partials are reduced in fp64 in a fixed order.
+__global__ void norm_finalize_kernel(const float* __restrict__ stats, int tiles, int c, int half, int hw,
+                                     const float* __restrict__ in_gamma, const float* __restrict__ in_beta,
+                                     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+                                     float* __restrict__ a_scale, float* __restrict__ a_shift) {
+    const int img = blockIdx.x;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        float a, b;
+        if (ch < half) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int t = 0; t < tiles; ++t) {
+                const float* st = stats + (((long long)img * tiles + t) * c + ch) * 2;
+                s1 += (double)st[0];
+                s2 += (double)st[1];
+            }
+            const double mean = s1 / hw;
+            double var = s2 / hw - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double inv = 1.0 / sqrt(var + 1e-5);
+            a = (float)(inv * (double)in_gamma[ch]);
+            b = (float)((double)in_beta[ch] - mean * inv * (double)in_gamma[ch]);
+        } else {
+            a = bn_scale[ch - half];
+            b = bn_shift[ch - half];
+        }
+        a_scale[(long long)img * c + ch] = a;
+        a_shift[(long long)img * c + ch] = b;
+    }
+}
+
+// ---- SEBlock (SERes18_IBN.py:32-41): s = sigmoid(W2 . relu(W1 . avgpool(y))), no bias, norm layer disabled (:36).
+// avgpool comes from the conv2 epilogue's per-tile column sums.  One block per image.
+__global__ __launch_bounds__(256) void se_finalize_kernel(const float* __restrict__ stats, int tiles, int c, int mid,
+                                                          int hw, const float* __restrict__ w1,
+                                                          const float* __restrict__ w2, float* __restrict__ s) {
+    __shared__ float pooled[512];
+    __shared__ float hid[64];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int ch = tid; ch < c; ch += 256) {
+        double acc = 0.0;
+        for (int t = 0; t < tiles; ++t) acc += (double)stats[(((long long)img * tiles + t) * c + ch) * 2];
+        pooled[ch] = (float)(acc / hw);
+    }
+    __syncthreads();
+    for (int m = wave; m < mid; m += 4) {
+        float acc = 0.f;
+        for (int ch = lane; ch < c; ch += 64) acc += w1[m * c + ch] * pooled[ch];
+        acc = wave_sum(acc);
+        if (lane == 0) hid[m] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 256) {
+        float acc = 0.f;
+        for (int m = 0; m < mid; ++m) acc += w2[ch * mid + m] * hid[m];
+        s[(long long)img * c + ch] = 1.0f / (1.0f + expf(-acc));
+    }
+}
+
+// ---- out = relu(s[n][c] * y + shortcut)   (SEBasicBlock.forward, SERes18_IBN.py:123-128)
+__global__ void se_combine_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ s,
+                                  long long total4, int hw, int c, float* __restrict__ out) {
+    const int c4n = c >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c4n);
+        const long long pix = i / c4n;
+        const long long img = pix / hw;
+        const f32x4 yy = *(const f32x4*)(y + i * 4);
+        const f32x4 rr = *(const f32x4*)(sc + i * 4);
+        const f32x4 ss = *(const f32x4*)(s + img * c + cc * 4);
+        f32x4 o = ss * yy + rr;
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        *(f32x4*)(out + i * 4) = o;
+    }
+}
+
+// ---- GeM (attention_pooling.py:58-60) + BNNeck (SERes18_IBN.py:268).  One block per image, thread = channel.
+__global__ __launch_bounds__(256) void gem_neck_kernel(const float* __restrict__ x, int hw, int c,
+                                                       const float* __restrict__ p_ptr, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ gem_out,
+                                                       float* __restrict__ emb) {
+    const int img = blockIdx.x;
+    const float p = p_ptr[0];
+    const float* xi = x + (long long)img * hw * c;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        float acc = 0.f;
+        for (int px = 0; px < hw; ++px) acc += powf(fmaxf(xi[(long long)px * c + ch], 1e-6f), p);
+        const float g = powf(acc / (float)hw, 1.0f / p);
+        if (gem_out) gem_out[(long long)img * c + ch] = g;
+        emb[(long long)img * c + ch] = g * scale[ch] + shift[ch];
+    }
+}
+
+// ---- |x_i|^2 per row, one wave per row
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x, int m, int d, long long ld,
+                                                         float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= m) return;
+    const float* xr = x + (long long)row * ld;
+    float acc = 0.f;
+    for (int k = lane; k < d; k += 64) acc += xr[k] * xr[k];
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = acc;
+}
+
+inline int grid_for(long long work, int block) {
+    long long g = (work + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));  // cap at 256 CUs x 8 blocks, grid-stride the rest
+}
+
+}  // namespace
+
+int launch_nchw_to_nhwc3(reid_ctx* ctx, const float* x, int n, int h, int w, float* out) {
+    const long long npix = (long long)n * h * w;
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, npix * 24.0);
+    hipLaunchKernelGGL(nchw_to_nhwc3_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, ctx->stream, x, npix, h * w, out);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_resize_norm(reid_ctx* ctx, const uint8_t* packed, const long long* offsets, const int* hw, int n, int H, int W,
+                       float* out) {
+    const long long total = (long long)n * H * W;
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, total * 15.0);
+    hipLaunchKernelGGL(resize_norm_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, packed, offsets, hw, n,
+                       H, W, out);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_maxpool3s2(reid_ctx* ctx, const float* x, int n, int h, int w, int c, float* out) {
+    ARG_CHECK(c % 4 == 0);
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)n * ho * wo * (c / 4);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, ((double)n * h * w * c + (double)n * ho * wo * c) * 4.0);
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, x, n, h, w, c, ho, wo, out);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_norm_finalize(reid_ctx* ctx, const float* stats, int n_img, int tiles, int c, int half, int hw,
+                         const float* in_gamma, const float* in_beta, const float* bn_scale, const float* bn_shift,
+                         float* a_scale, float* a_shift) {
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * c * (tiles * 8.0 + 8.0));
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(n_img), dim3(c < 256 ? c : 256), 0, ctx->stream, stats, tiles, c, half, hw,
+                       in_gamma, in_beta, bn_scale, bn_shift, a_scale, a_shift);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_se_finalize(reid_ctx* ctx, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1,
+                       const float* w2, float* s) {
+    ARG_CHECK(c <= 512 && mid <= 64);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * c * (tiles * 8.0 + 4.0));
+    hipLaunchKernelGGL(se_finalize_kernel, dim3(n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2, s);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_se_combine(reid_ctx* ctx, const float* y, const float* sc, const float* s, int n_img, int hw, int c, float* out) {
+    ARG_CHECK(c % 4 == 0);
+    const long long total4 = (long long)n_img * hw * (c / 4);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, total4 * 48.0);
+    hipLaunchKernelGGL(se_combine_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, ctx->stream, y, sc, s, total4, hw, c, out);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_gem_neck(reid_ctx* ctx, const float* x, int n_img, int hw, int c, const float* p, const float* scale,
+                    const float* shift, float* gem_out, float* emb) {
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 4.0);
+    hipLaunchKernelGGL(gem_neck_kernel, dim3(n_img), dim3(256), 0, ctx->stream, x, hw, c, p, scale, shift, gem_out, emb);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_row_sqnorm(reid_ctx* ctx, const float* x, int m, int d, long long ld, float* out) {
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)m * d * 4.0);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((m + 3) / 4), dim3(256), 0, ctx->stream, x, m, d, ld, out);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}

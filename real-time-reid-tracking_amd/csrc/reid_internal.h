@@ -1,0 +1,152 @@
+// Internal declarations shared by the HIP translation units of libreid_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <map>
+#include <vector>
+#include "../../include/reid_hip.h"
+
+void reid_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            reid_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return REID_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define REID_TRY(expr)            \
+    do {                          \
+        int _s = (expr);          \
+        if (_s != REID_OK) return _s; \
+    } while (0)
+
+#define ARG_CHECK(cond)                                                         \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            reid_set_error("%s:%d bad argument: %s", __FILE__, __LINE__, #cond); \
+            return REID_ERR_ARG;                                                \
+        }                                                                       \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// GEMM  C[M][N] = A'[M][K] . B[N][K]^T  on v_mfma_f32_32x32x2_f32, A' produced by one of the loaders.
+// ------------------------------------------------------------------------------------------------
+enum AMode {
+    A_DENSE = 0,     // A[M][lda], K contiguous, K % 4 == 0, 16-byte aligned rows
+    A_IM2COL = 1,    // NHWC fp32 activations, k = (r*S+s)*Cin + c, Cin % 32 == 0
+    A_STEM_F32 = 2,  // NHWC fp32 [N][H][W][3], 7x7 s2 p3, k = r*24 + (s*3+c), 8 x 24 = 192 (zero padded)
+    A_STEM_U8 = 3    // same from uint8 crops with (v/255-0.5)/0.5 fused into the loader
+};
+enum EpiMode {
+    E_CONV = 0,  // optional col scale/shift, residual, relu, per-(m-tile, col) sum/sumsq partials
+    E_DIST = 1,  // distance epilogue from row/col squared norms
+    E_BIAS = 2   // optional bias[n]
+};
+
+struct GemmParams {
+    const void* A;
+    long long lda;
+    // im2col geometry
+    int H, W, Cin, Ho, Wo, R, S, stride, pad;
+    const float* a_scale;  // [img][Cin] input transform x' = relu?(x*scale+shift) applied to in-bounds pixels
+    const float* a_shift;
+    int a_relu;
+    const float* B;        // [N][ldb]
+    long long ldb;
+    int M, N, K;
+    float* C;
+    long long ldc;
+    const float* col_scale;
+    const float* col_shift;
+    const float* residual;
+    int relu;
+    float* stats;          // [M/128][N][2] or null
+    const float* row_sq;   // E_DIST
+    const float* col_sq;
+    int metric;
+};
+
+struct reid_ctx;
+int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int kind, double flops, double bytes);
+
+// elementwise / reduction kernels (elementwise.hip)
+int launch_nchw_to_nhwc3(reid_ctx*, const float* x_nchw, int n, int h, int w, float* out_nhwc);
+int launch_resize_norm(reid_ctx*, const uint8_t* packed, const long long* offsets, const int* hw, int n, int H, int W,
+                       float* out_nhwc);
+int launch_maxpool3s2(reid_ctx*, const float* x, int n, int h, int w, int c, float* out);
+int launch_norm_finalize(reid_ctx*, const float* stats, int n_img, int tiles, int c, int half, int hw,
+                         const float* in_gamma, const float* in_beta, const float* bn_scale, const float* bn_shift,
+                         float* a_scale, float* a_shift);
+int launch_se_finalize(reid_ctx*, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1,
+                       const float* w2, float* s);
+int launch_se_combine(reid_ctx*, const float* y, const float* sc, const float* s, int n_img, int hw, int c, float* out);
+int launch_gem_neck(reid_ctx*, const float* x, int n_img, int hw, int c, const float* p, const float* scale,
+                    const float* shift, float* gem_out, float* emb);
+int launch_row_sqnorm(reid_ctx*, const float* x, int m, int d, long long ld, float* out);
+// selection kernels (select.hip)
+int launch_argmin_rows(reid_ctx*, const float* dist, int m, int n, long long ld, int32_t* idx, float* val);
+int launch_topk_rows(reid_ctx*, const float* dist, int m, int n, long long ld, int k, float* D, int32_t* I);
+int launch_rank_eval(reid_ctx*, const float* score, int nq, int ng, long long ld, const long long* ql,
+                     const long long* qc, const long long* gl, const long long* gc, int32_t* cmc_sum, double* ap,
+                     int32_t* valid);
+int launch_diou_cost(reid_ctx*, const double* tracks, int t, const double* dets, int m, double* out, int as_cost);
+
+// ------------------------------------------------------------------------------------------------
+struct ProfSlot {
+    double ms = 0, flops = 0, bytes = 0;
+    long long launches = 0;
+};
+
+struct Se18Block {
+    int c, cin, stride, ibn, ds, mid;
+    const float *conv1_w, *in_gamma, *in_beta, *bn1_scale, *bn1_shift, *conv2_w, *bn2_scale, *bn2_shift;
+    const float *ds_w, *ds_scale, *ds_shift, *se_w1, *se_w2;
+};
+
+struct Se18Weights {
+    bool loaded = false;
+    float* blob = nullptr;
+    size_t n_floats = 0;
+    int num_class = 0;
+    const float *stem_w, *stem_scale, *stem_shift;
+    Se18Block blk[8];
+    const float *gem_p, *neck_scale, *neck_shift, *cls_w;
+};
+
+struct reid_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    int chunk = 64;
+    int precision = 0;
+    bool profile = false;
+    ProfSlot prof[REID_K_COUNT];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    struct Pending { int kind; hipEvent_t a, b; double flops, bytes; };
+    std::vector<Pending> pending;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // growable device workspaces, keyed by name
+    std::map<std::string, std::pair<void*, size_t>> ws;
+    Se18Weights se18;
+    int last_n = 0;  // crops in the last embed chunk (for reid_debug_stage)
+    bool debug_keep = false;
+    float* stage_ptr[11] = {nullptr};
+};
+
+int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out);  // grow-only named workspace
+void prof_begin(reid_ctx* ctx, int kind, double flops, double bytes);
+void prof_end(reid_ctx* ctx);
+
+#define LAUNCH_CHECK()                                                                 \
+    do {                                                                               \
+        hipError_t _e = hipGetLastError();                                             \
+        if (_e != hipSuccess) {                                                        \
+            reid_set_error("%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            return REID_ERR_HIP;                                                       \
+        }                                                                              \
+    } while (0)

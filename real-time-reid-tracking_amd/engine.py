@@ -1,0 +1,246 @@
+"""Thin numpy-facing wrapper over one libreid_hip context (one per process and device).
+
+Nothing here computes: every method marshals numpy arrays (or raw device
+pointers) into the C ABI and returns what the HIP kernels produced.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check
+
+_ENGINES = {}
+
+IMG_H, IMG_W = 256, 128   # Extractor.size = (128, 256) as (W, H), feature_extractor.py:24
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.lib = _ffi.lib()
+        h = C.c_void_p()
+        check(self.lib.reid_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+        self.embed_dim = 512
+        self.num_class = 0
+
+    def close(self):
+        if self.h:
+            self.lib.reid_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- runtime
+    def sync(self):
+        check(self.lib.reid_ctx_sync(self.h))
+
+    def set_stream(self, hip_stream):
+        check(self.lib.reid_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    def set_chunk(self, n):
+        check(self.lib.reid_ctx_set_chunk(self.h, int(n)))
+
+    def set_precision(self, mode):
+        check(self.lib.reid_ctx_set_precision(self.h, int(mode)))
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.reid_malloc(self.h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        check(self.lib.reid_free(self.h, C.c_void_p(dptr)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self.lib.reid_memcpy_h2d(self.h, C.c_void_p(dptr), _ptr(arr), arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        check(self.lib.reid_memcpy_d2h(self.h, _ptr(arr), C.c_void_p(dptr), arr.nbytes))
+        return arr
+
+    def timer_start(self):
+        check(self.lib.reid_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.lib.reid_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile(self, on):
+        check(self.lib.reid_profile_enable(self.h, int(bool(on))))
+
+    def profile_reset(self):
+        check(self.lib.reid_profile_reset(self.h))
+
+    def profile_get(self, kind):
+        ms, n, fl, by = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        check(self.lib.reid_profile_get(self.h, int(kind), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
+    # ---- weights
+    def load_seres18(self, blob, manifest):
+        blob = _f32(blob)
+        check(self.lib.reid_seres18_load(self.h, _ptr(blob), blob.size, manifest.encode()))
+        d, nc = C.c_int(), C.c_int()
+        check(self.lib.reid_seres18_dims(self.h, C.byref(d), C.byref(nc)))
+        self.embed_dim, self.num_class = d.value, nc.value
+
+    # ---- embedding
+    def _outs(self, n, want_logits):
+        emb = np.empty((n, self.embed_dim), np.float32)
+        logits = np.empty((n, self.num_class), np.float32) if want_logits else None
+        return emb, logits
+
+    def embed_u8(self, crops, logits=False):
+        """uint8[n,256,128,3] -> float32[n,512] (and logits[n,num_class])."""
+        crops = np.ascontiguousarray(crops, dtype=np.uint8)
+        if crops.ndim != 4 or crops.shape[1:] != (IMG_H, IMG_W, 3):
+            raise ValueError("embed_u8 expects uint8[n,%d,%d,3], got %s" % (IMG_H, IMG_W, crops.shape))
+        emb, lg = self._outs(crops.shape[0], logits)
+        check(self.lib.reid_embed_u8(self.h, _ptr(crops), crops.shape[0], _ptr(emb), _ptr(lg)))
+        return (emb, lg) if logits else emb
+
+    def embed_ragged_u8(self, crops, logits=False):
+        """list of uint8[h_i,w_i,3] -> float32[n,512]; resize + normalise run on the device."""
+        n = len(crops)
+        hw = np.empty((n, 2), np.int32)
+        offs = np.empty(n, np.int64)
+        total = 0
+        flat = []
+        for i, c in enumerate(crops):
+            c = np.ascontiguousarray(c, dtype=np.uint8)
+            if c.ndim != 3 or c.shape[2] != 3 or c.shape[0] < 1 or c.shape[1] < 1:
+                raise ValueError("crop %d must be uint8[h,w,3], got %s" % (i, c.shape))
+            hw[i] = c.shape[:2]
+            offs[i] = total
+            total += c.size
+            flat.append(c.reshape(-1))
+        packed = np.concatenate(flat) if flat else np.empty(0, np.uint8)
+        emb, lg = self._outs(n, logits)
+        check(self.lib.reid_embed_ragged_u8(self.h, _ptr(packed), _ptr(offs), _ptr(hw), n, _ptr(emb), _ptr(lg)))
+        return (emb, lg) if logits else emb
+
+    def embed_f32_nchw(self, x, logits=False):
+        x = _f32(x)
+        if x.ndim != 4 or x.shape[1:] != (3, IMG_H, IMG_W):
+            raise ValueError("embed_f32_nchw expects float32[n,3,%d,%d], got %s" % (IMG_H, IMG_W, x.shape))
+        emb, lg = self._outs(x.shape[0], logits)
+        check(self.lib.reid_embed_f32_nchw(self.h, _ptr(x), x.shape[0], _ptr(emb), _ptr(lg)))
+        return (emb, lg) if logits else emb
+
+    def embed_u8_dev(self, d_crops, n, d_emb, d_logits=None):
+        check(self.lib.reid_embed_u8_dev(self.h, C.c_void_p(d_crops), int(n), C.c_void_p(d_emb),
+                                         C.c_void_p(d_logits or 0)))
+
+    def debug_keep(self, on):
+        check(self.lib.reid_ctx_set_debug_keep(self.h, int(bool(on))))
+
+    def debug_stage(self, stage, n):
+        sizes = [524288, 131072, 131072, 131072, 65536, 65536, 32768, 32768, 65536, 65536, 512]
+        out = np.empty(sizes[stage] * n, np.float32)
+        cnt = C.c_size_t()
+        check(self.lib.reid_debug_stage(self.h, int(stage), _ptr(out), out.size, C.byref(cnt)))
+        assert cnt.value == out.size
+        return out
+
+    # ---- matching
+    def distmat(self, x, y, metric=_ffi.METRIC_L2):
+        x, y = _f32(x), _f32(y)
+        if x.ndim != 2 or y.ndim != 2 or x.shape[1] != y.shape[1]:
+            raise ValueError("distmat expects x[m,d], y[n,d]")
+        out = np.empty((x.shape[0], y.shape[0]), np.float32)
+        check(self.lib.reid_distmat(self.h, _ptr(x), x.shape[0], _ptr(y), y.shape[0], x.shape[1], int(metric), _ptr(out)))
+        return out
+
+    def distmat_dev(self, d_x, m, d_y, n, d, metric, d_out):
+        check(self.lib.reid_distmat_dev(self.h, C.c_void_p(d_x), int(m), C.c_void_p(d_y), int(n), int(d), int(metric),
+                                        C.c_void_p(d_out)))
+
+    def argmin_rows(self, x, y, metric=_ffi.METRIC_L2):
+        x, y = _f32(x), _f32(y)
+        idx = np.empty(x.shape[0], np.int32)
+        val = np.empty(x.shape[0], np.float32)
+        check(self.lib.reid_argmin_rows(self.h, _ptr(x), x.shape[0], _ptr(y), y.shape[0], x.shape[1], int(metric),
+                                        _ptr(idx), _ptr(val)))
+        return idx, val
+
+    def argmin_rows_dev(self, d_x, m, d_y, n, d, metric, d_idx, d_val=None):
+        check(self.lib.reid_argmin_rows_dev(self.h, C.c_void_p(d_x), int(m), C.c_void_p(d_y), int(n), int(d), int(metric),
+                                            C.c_void_p(d_idx), C.c_void_p(d_val or 0)))
+
+    def knn(self, xq, xb, k):
+        xq, xb = _f32(xq), _f32(xb)
+        D = np.empty((xq.shape[0], k), np.float32)
+        I = np.empty((xq.shape[0], k), np.int32)
+        check(self.lib.reid_knn(self.h, _ptr(xq), xq.shape[0], _ptr(xb), xb.shape[0], xq.shape[1], int(k), _ptr(D), _ptr(I)))
+        return D, I
+
+    def diou(self, bbox, candidates):
+        b = np.ascontiguousarray(bbox, dtype=np.float64).reshape(4)
+        c = np.ascontiguousarray(candidates, dtype=np.float64).reshape(-1, 4)
+        out = np.empty(c.shape[0], np.float64)
+        check(self.lib.reid_diou(self.h, _ptr(b), _ptr(c), c.shape[0], _ptr(out)))
+        return out
+
+    def diou_cost(self, tracks, dets):
+        t = np.ascontiguousarray(tracks, dtype=np.float64).reshape(-1, 4)
+        d = np.ascontiguousarray(dets, dtype=np.float64).reshape(-1, 4)
+        out = np.empty((t.shape[0], d.shape[0]), np.float64)
+        check(self.lib.reid_diou_cost(self.h, _ptr(t), t.shape[0], _ptr(d), d.shape[0], _ptr(out)))
+        return out
+
+    def rank_eval(self, qf, ql, qc, gf, gl, gc):
+        qf, gf = _f32(qf), _f32(gf)
+        ql, qc, gl, gc = (np.ascontiguousarray(a, dtype=np.int64) for a in (ql, qc, gl, gc))
+        nq, ng = qf.shape[0], gf.shape[0]
+        cmc = np.empty(ng, np.int32)
+        ap = np.empty(nq, np.float64)
+        valid = np.empty(nq, np.int32)
+        check(self.lib.reid_rank_eval(self.h, _ptr(qf), _ptr(ql), _ptr(qc), nq, _ptr(gf), _ptr(gl), _ptr(gc), ng,
+                                      qf.shape[1], _ptr(cmc), _ptr(ap), _ptr(valid)))
+        return cmc, ap, valid
+
+    # ---- single operators
+    def conv2d_nhwc(self, x, w, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False):
+        x, w = _f32(x), _f32(w)
+        n, h, ww, cin = x.shape
+        cout, r, s, _ = w.shape
+        ho, wo = (h + 2 * pad - r) // stride + 1, (ww + 2 * pad - s) // stride + 1
+        out = np.empty((n, ho, wo, cout), np.float32)
+        sc = _f32(scale) if scale is not None else None
+        sh = _f32(shift) if shift is not None else None
+        res = _f32(residual) if residual is not None else None
+        check(self.lib.reid_conv2d_nhwc(self.h, _ptr(x), n, h, ww, cin, _ptr(w), cout, r, s, stride, pad, _ptr(sc), _ptr(sh),
+                                        _ptr(res), int(bool(relu)), _ptr(out)))
+        return out
+
+    def gemm_nt(self, a, b, bias=None):
+        a, b = _f32(a), _f32(b)
+        out = np.empty((a.shape[0], b.shape[0]), np.float32)
+        bi = _f32(bias) if bias is not None else None
+        check(self.lib.reid_gemm_nt(self.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], _ptr(bi), _ptr(out)))
+        return out
+
+
+def get_engine(device=0):
+    """Process-wide engine per device (one context per (process, device))."""
+    device = int(device)
+    if device not in _ENGINES:
+        _ENGINES[device] = Engine(device)
+    return _ENGINES[device]

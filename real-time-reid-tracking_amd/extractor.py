@@ -1,0 +1,54 @@
+"""DeepSORT appearance extractor - mirror of modification_deepsort/feature_extractor.py:14-53.
+
+    extractor = Extractor(model_path, use_cuda=True)
+    features  = extractor(im_crops)        # list of HxWx3 uint8 -> np.ndarray float32 [N, 512]
+
+What the reference does per call (feature_extractor.py:31-53): a Python loop of cv2.resize + ToTensor + Normalize
+per crop, torch.cat, H2D copy, backbone forward, D2H copy.  Here the crops are packed once, copied once, and the
+resize / normalise / backbone all run as HIP kernels; the return value is a fresh C-contiguous host array.
+
+Deviations, all forced by defects of the reference file itself:
+  Q1  it imports a class that no longer exists (SEDense18_IBN); this binds to the current SERse18_IBN layout.
+  Q2  it never calls .eval(); the only well-defined semantics, used here, is eval mode (running-stat BN).
+  Q3  embedding = BNNeck output (512-d), the first element of the eval-mode tuple (SERes18_IBN.py:274-275).
+"""
+import logging
+
+import numpy as np
+
+from . import weights
+from .engine import get_engine
+
+
+class Extractor(object):
+    def __init__(self, model_path, use_cuda=True, device=0):
+        if not use_cuda:
+            raise RuntimeError("Extractor: the MI355X engine has no CPU path (use_cuda=False is not supported)")
+        self.device = "cuda"
+        self.size = (128, 256)                 # (W, H), feature_extractor.py:24
+        self.net = get_engine(device)
+        if isinstance(model_path, dict):
+            state_dict = model_path            # already-loaded state_dict (tests, benchmarks)
+        else:
+            import torch                       # PyTorch only reads the checkpoint (feature_extractor.py:18)
+            state_dict = torch.load(model_path, map_location="cpu")
+        blob, manifest, self.info = weights.pack_seres18(state_dict)   # strict=False semantics, :19
+        self.net.load_seres18(blob, manifest)
+        self.net._owner = self
+        self._packed = (blob, manifest)
+        logger = logging.getLogger("root.tracker")
+        logger.info("Loading weights from {}... Done!".format(model_path if not isinstance(model_path, dict) else "<state_dict>"))
+
+    def _preprocess(self, im_crops):
+        """Host-visible equivalent of feature_extractor.py:31-46 is fused into the device path; this only
+        validates the crops the way the reference's torch.cat would fail on an empty list."""
+        if len(im_crops) == 0:
+            raise RuntimeError("Extractor: expected a non-empty list of crops")   # torch.cat([]) raises, :44
+        return [np.asarray(im) for im in im_crops]
+
+    def __call__(self, im_crops):
+        crops = self._preprocess(im_crops)
+        if getattr(self.net, "_owner", None) is not self:      # another model was loaded on this device meanwhile
+            self.net.load_seres18(*self._packed)
+            self.net._owner = self
+        return self.net.embed_ragged_u8(crops)

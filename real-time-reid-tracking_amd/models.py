@@ -1,0 +1,24 @@
+"""torchreid-style model registry - mirror of modification_tracking/models/__init__.py:26-121.
+
+The reference's registry maps ~55 names to torchreid constructors that are not vendored; its
+own additions are 'vit' and 'swin_transformer' (:79-80).  This registry holds the backbones that exist as HIP
+kernel sequences; every other name raises the same ``KeyError`` the reference raises for an unknown model.
+"""
+from .backbone import seres18_ibn
+
+__model_factory = {
+    'seres18_ibn': seres18_ibn,
+}
+
+
+def show_avai_models():
+    print(list(__model_factory.keys()))
+
+
+def build_model(name, num_classes, loss='softmax', pretrained=True, use_gpu=True):
+    """Same signature, same ``KeyError`` text as models/__init__.py:93-121; constructors are called with
+    exactly (num_classes, loss, pretrained, use_gpu)."""
+    avai_models = list(__model_factory.keys())
+    if name not in avai_models:
+        raise KeyError('Unknown model: {}. Must be one of {}'.format(name, avai_models))
+    return __model_factory[name](num_classes=num_classes, loss=loss, pretrained=pretrained, use_gpu=use_gpu)

@@ -1,0 +1,139 @@
+"""state_dict -> packed fp32 blob + manifest for libreid_hip.so.
+
+Weight-ingest contract of the reference (checkpoint row):
+  * checkpoints are ``torch.save(model.state_dict())`` of a DataParallel model, so keys may carry a
+    ``module.`` prefix (image_reid_train.py:111,635); ``{'state_dict': ...}`` wrappers are accepted
+    (reid_model_factory.py:172-175);
+  * ``Extractor`` loads with ``strict=False`` (feature_extractor.py:18-19): unknown keys are ignored;
+  * tensors the forward pass never reads are dropped: ``cam_bias`` (only used when ``cam`` is passed,
+    SERes18_IBN.py:269-270), ``*.seblock.bn.*`` (SERes18_IBN.py:36 commented out), ``num_batches_tracked``;
+  * ``--renorm`` checkpoints hold BatchRenormalization2D layers (gamma/beta/running_avg_*), whose eval
+    math is plain BN (batchrenorm.py:93-95).
+
+Packing for the kernels:
+  * eval BatchNorm is folded to per-channel (scale, shift) in float64 and rounded once;
+  * conv weights go from [Cout][Cin][R][S] to [Cout][R][S][Cin] (K contiguous, matching the NHWC im2col order);
+  * the 7x7 stem is stored as [64][8][24]: 7 kernel rows x (7 taps x 3 channels = 21) padded to 8 x 24 = 192.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from . import synth
+
+BN_EPS = 1e-5
+_BLK_SHORT = {"basicBlock11": "b11", "basicBlock12": "b12", "basicBlock21": "b21", "basicBlock22": "b22",
+              "basicBlock31": "b31", "basicBlock32": "b32", "basicBlock41": "b41", "basicBlock42": "b42"}
+
+
+def _np(v):
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def normalize_state_dict(state_dict):
+    """Unwraps {'state_dict': ...}, strips 'module.', converts to numpy."""
+    if isinstance(state_dict, dict) and "state_dict" in state_dict and not hasattr(state_dict["state_dict"], "shape"):
+        state_dict = state_dict["state_dict"]
+    out = OrderedDict()
+    for k, v in state_dict.items():
+        if k.startswith("module."):
+            k = k[7:]
+        out[k] = _np(v)
+    return out
+
+
+def fold_bn(sd, prefix):
+    """Eval-mode BN (or BatchRenormalization2D) -> (scale, shift) float32."""
+    if prefix + ".weight" in sd:
+        g, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+        m, v = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    elif prefix + ".gamma" in sd:
+        g, b = sd[prefix + ".gamma"], sd[prefix + ".beta"]
+        m, v = sd[prefix + ".running_avg_mean"], sd[prefix + ".running_avg_var"]
+    else:
+        raise KeyError("no BatchNorm parameters under '%s'" % prefix)
+    g, b, m, v = (np.asarray(t, np.float64).reshape(-1) for t in (g, b, m, v))
+    scale = g / np.sqrt(v + BN_EPS)
+    return scale.astype(np.float32), (b - m * scale).astype(np.float32)
+
+
+def conv_krsc(w):
+    """[Cout][Cin][R][S] -> [Cout][R*S*Cin] float32."""
+    w = np.asarray(w, np.float32)
+    return np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(w.shape[0], -1)
+
+
+def stem_pack(w):
+    """[64][3][7][7] -> [64][8][24]: k = r*24 + s*3 + c, zero padded."""
+    w = np.asarray(w, np.float32)
+    out = np.zeros((w.shape[0], 8, 24), np.float32)
+    out[:, :7, :21] = w.transpose(0, 2, 3, 1).reshape(w.shape[0], 7, 21)
+    return out.reshape(w.shape[0], 192)
+
+
+class Packer:
+    def __init__(self):
+        self.parts, self.lines, self.off = [], [], 0
+
+    def add(self, name, arr):
+        arr = np.ascontiguousarray(np.asarray(arr, np.float32).reshape(-1))
+        self.lines.append("%s %d %d" % (name, self.off, arr.size))
+        pad = (-arr.size) % 4            # keep every tensor 16-byte aligned
+        self.parts.append(arr)
+        if pad:
+            self.parts.append(np.zeros(pad, np.float32))
+        self.off += arr.size + pad
+
+    def finish(self):
+        return np.concatenate(self.parts).astype(np.float32), "\n".join(self.lines) + "\n"
+
+
+def pack_seres18(state_dict):
+    """Returns (blob float32[n], manifest str, info dict) for reid_seres18_load."""
+    sd = normalize_state_dict(state_dict)
+    required = ["conv0.weight", "basicBlock11.block_pre.conv1.weight", "bnneck.running_mean"]
+    for k in required:
+        if k not in sd:
+            raise KeyError("state_dict is not a SERse18_IBN checkpoint: missing '%s'" % k)
+    pk = Packer()
+    pk.add("stem.w", stem_pack(sd["conv0.weight"]))
+    s, b = fold_bn(sd, "bn0")
+    pk.add("stem.scale", s)
+    pk.add("stem.shift", b)
+    for name, c, ibn, ds, cin in synth.SERES18_BLOCKS:
+        sh, pre = _BLK_SHORT[name], name + ".block_pre"
+        pk.add(sh + ".conv1.w", conv_krsc(sd[pre + ".conv1.weight"]))
+        if ibn:
+            pk.add(sh + ".n1.in_gamma", sd[pre + ".bn1.IN.weight"])
+            pk.add(sh + ".n1.in_beta", sd[pre + ".bn1.IN.bias"])
+            s, b = fold_bn(sd, pre + ".bn1.BN")
+        else:
+            s, b = fold_bn(sd, pre + ".bn1")
+        pk.add(sh + ".n1.bn_scale", s)
+        pk.add(sh + ".n1.bn_shift", b)
+        pk.add(sh + ".conv2.w", conv_krsc(sd[pre + ".conv2.weight"]))
+        s, b = fold_bn(sd, pre + ".bn2")
+        pk.add(sh + ".bn2.scale", s)
+        pk.add(sh + ".bn2.shift", b)
+        if ds:
+            pk.add(sh + ".ds.w", conv_krsc(sd[name + ".block_post.conv.weight"]))
+            s, b = fold_bn(sd, name + ".block_post.bn")
+            pk.add(sh + ".ds.scale", s)
+            pk.add(sh + ".ds.shift", b)
+        mid = synth.se_mid(c)
+        pk.add(sh + ".se.w1", np.asarray(sd[name + ".seblock.fc1.weight"], np.float32).reshape(mid, c))
+        pk.add(sh + ".se.w2", np.asarray(sd[name + ".seblock.fc2.weight"], np.float32).reshape(c, mid))
+    p = sd.get("avgpooling.p", np.asarray([3.0], np.float32))   # GeM init p=3 (attention_pooling.py:52)
+    pk.add("gem.p", np.asarray(p, np.float32).reshape(1))
+    s, b = fold_bn(sd, "bnneck")
+    pk.add("neck.scale", s)
+    pk.add("neck.shift", b)
+    num_class = 0
+    if "classifier.0.weight" in sd:
+        w = np.asarray(sd["classifier.0.weight"], np.float32)
+        num_class = w.shape[0]
+        pk.add("cls.w", w)
+    blob, manifest = pk.finish()
+    return blob, manifest, {"arch": "seres18_ibn", "embed_dim": 512, "num_class": num_class}

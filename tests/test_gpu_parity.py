@@ -1,0 +1,203 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the committed golden
+fixtures (which came from the reference's own modules).  Run on an MI355X: pytest -m gpu."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import matching, seres18
+from reid_amd import _ffi, synth, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from reid_amd.engine import get_engine
+    return get_engine(0)
+
+
+@pytest.fixture(scope="module")
+def eng_w0(eng):
+    sd = synth.seres18_state_dict(0)
+    blob, manifest, _ = weights.pack_seres18(sd)
+    eng.load_seres18(blob, manifest)
+    return eng, sd
+
+
+# ----------------------------------------------------------------------------- single operators
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (1, 751, 512), (130, 70, 96), (257, 129, 36), (5, 3, 1263)])
+def test_gemm_nt(eng, m, n, k):
+    rng = np.random.default_rng(m * 1000 + n)
+    a = rng.normal(size=(m, k)).astype(np.float32)
+    b = rng.normal(size=(n, k)).astype(np.float32)
+    bias = rng.normal(size=n).astype(np.float32)
+    got = eng.gemm_nt(a, b, bias)
+    ref = (a.astype(np.float64) @ b.astype(np.float64).T + bias).astype(np.float32)
+    # fp32 MFMA = k-ordered fmaf chain: error ~1e-7 * sum|a.b|
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5 * np.sqrt(k))
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, h=16, w=8, cin=64, cout=64, k=3, stride=1, pad=1),
+    dict(n=3, h=32, w=16, cin=64, cout=128, k=3, stride=2, pad=1),
+    dict(n=2, h=32, w=16, cin=64, cout=128, k=1, stride=2, pad=0),
+    dict(n=1, h=16, w=8, cin=256, cout=512, k=3, stride=1, pad=1),
+    dict(n=2, h=8, w=8, cin=32, cout=96, k=3, stride=1, pad=1),
+])
+def test_conv2d_nhwc(eng, cfg):
+    rng = np.random.default_rng(cfg["cin"] + cfg["cout"])
+    n, h, w, cin, cout, k = cfg["n"], cfg["h"], cfg["w"], cfg["cin"], cfg["cout"], cfg["k"]
+    x = rng.normal(size=(n, h, w, cin)).astype(np.float32)
+    wt = (rng.normal(size=(cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(wt), None, cfg["stride"], cfg["pad"])
+    res = rng.normal(size=tuple(ref.permute(0, 2, 3, 1).shape)).astype(np.float32)
+    ref2 = F.relu(ref * torch.from_numpy(scale)[None, :, None, None] + torch.from_numpy(shift)[None, :, None, None]
+                  + torch.from_numpy(res).permute(0, 3, 1, 2))
+    w_krsc = np.ascontiguousarray(wt.transpose(0, 2, 3, 1))
+    got = eng.conv2d_nhwc(x, w_krsc, cfg["stride"], cfg["pad"])
+    np.testing.assert_allclose(got, ref.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
+    got2 = eng.conv2d_nhwc(x, w_krsc, cfg["stride"], cfg["pad"], scale, shift, res, relu=True)
+    np.testing.assert_allclose(got2, ref2.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- embedding
+@pytest.mark.parametrize("tag,crops_fn", [("seed0", synth.crops_u8), ("smooth1", synth.smooth_crops_u8)])
+def test_seres18_embed_matches_reference_fixture(eng, golden_dir, tag, crops_fn):
+    """Eval-mode semantics.  Tolerance: north_star 1e-3 cosine; the fp32 MFMA path is held to 1e-5."""
+    g = np.load(os.path.join(golden_dir, "seres18_%s.npz" % tag))
+    seed, n = int(g["seed"]), int(g["n"])
+    sd = synth.seres18_state_dict(seed)
+    blob, manifest, info = weights.pack_seres18(sd)
+    eng.load_seres18(blob, manifest)
+    assert info["num_class"] == 751
+    crops = crops_fn(n, seed)
+    eng.debug_keep(True)
+    try:
+        emb, logits = eng.embed_u8(crops, logits=True)
+        taps = {}
+        ref_emb, ref_logits = seres18.forward(sd, seres18.preprocess_u8(crops), taps)
+        names = ["stem", "pool0"] + [b[0] for b in synth.SERES18_BLOCKS] + ["gem"]
+        for s, name in enumerate(names):
+            t = taps[name]
+            want = t.permute(0, 2, 3, 1).contiguous().numpy().reshape(-1) if t.dim() == 4 else t.numpy().reshape(-1)
+            got = eng.debug_stage(s, n)
+            err = np.abs(got - want).max() / max(1e-6, np.abs(want).max())
+            assert err < 2e-5, "stage %d (%s): rel max err %g" % (s, name, err)
+    finally:
+        eng.debug_keep(False)
+    for mine, ref in ((emb, g["emb"]), (emb, ref_emb.numpy()), (logits, g["logits"])):
+        assert np.abs(mine - ref).max() / np.abs(ref).max() < 5e-5
+    cos = (emb * g["emb"]).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(g["emb"], axis=1)
+    assert (1 - cos).max() < 1e-5
+    # N=1 and the float NCHW entry of the plugin surface give the same embedding
+    emb1 = eng.embed_u8(crops[:1])
+    np.testing.assert_allclose(emb1, g["emb_single0"], rtol=1e-4, atol=2e-4 * np.abs(g["emb"]).max())
+    embf = eng.embed_f32_nchw(seres18.preprocess_u8(crops).numpy())
+    np.testing.assert_allclose(embf, emb, rtol=1e-6, atol=1e-6 * np.abs(emb).max())
+    # rebatching does not change results beyond fp32 noise (chunked passes)
+    eng.set_chunk(2)
+    emb_c = eng.embed_u8(crops)
+    eng.set_chunk(64)
+    np.testing.assert_allclose(emb_c, emb, rtol=1e-6, atol=1e-6 * np.abs(emb).max())
+
+
+def test_embed_ragged_resize_matches_oracle(eng_w0):
+    eng, sd = eng_w0
+    crops = synth.ragged_crops_u8(6, seed=3) + [synth.crops_u8(1, 9)[0]]
+    emb = eng.embed_ragged_u8(crops)
+    x = matching.preprocess(crops)                      # oracle restatement of feature_extractor.py:31-46
+    ref, _ = seres18.forward(sd, torch.from_numpy(x))
+    ref = ref.numpy()
+    assert np.abs(emb - ref).max() / np.abs(ref).max() < 5e-5
+    assert eng.embed_ragged_u8([]).shape == (0, 512)    # empty input
+
+
+def test_embed_rank_parity_and_cosine_distmat(eng_w0):
+    """BASELINE config 1 shape: 64 crops -> 512-d -> cosine distmat; argmin ranks equal to the oracle's."""
+    eng, sd = eng_w0
+    crops = synth.smooth_crops_u8(64, seed=5)
+    emb = eng.embed_u8(crops)
+    ref = seres18.embed_u8(sd, crops)
+    cos = (emb * ref).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (1 - cos).max() < 1e-5
+    d_gpu = eng.distmat(emb, emb, _ffi.METRIC_COS)
+    d_ref = matching.cosine_dist_deepsort(ref, ref)
+    np.testing.assert_allclose(d_gpu, d_ref, atol=2e-5)
+    np.fill_diagonal(d_gpu, np.inf)
+    np.fill_diagonal(d_ref, np.inf)
+    srt = np.sort(d_ref, axis=1)
+    decided = (srt[:, 1] - srt[:, 0]) > 1e-5           # near-ties are not deterministic in the reference either
+    assert decided.sum() >= 48
+    assert (d_gpu.argmin(1)[decided] == d_ref.argmin(1)[decided]).all()
+
+
+# ----------------------------------------------------------------------------- matching
+def test_distances_match_reference_fixture(eng, golden_dir):
+    g = np.load(os.path.join(golden_dir, "matching.npz"))
+    x, y = g["x"], g["y"]
+    np.testing.assert_allclose(eng.distmat(x, y, _ffi.METRIC_L2), g["euclid"], rtol=1e-5, atol=5e-4)
+    mask = g["euclid"] > 0.1                            # away from the clamp(1e-12).sqrt() cancellation point
+    np.testing.assert_allclose(eng.distmat(x, y, _ffi.METRIC_L2)[mask], g["euclid"][mask], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(eng.distmat(x, y, _ffi.METRIC_COS_HALF), g["cosine"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(eng.distmat(x, y, _ffi.METRIC_COS), 2 * g["cosine"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(eng.distmat(x, y, _ffi.METRIC_DOT), x @ y.T, rtol=1e-5, atol=1e-5)
+    idx, val = eng.argmin_rows(x, y, _ffi.METRIC_L2)
+    np.testing.assert_array_equal(idx, g["euclid"].argmin(1))
+    np.testing.assert_allclose(val, g["euclid"].min(1), rtol=1e-5, atol=5e-4)
+
+
+@pytest.mark.parametrize("m,n,d", [(1, 1, 4), (3, 1000, 96), (300, 257, 512), (17, 33, 1263)])
+def test_distmat_shapes(eng, m, n, d):
+    rng = np.random.default_rng(d)
+    x = rng.normal(size=(m, d)).astype(np.float32)
+    y = rng.normal(size=(n, d)).astype(np.float32)
+    np.testing.assert_allclose(eng.distmat(x, y, _ffi.METRIC_L2), matching.euclidean_dist(x, y), rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(eng.distmat(x, y, _ffi.METRIC_COS_HALF), matching.cosine_dist(x, y), rtol=1e-5, atol=2e-6)
+    assert eng.distmat(x[:0], y).shape == (0, n)        # empty inputs
+
+
+def test_knn_matches_oracle(eng):
+    rng = np.random.default_rng(2)
+    xb = rng.normal(size=(700, 64)).astype(np.float32)
+    xq = np.concatenate([xb[:40] + 0.05 * rng.normal(size=(40, 64)).astype(np.float32), xb[:3]], 0)
+    D, I = eng.knn(xq, xb, 20)
+    Dr, Ir = matching.knn_l2sqr(xq, xb, 20)
+    assert (np.diff(D, axis=1) >= 0).all()
+    np.testing.assert_allclose(D, Dr, rtol=1e-4, atol=2e-4)
+    gap = np.abs(np.diff(Dr, axis=1)).min(1) > 1e-3     # rows whose 20 neighbours are well separated
+    assert gap.sum() > 20
+    np.testing.assert_array_equal(I[gap], Ir[gap])
+    assert (I[:, 0] == np.r_[np.arange(40), np.arange(3)]).all()
+
+
+def test_diou_bit_exact(eng, golden_dir):
+    g = np.load(os.path.join(golden_dir, "matching.npz"))
+    demo = eng.diou([10, 12, 8, 9], [[9, 10, 9, 9], [8, 12, 9, 10], [10, 12, 9, 8]])
+    np.testing.assert_array_equal(demo, g["diou_demo"])          # the reference file's own demo (iou_matching.py:50-53)
+    got = np.stack([eng.diou(b, g["diou_cands"]) for b in g["diou_boxes"]], 0)
+    np.testing.assert_array_equal(got, g["diou"])                # fp64, bit-exact
+    np.testing.assert_array_equal(eng.diou_cost(g["diou_boxes"], g["diou_cands"]), 1.0 - g["diou"])
+    assert eng.diou_cost(np.zeros((0, 4)), g["diou_cands"]).shape == (0, 31)
+
+
+def test_rank_eval_matches_reference_fixture(eng, golden_dir):
+    from reid_amd.evaluate import evaluate_all
+    g = np.load(os.path.join(golden_dir, "matching.npz"))
+    cmc, ap = evaluate_all(g["ev_qf"], g["ev_ql"], g["ev_qc"], g["ev_gf"], g["ev_gl"], g["ev_gc"], verbose=False)
+    np.testing.assert_array_equal(np.asarray(cmc), g["ev_cmc"])  # integer rank counting: exact
+    assert abs(ap - float(g["ev_map"])) < 1e-12
+
+
+def test_rank_eval_market_shape(eng):
+    """Config-5 shaped problem at reduced size against the oracle."""
+    from reid_amd.evaluate import evaluate_all
+    qf, ql, qc, gf, gl, gc = synth.clustered_embeddings(200, 3000, d=512, n_ids=120, seed=4)
+    cmc, ap = evaluate_all(qf, ql, qc, gf, gl, gc, verbose=False)
+    cmc_r, ap_r = matching.evaluate_all(qf, ql, qc, gf, gl, gc)
+    np.testing.assert_array_equal(np.asarray(cmc), cmc_r)
+    assert abs(ap - ap_r) < 1e-10

@@ -1,0 +1,129 @@
+"""CPU-side tests: C-ABI surface, weight packer, plugin-surface host logic.  No GPU needed."""
+import ctypes
+import json
+import os
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from reid_amd import _ffi, synth, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import __graft_entry__ as g
+    g.build()
+    return ctypes.CDLL(_ffi.LIB_PATH)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "reid_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(reid_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 35
+    for sym in declared:
+        assert hasattr(built_lib, sym), sym
+    assert declared == set(_ffi.EXPORTS)          # the ctypes binding covers exactly the header
+
+
+def test_no_gpu_means_loud_failure(built_lib):
+    """The product path must fail loudly, not fall back, when it cannot run on the device."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from reid_amd.engine import Engine
+    with pytest.raises(_ffi.ReidHipError):
+        Engine(0)
+
+
+def test_pack_seres18_layout():
+    sd = synth.seres18_state_dict(0)
+    blob, manifest, info = weights.pack_seres18(sd)
+    assert info == {"arch": "seres18_ibn", "embed_dim": 512, "num_class": 751}
+    tab = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in manifest.strip().split("\n")}
+    assert all(off % 4 == 0 for off, _ in tab.values())
+    assert not any("seblock.bn" in k or "cam_bias" in k for k in tab)         # unused tensors dropped (Q6)
+    # stem: [64][8][24] with k = r*24 + s*3 + c
+    off, cnt = tab["stem.w"]
+    w = blob[off:off + cnt].reshape(64, 8, 24)
+    src = sd["conv0.weight"]
+    assert w[5, 2, 4 * 3 + 1] == src[5, 1, 2, 4] and (w[:, 7] == 0).all() and (w[:, :, 21:] == 0).all()
+    # 3x3: [Cout][R][S][Cin]
+    off, cnt = tab["b21.conv1.w"]
+    w = blob[off:off + cnt].reshape(128, 3, 3, 64)
+    assert w[7, 2, 1, 33] == sd["basicBlock21.block_pre.conv1.weight"][7, 33, 2, 1]
+    # folded BN
+    off, cnt = tab["b41.n1.bn_scale"]
+    g, v = sd["basicBlock41.block_pre.bn1.weight"], sd["basicBlock41.block_pre.bn1.running_var"]
+    np.testing.assert_allclose(blob[off:off + cnt], g / np.sqrt(v + 1e-5), rtol=1e-6)
+    assert tab["b11.n1.in_gamma"][1] == 32 and tab["b11.n1.bn_scale"][1] == 32 and tab["b41.n1.bn_scale"][1] == 512
+    assert tab["b31.se.w1"][1] == 16 * 256 and tab["b42.se.w2"][1] == 512 * 32
+
+
+def test_pack_accepts_dataparallel_and_renorm_checkpoints():
+    sd = synth.seres18_state_dict(1)
+    base, _, _ = weights.pack_seres18(sd)
+    wrapped = {"state_dict": {"module." + k: v for k, v in sd.items()}}      # image_reid_train.py:111 / factory :172-183
+    b2, _, _ = weights.pack_seres18(wrapped)
+    np.testing.assert_array_equal(base, b2)
+    rn = dict(sd)                                                            # --renorm layout, batchrenorm.py:26-40
+    for suffix, new in (("weight", "gamma"), ("bias", "beta"), ("running_mean", "running_avg_mean"),
+                        ("running_var", "running_avg_var")):
+        rn["bn0." + new] = rn.pop("bn0." + suffix).reshape(1, 64, 1, 1)
+    b3, _, _ = weights.pack_seres18(rn)
+    np.testing.assert_array_equal(base, b3)
+    with pytest.raises(KeyError):
+        weights.pack_seres18({"foo": np.zeros(3)})
+
+
+def test_model_factory_matches_reference_fixture(golden_dir):
+    from reid_amd import reid_model_factory as rmf
+    ref = json.load(open(os.path.join(golden_dir, "factory.json")))
+    for name, want in ref["get_model_name"].items():
+        got = rmf.get_model_name(Path(name))
+        if name == "seres18_ibn.pt":
+            assert want is None and got == "seres18_ibn"       # the one deliberate addition
+        else:
+            assert got == want, name
+    for name, want in ref["get_model_url"].items():
+        assert rmf.get_model_url(Path(name)) == want, name
+    for name, want in ref["is_model_in_model_types"].items():
+        assert rmf.is_model_in_model_types(Path(name)) == want, name
+
+
+def test_load_pretrained_weights_behaviour(golden_dir, tmp_path, capsys):
+    import torch
+    from reid_amd import reid_model_factory as rmf
+    ref = json.load(open(os.path.join(golden_dir, "factory.json")))["load_pretrained"]
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    ck = {"state_dict": {"module.0.weight": torch.ones(3, 4), "module.0.bias": torch.zeros(3),
+                         "1.weight": torch.ones(5, 5), "junk": torch.ones(1)}}
+    p = tmp_path / "w.pt"
+    torch.save(ck, p)
+    rmf.load_pretrained_weights(lin, str(p))
+    out = capsys.readouterr().out
+    assert bool((lin[0].weight == 1).all()) == ref["w0_is_ones"]
+    assert "discarded" in out and "['1.weight', 'junk']" in out and "['1.weight', 'junk']" in ref["stdout"]
+    # nothing matches -> warning, no exception (reid_model_factory.py:194-199)
+    torch.save({"zzz": torch.ones(2)}, p)
+    with pytest.warns(UserWarning):
+        rmf.load_pretrained_weights(lin, str(p))
+
+
+def test_build_model_registry():
+    from reid_amd import models
+    with pytest.raises(KeyError, match="Unknown model"):
+        models.build_model("resnet50", 751)
+    m = models.build_model("seres18_ibn", num_classes=10, loss="triplet", pretrained=False, use_gpu=True)
+    assert m.eval() is m and m.half() is m and m.to("cuda:0") is m
+    sd = m.state_dict()
+    assert tuple(sd["classifier.0.weight"].shape) == (10, 512) and len(sd) == len(synth.seres18_state_dict(0))
+    missing, unexpected = m.load_state_dict({"module.bn0.weight": np.ones(64, np.float32), "nope": np.ones(1)}, strict=False)
+    assert "nope" in unexpected and float(m.state_dict()["bn0.weight"][0]) == 1.0
+    with pytest.raises(RuntimeError):
+        m.to("cpu")
+    with pytest.raises(NotImplementedError):
+        models.build_model("seres18_ibn", 751, loss="arcface")
