@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (spec, no sparsity)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_CROP = 3.980e9        # 1 990 145 536 MAC
 FUSED_BYTES_PER_CROP = 13.78e6 # layer-fused fp32 activation traffic model, SURVEY.md section 8(d)
@@ -80,6 +81,8 @@ def main():
     ap.add_argument("--crops", type=int, default=4096, help="crops per GPU per step (BASELINE config 2: 4096)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "128")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f32"),
+                    help="f32 = exact fp32 MFMA; f16 = fp16 storage / fp32 accumulate (1e-3 cosine tolerance of north_star)")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +107,7 @@ def main():
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
     eng.set_chunk(args.chunk)
+    eng.set_precision(1 if args.precision == "f16" else 0)
     sd = synth.seres18_state_dict(0, gem_p=3.0)
     blob, manifest, _ = weights.pack_seres18(sd)
     eng.load_seres18(blob, manifest)
@@ -176,6 +180,8 @@ def main():
         total_crops = n * world * args.steps
         ms_per_step = elapsed * 1e3 / args.steps
         conv_tflops = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        f16 = args.precision == "f16"
+        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "crops/sec embedded + NxM distmat ms, ResNet18-SE 128x256",
             "value": round(total_crops / elapsed, 1),
@@ -187,7 +193,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f16" if f16 else "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: ResNet18-SE embed %d uint8 crops (128x256) per GPU + %dx%d L2 distmat"
                                    % (n, n, n * world),
@@ -196,15 +202,16 @@ def main():
             "embed_ms": round(embed_ms, 3),
             "embed_crops_per_s_per_gpu": round(n / (embed_ms * 1e-3), 1),
             "distmat_ms": round(match_ms, 3),
-            "whole_net_fraction_of_f32_mfma_peak": round(FLOP_PER_CROP * n / (embed_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-            "whole_net_fraction_of_hbm_roofline": round(FUSED_BYTES_PER_CROP * n / (embed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "whole_net_fraction_of_mfma_peak": round(FLOP_PER_CROP * n / (embed_ms * 1e-3) / 1e12 / peak, 4),
+            "whole_net_fraction_of_hbm_roofline": round(FUSED_BYTES_PER_CROP * (0.5 if f16 else 1.0) * n / (embed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": {
-                "kernel": "gemm_f32_kernel<im2col> (3x3/1x1/7x7 implicit-GEMM convolutions, v_mfma_f32_32x32x2_f32)",
+                "kernel": ("gemm_f16_kernel<im2col> (implicit-GEMM convolutions, v_mfma_f32_32x32x16_f16, LDS-DMA staging)" if f16 else
+                           "gemm_f32_kernel<im2col> (3x3/1x1/7x7 implicit-GEMM convolutions, v_mfma_f32_32x32x2_f32)"),
                 "bound": "mfma",
                 "achieved": round(conv_tflops, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                "frac": round(conv_tflops / peak, 4),
                 "traffic": None,
                 "launches": conv["launches"],
                 "avg_launch_us": round(conv["ms"] * 1e3 / max(1, conv["launches"]), 2),

@@ -49,6 +49,9 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->ws) hipFree(kv.second.first);
     if (ctx->se18.blob) hipFree(ctx->se18.blob);
+    if (ctx->se18.blob16) hipFree(ctx->se18.blob16);
+    if (ctx->se18.stem_w16) hipFree(ctx->se18.stem_w16);
+    if (ctx->se18.zero_page) hipFree(ctx->se18.zero_page);
     for (auto& e : ctx->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& p : ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     hipEventDestroy(ctx->t0);
@@ -78,8 +81,8 @@ extern "C" int reid_ctx_set_chunk(reid_ctx* ctx, int n) {
 
 extern "C" int reid_ctx_set_precision(reid_ctx* ctx, int mode) {
     ARG_CHECK(ctx);
-    if (mode != 0) {
-        reid_set_error("reid_ctx_set_precision: only mode 0 (exact fp32 MFMA) is built in this version");
+    if (mode != 0 && mode != 1) {
+        reid_set_error("reid_ctx_set_precision: mode must be 0 (exact fp32 MFMA) or 1 (fp16 storage / fp32 accumulate)");
         return REID_ERR_ARG;
     }
     ctx->precision = mode;
@@ -245,6 +248,9 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
     if (w.blob) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipFree(w.blob));
+        if (w.blob16) HIP_TRY(hipFree(w.blob16));
+        if (w.stem_w16) HIP_TRY(hipFree(w.stem_w16));
+        if (w.zero_page) HIP_TRY(hipFree(w.zero_page));
         w = Se18Weights();
     }
     HIP_TRY(hipMalloc((void**)&w.blob, n_floats * sizeof(float)));
@@ -301,6 +307,14 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         w = Se18Weights();
         return REID_ERR_ARG;
     }
+    // fp16 copies for the fp16 path: whole blob at the same element offsets + the padded-NHWC4 stem weights
+    HIP_TRY(hipMalloc((void**)&w.blob16, n_floats * sizeof(_Float16)));
+    HIP_TRY(hipMalloc((void**)&w.stem_w16, 64 * 256 * sizeof(_Float16)));
+    HIP_TRY(hipMalloc((void**)&w.zero_page, 256));
+    HIP_TRY(hipMemsetAsync(w.zero_page, 0, 256, ctx->stream));
+    REID_TRY(launch_f32_to_f16(ctx, w.blob, n_floats, w.blob16));
+    REID_TRY(launch_stem_w16(ctx, w.stem_w, w.stem_w16));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     w.loaded = true;
     return REID_OK;
 }
@@ -433,8 +447,126 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
                                  ((double)n * 512 + (double)w.num_class * 512 + (double)n * w.num_class) * 4.0));
     }
     ctx->last_n = n;
+    ctx->last_f16 = false;
     for (int s = 0; s < 11; ++s) ctx->stage_ptr[s] = b.stage[s];
     return REID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fp16 forward
+static int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H, int W, int Cin, const _Float16* wgt, int Cout,
+                       int R, int S, int stride, int pad, int K, const float* col_scale, const float* col_shift,
+                       const _Float16* residual, int relu, float* stats, _Float16* out, int Hp = 0, int Wp = 0) {
+    Gemm16Params p;
+    memset(&p, 0, sizeof(p));
+    p.A = x;
+    p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.Hp = Hp; p.Wp = Wp;
+    p.Ho = (H + 2 * pad - R) / stride + 1;
+    p.Wo = (W + 2 * pad - S) / stride + 1;
+    p.B = wgt; p.ldb = K;
+    p.M = n * p.Ho * p.Wo; p.N = Cout; p.K = K;
+    p.C = out; p.ldc = Cout;
+    p.col_scale = col_scale; p.col_shift = col_shift; p.residual = residual; p.relu = relu; p.stats = stats;
+    p.zero_page = ctx->se18.zero_page;
+    const double ktrue = (double)R * S * (amode == A16_STEM ? 3 : Cin);
+    const double flops = 2.0 * p.M * Cout * ktrue;
+    const double bytes = ((double)n * H * W * (amode == A16_STEM ? 4 : Cin) + (double)p.M * Cout + (double)Cout * ktrue +
+                          (residual ? (double)p.M * Cout : 0.0)) * 2.0;
+    return launch_gemm_f16(ctx, amode, p, REID_K_CONV_GEMM, flops, bytes);
+}
+
+static const int PAD_H = 262, PAD_W = 136;  // 256+6, 128+8: 3 zero rows/cols before, 3/5 after
+
+// x: uint8 NHWC crops (is_u8) or fp32 NHWC, both [n][256][128][3] on the device
+static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, float* d_emb, float* d_logits) {
+    Se18Weights& w = ctx->se18;
+    if (!w.loaded) {
+        reid_set_error("reid_embed_*: call reid_seres18_load first");
+        return REID_ERR_STATE;
+    }
+    typedef _Float16 f16;
+    const size_t per = 131072;
+    const bool keep = ctx->debug_keep;
+    f16 *pad_in, *stem, *pool, *tbase;
+    float *stats, *a_scale, *a_shift, *se, *gem;
+    REID_TRY(ctx_ws(ctx, "se18h.pad", (size_t)n * PAD_H * PAD_W * 4 * 2, (void**)&pad_in));
+    REID_TRY(ctx_ws(ctx, "se18h.stem", (size_t)n * 524288 * 2, (void**)&stem));
+    REID_TRY(ctx_ws(ctx, "se18h.pool", (size_t)n * per * 2, (void**)&pool));
+    REID_TRY(ctx_ws(ctx, "se18h.t", (size_t)n * per * 2 * (keep ? 4 * 8 : 4), (void**)&tbase));
+    REID_TRY(ctx_ws(ctx, "se18.stats", (size_t)n * 2048 * 4, (void**)&stats));
+    REID_TRY(ctx_ws(ctx, "se18.ascale", (size_t)n * 512 * 4, (void**)&a_scale));
+    REID_TRY(ctx_ws(ctx, "se18.ashift", (size_t)n * 512 * 4, (void**)&a_shift));
+    REID_TRY(ctx_ws(ctx, "se18.se", (size_t)n * 512 * 4, (void**)&se));
+    REID_TRY(ctx_ws(ctx, "se18.gem", (size_t)n * 512 * 4, (void**)&gem));
+
+    if (is_u8) REID_TRY(launch_prep_u8_pad_f16(ctx, (const uint8_t*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
+    else REID_TRY(launch_prep_f32_pad_f16(ctx, (const float*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
+    REID_TRY(conv_gemm16(ctx, A16_STEM, pad_in, n, IMG_H, IMG_W, 4, w.stem_w16, 64, 7, 7, 2, 3, 256, w.stem_scale, w.stem_shift,
+                         nullptr, 0, nullptr, stem, PAD_H, PAD_W));
+    REID_TRY(launch_maxpool3s2_f16(ctx, stem, n, 128, 64, 64, pool));
+    float* stage[11];
+    stage[0] = (float*)stem;
+    stage[1] = (float*)pool;
+
+    const f16* cur = pool;
+    int H = 64, W = 32;
+    for (int i = 0; i < 8; ++i) {
+        const Se18Block& k = w.blk[i];
+        f16* tb[4];
+        for (int j = 0; j < 4; ++j) tb[j] = tbase + ((size_t)(keep ? i * 4 : 0) + j) * n * per;
+        f16* free_[3];
+        int nf = 0;
+        for (int j = 0; j < 4 && nf < 3; ++j)
+            if (tb[j] != cur) free_[nf++] = tb[j];
+        f16 *c1 = free_[0], *y = free_[1], *sc = free_[2];
+        const int Ho = (H + 2 - 3) / k.stride + 1, Wo = (W + 2 - 3) / k.stride + 1;
+        const int hw = Ho * Wo, tiles = hw / 128;
+        const int half = k.ibn ? k.c / 2 : 0;
+        REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.conv1_w), k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr,
+                             nullptr, nullptr, 0, stats, c1));
+        REID_TRY(launch_norm_finalize(ctx, stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift,
+                                      a_scale, a_shift));
+        REID_TRY(launch_affine_relu_f16(ctx, c1, a_scale, a_shift, n, hw, k.c));
+        REID_TRY(conv_gemm16(ctx, A16_IM2COL, c1, n, Ho, Wo, k.c, w.h(k.conv2_w), k.c, 3, 3, 1, 1, 9 * k.c, k.bn2_scale,
+                             k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, stats, y));
+        const f16* shortcut = cur;
+        if (k.ds) {
+            REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.ds_w), k.c, 1, 1, k.stride, 0, k.cin, k.ds_scale,
+                                 k.ds_shift, nullptr, 0, nullptr, sc));
+            shortcut = sc;
+        }
+        REID_TRY(launch_se_finalize(ctx, stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, se));
+        f16* out = c1;
+        REID_TRY(launch_se_combine_f16(ctx, y, shortcut, se, n, hw, k.c, out));
+        stage[2 + i] = (float*)out;
+        cur = out;
+        H = Ho;
+        W = Wo;
+    }
+    REID_TRY(launch_gem_neck_f16(ctx, cur, n, H * W, 512, w.gem_p, w.neck_scale, w.neck_shift, gem, d_emb));
+    stage[10] = gem;
+    if (d_logits) {
+        if (!w.cls_w) {
+            reid_set_error("logits requested but the weight blob has no classifier (cls.w)");
+            return REID_ERR_STATE;
+        }
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.A = d_emb; p.lda = 512;
+        p.B = w.cls_w; p.ldb = 512;
+        p.M = n; p.N = w.num_class; p.K = 512;
+        p.C = d_logits; p.ldc = w.num_class;
+        REID_TRY(launch_gemm_f32(ctx, A_DENSE, E_BIAS, p, REID_K_CONV_GEMM, 2.0 * n * w.num_class * 512,
+                                 ((double)n * 512 + (double)w.num_class * 512 + (double)n * w.num_class) * 4.0));
+    }
+    ctx->last_n = n;
+    ctx->last_f16 = true;
+    for (int s2 = 0; s2 < 11; ++s2) ctx->stage_ptr[s2] = stage[s2];
+    return REID_OK;
+}
+
+static int seres18_run(reid_ctx* ctx, const void* x, bool is_u8, int n, float* d_emb, float* d_logits) {
+    return ctx->precision == 1 ? seres18_forward_f16(ctx, x, is_u8, n, d_emb, d_logits)
+                               : seres18_forward(ctx, x, is_u8, n, d_emb, d_logits);
 }
 
 static const size_t kStageElems[11] = {524288, 131072, 131072, 131072, 65536, 65536, 32768, 32768, 65536, 65536, 512};
@@ -448,6 +580,13 @@ extern "C" int reid_debug_stage(reid_ctx* ctx, int stage, float* out, size_t max
     const size_t total = kStageElems[stage] * (size_t)ctx->last_n;
     if (count) *count = total;
     const size_t ncopy = total < max_floats ? total : max_floats;
+    if (ctx->last_f16 && stage < 10) {   // fp16 path: activations are stored as f16, widen on the host
+        std::vector<_Float16> tmp(ncopy);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), ctx->stage_ptr[stage], ncopy * 2, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < ncopy; ++i) out[i] = (float)tmp[i];
+        return REID_OK;
+    }
     HIP_TRY(hipMemcpyAsync(out, ctx->stage_ptr[stage], ncopy * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return REID_OK;
@@ -458,7 +597,7 @@ extern "C" int reid_embed_u8_dev(reid_ctx* ctx, const uint8_t* d_crops, int n, f
     const int nc = ctx->se18.num_class;
     for (int i = 0; i < n; i += ctx->chunk) {
         const int m = n - i < ctx->chunk ? n - i : ctx->chunk;
-        REID_TRY(seres18_forward(ctx, d_crops + (size_t)i * IMG_H * IMG_W * 3, true, m, d_emb + (size_t)i * 512,
+        REID_TRY(seres18_run(ctx, d_crops + (size_t)i * IMG_H * IMG_W * 3, true, m, d_emb + (size_t)i * 512,
                                  d_logits ? d_logits + (size_t)i * nc : nullptr));
     }
     return REID_OK;
@@ -491,7 +630,7 @@ extern "C" int reid_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, f
         float* nhwc;
         REID_TRY(ctx_ws(ctx, "se18.in_nhwc", (size_t)m * img * 4, (void**)&nhwc));
         REID_TRY(launch_nchw_to_nhwc3(ctx, d_x + (size_t)i * img, m, IMG_H, IMG_W, nhwc));
-        REID_TRY(seres18_forward(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_logits ? d_logits + (size_t)i * nc : nullptr));
+        REID_TRY(seres18_run(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_logits ? d_logits + (size_t)i * nc : nullptr));
     }
     return REID_OK;
 }
@@ -542,7 +681,7 @@ extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const 
         float* nhwc;
         REID_TRY(ctx_ws(ctx, "se18.in_nhwc", (size_t)m * img * 4, (void**)&nhwc));
         REID_TRY(launch_resize_norm(ctx, d_pk, d_off + i, d_hw + 2 * i, m, IMG_H, IMG_W, nhwc));
-        REID_TRY(seres18_forward(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_log ? d_log + (size_t)i * nc : nullptr));
+        REID_TRY(seres18_run(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_log ? d_log + (size_t)i * nc : nullptr));
     }
     HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));

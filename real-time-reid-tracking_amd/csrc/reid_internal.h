@@ -71,7 +71,42 @@ struct GemmParams {
     int metric;
 };
 
+// ---- fp16-input / fp32-accumulate GEMM (gemm_f16.hip)
+enum A16Mode {
+    A16_DENSE = 0,   // A[M][lda] f16
+    A16_IM2COL = 1,  // NHWC f16 activations, Cin % 64 == 0
+    A16_STEM = 2     // zero-padded NHWC4 f16 image [n][Hp][Wp][4], 7x7 s2 as k = r*32 + s*4 + c (K = 256)
+};
+struct Gemm16Params {
+    const _Float16* A;
+    long long lda;
+    int H, W, Cin, Ho, Wo, R, S, stride, pad, Hp, Wp;
+    const _Float16* B;  // [N][ldb]
+    long long ldb;
+    int M, N, K;
+    _Float16* C;
+    long long ldc;
+    const float* col_scale;
+    const float* col_shift;
+    const _Float16* residual;
+    int relu;
+    float* stats;
+    const _Float16* zero_page;
+};
+
 struct reid_ctx;
+int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, double flops, double bytes);
+// fp16 elementwise kernels (elementwise_f16.hip)
+int launch_prep_u8_pad_f16(reid_ctx*, const uint8_t* crops, int n, int h, int w, int hp, int wp, _Float16* out);
+int launch_prep_f32_pad_f16(reid_ctx*, const float* nhwc3, int n, int h, int w, int hp, int wp, _Float16* out);
+int launch_maxpool3s2_f16(reid_ctx*, const _Float16* x, int n, int h, int w, int c, _Float16* out);
+int launch_affine_relu_f16(reid_ctx*, _Float16* x, const float* a_scale, const float* a_shift, int n_img, int hw, int c);
+int launch_se_combine_f16(reid_ctx*, const _Float16* y, const _Float16* sc, const float* s, int n_img, int hw, int c,
+                          _Float16* out);
+int launch_gem_neck_f16(reid_ctx*, const _Float16* x, int n_img, int hw, int c, const float* p, const float* scale,
+                        const float* shift, float* gem_out, float* emb);
+int launch_f32_to_f16(reid_ctx*, const float* x, size_t n, _Float16* out);
+int launch_stem_w16(reid_ctx*, const float* stem_w_f32, _Float16* out);   // [64][8][24] -> [64][8][8][4]
 int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int kind, double flops, double bytes);
 
 // elementwise / reduction kernels (elementwise.hip)
@@ -116,6 +151,10 @@ struct Se18Weights {
     const float *stem_w, *stem_scale, *stem_shift;
     Se18Block blk[8];
     const float *gem_p, *neck_scale, *neck_shift, *cls_w;
+    _Float16* blob16 = nullptr;   // fp16 copy of the whole blob (same element offsets) for the fp16 path
+    _Float16* stem_w16 = nullptr; // [64][256] stem weights of the padded-NHWC4 formulation
+    _Float16* zero_page = nullptr;
+    const _Float16* h(const float* p) const { return blob16 + (p - blob); }
 };
 
 struct reid_ctx {
@@ -135,6 +174,7 @@ struct reid_ctx {
     Se18Weights se18;
     int last_n = 0;  // crops in the last embed chunk (for reid_debug_stage)
     bool debug_keep = false;
+    bool last_f16 = false;
     float* stage_ptr[11] = {nullptr};
 };
 

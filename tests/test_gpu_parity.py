@@ -19,7 +19,7 @@ def eng():
     return get_engine(0)
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture()
 def eng_w0(eng):
     sd = synth.seres18_state_dict(0)
     blob, manifest, _ = weights.pack_seres18(sd)
@@ -201,3 +201,61 @@ def test_rank_eval_market_shape(eng):
     cmc_r, ap_r = matching.evaluate_all(qf, ql, qc, gf, gl, gc)
     np.testing.assert_array_equal(np.asarray(cmc), cmc_r)
     assert abs(ap - ap_r) < 1e-10
+
+
+# ----------------------------------------------------------------------------- fp16-storage fast path
+@pytest.mark.parametrize("tag,crops_fn", [("seed0", synth.crops_u8), ("smooth1", synth.smooth_crops_u8)])
+def test_seres18_f16_path_within_north_star_tolerance(eng, golden_dir, tag, crops_fn):
+    """precision=1: fp16 activations/weights, fp32 accumulation (v_mfma_f32_32x32x16_f16).  north_star tolerance:
+    1e-3 cosine against the reference; measured here at < 2e-5 and asserted at 1e-4."""
+    g = np.load(os.path.join(golden_dir, "seres18_%s.npz" % tag))
+    seed, n = int(g["seed"]), int(g["n"])
+    sd = synth.seres18_state_dict(seed)
+    blob, manifest, _ = weights.pack_seres18(sd)
+    eng.load_seres18(blob, manifest)
+    crops = crops_fn(n, seed)
+    eng.set_precision(1)
+    eng.debug_keep(True)
+    try:
+        emb, logits = eng.embed_u8(crops, logits=True)
+        taps = {}
+        seres18.forward(sd, seres18.preprocess_u8(crops), taps)
+        names = ["stem", "pool0"] + [b[0] for b in synth.SERES18_BLOCKS] + ["gem"]
+        for s, name in enumerate(names):
+            t = taps[name]
+            want = t.permute(0, 2, 3, 1).contiguous().numpy().reshape(-1) if t.dim() == 4 else t.numpy().reshape(-1)
+            got = eng.debug_stage(s, n)
+            err = np.abs(got - want).max() / max(1e-6, np.abs(want).max())
+            assert err < 1e-2, "f16 stage %d (%s): rel max err %g" % (s, name, err)
+        embf = eng.embed_f32_nchw(seres18.preprocess_u8(crops).numpy())
+        emb_r = eng.embed_ragged_u8(list(crops))
+    finally:
+        eng.debug_keep(False)
+        eng.set_precision(0)
+    cos = (emb * g["emb"]).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(g["emb"], axis=1)
+    assert (1 - cos).max() < 1e-4
+    assert np.abs(emb - g["emb"]).max() / np.abs(g["emb"]).max() < 1e-2
+    assert np.abs(logits - g["logits"]).max() / np.abs(g["logits"]).max() < 1e-2
+    np.testing.assert_allclose(embf, emb, rtol=0, atol=2e-3 * np.abs(emb).max())
+    np.testing.assert_allclose(emb_r, emb, rtol=0, atol=2e-3 * np.abs(emb).max())
+
+
+def test_f16_path_rank_parity(eng_w0):
+    eng, sd = eng_w0
+    crops = synth.smooth_crops_u8(64, seed=5)
+    ref = seres18.embed_u8(sd, crops)
+    eng.set_precision(1)
+    try:
+        emb = eng.embed_u8(crops)
+    finally:
+        eng.set_precision(0)
+    cos = (emb * ref).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (1 - cos).max() < 1e-4
+    d_gpu = eng.distmat(emb, emb, _ffi.METRIC_COS)
+    d_ref = matching.cosine_dist_deepsort(ref, ref)
+    np.fill_diagonal(d_gpu, np.inf)
+    np.fill_diagonal(d_ref, np.inf)
+    srt = np.sort(d_ref, axis=1)
+    decided = (srt[:, 1] - srt[:, 0]) > 2e-3           # fp16 storage: ranks are asserted where the gap exceeds its noise
+    assert decided.sum() >= 32
+    assert (d_gpu.argmin(1)[decided] == d_ref.argmin(1)[decided]).all()
