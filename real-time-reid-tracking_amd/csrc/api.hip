@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <sstream>
 
 static thread_local char g_err[1024] = "";
@@ -35,6 +36,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     reid_ctx* c = new reid_ctx();
     c->device = device;
+    if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipEventCreate(&c->t0));
@@ -462,7 +464,7 @@ static int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H
     p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.Hp = Hp; p.Wp = Wp;
     p.Ho = (H + 2 * pad - R) / stride + 1;
     p.Wo = (W + 2 * pad - S) / stride + 1;
-    p.B = wgt; p.ldb = K;
+    p.B = wgt; p.ldb = amode == A16_STEM ? 256 : K;   // stem weights are stored [64][8 rows][32], 7 rows used
     p.M = n * p.Ho * p.Wo; p.N = Cout; p.K = K;
     p.C = out; p.ldc = Cout;
     p.col_scale = col_scale; p.col_shift = col_shift; p.residual = residual; p.relu = relu; p.stats = stats;
@@ -938,4 +940,36 @@ extern "C" int reid_gemm_nt(reid_ctx* ctx, const float* a, int m, const float* b
     HIP_TRY(hipMemcpyAsync(c, dc, (size_t)m * n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return REID_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ kernel experiments
+// Times `iters` launches of one fp16 implicit-GEMM convolution on random device data (not part of the public header).
+extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int cfg,
+                                   int iters, float* ms_per_launch) {
+    ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded);
+    typedef _Float16 f16;
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - r) / stride + 1;
+    const size_t nin = (size_t)n * h * w * cin, nw = (size_t)cout * r * r * cin, nout = (size_t)n * ho * wo * cout;
+    f16 *x, *wt, *out;
+    REID_TRY(ctx_ws(ctx, "dbg.x", nin * 2, (void**)&x));
+    REID_TRY(ctx_ws(ctx, "dbg.w", nw * 2, (void**)&wt));
+    REID_TRY(ctx_ws(ctx, "dbg.out", nout * 2, (void**)&out));
+    // random-ish operands: the loaded weight blob (f32 -> f16), cycled
+    const size_t src_n = ctx->se18.n_floats;
+    for (size_t o = 0; o < nin; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nin - o < src_n ? nin - o : src_n, x + o));
+    for (size_t o = 0; o < nw; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nw - o < src_n ? nw - o : src_n, wt + o));
+    const int c0 = ctx->f16_cfg;
+    ctx->f16_cfg = cfg;
+    int st = REID_OK;
+    for (int i = 0; i < 2 && st == REID_OK; ++i)
+        st = conv_gemm16(ctx, A16_IM2COL, x, n, h, w, cin, wt, cout, r, r, stride, pad, r * r * cin, nullptr, nullptr, nullptr, 0, nullptr, out);
+    if (st == REID_OK) st = reid_timer_start(ctx);
+    for (int i = 0; i < iters && st == REID_OK; ++i)
+        st = conv_gemm16(ctx, A16_IM2COL, x, n, h, w, cin, wt, cout, r, r, stride, pad, r * r * cin, nullptr, nullptr, nullptr, 0, nullptr, out);
+    float ms = 0.f;
+    if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
+    ctx->f16_cfg = c0;
+    *ms_per_launch = ms / (iters > 0 ? iters : 1);
+    return st;
 }

@@ -3,13 +3,23 @@
 // fp16, every sum is fp32, BN / residual / ReLU / statistics run in fp32 in the epilogue.
 //
 // Staging is LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, the im2col gather is the per-lane SOURCE
-// address, zero padding is a lane pointing at a zero page.  The LDS image is lane-linear ([row][8 chunks of 16 B],
-// 128-B rows), so the bank-conflict fix is an XOR swizzle applied to the source chunk and to the read address:
-// chunk c of row r sits at position c ^ ((r >> 1) & 7).  For the lane groups of ds_read_b128 the 16 rows of a group
-// then cover 16 distinct 16-B slots of the 256-B bank row (conflict-free).
-// Two LDS stages: the DMA of K-tile t+1 is issued before the MFMAs of tile t; one barrier per K-tile.
-// Tiling as the f32 kernel: 4 waves (2x2), block 128 x BN, wave 64 x BN/2, BK = 64.
-// Requirements (all met by the conv stack): M % 128 == 0, N % BN == 0, K % 64 == 0.
+// address, zero padding is a lane pointing at a zero page.  The LDS image is lane-linear ([row][BK*2 bytes]), so the
+// bank-conflict fix is an XOR swizzle applied to the source chunk and to the read address: with RPB = rows per 256-B
+// bank row and CH = 16-B chunks per row, chunk c of row r sits at position c ^ ((r / RPB) % CH); the 16 rows of a
+// ds_read_b128 lane group then cover the 16 slots of the bank row (SQ_LDS_BANK_CONFLICT = 0 measured).
+//
+// 256 x BN block tile, 8 waves, NST-deep LDS ring.  A loop that keeps ONE K-tile of DMA in flight (issue -> MFMAs ->
+// vmcnt(0) -> barrier) is latency-bound (an LDS-DMA takes ~1 us to land under load).  Here NST-1 K-tiles are in
+// flight: per iteration a wave waits for its OWN pieces of tile t with a counted s_waitcnt vmcnt((NST-2)*G) (G = DMA
+// instructions per wave per tile), passes ONE raw s_barrier (every wave's pieces of tile t have landed, and every wave
+// has finished reading tile t-1), refills the slot of tile t-1 with tile t+NST-1, then runs the MFMAs of tile t.
+// No vmcnt(0) inside the loop (a __syncthreads() would drain the ring).
+//
+// Measured model (tools/bench_conv_f16.py): throughput = DMA byte rate x tile intensity BM*BN/(BM+BN) flop/B.  The DMA
+// byte rate is ~7.5 TB/s chip-wide with 64-B rows (BK = 32) and ~12+ TB/s with full 128-B lines (BK = 64), independent
+// of the inner-loop order, s_setprio, K ordering (tap-major vs channel-chunk-major) - so: BK = 64 and the widest tile
+// that keeps the ring in 160 KB of LDS.
+// Requirements: M % 128 == 0 (a ragged last 256-row tile is predicated), N % 64 == 0, K % BK == 0.
 #include "reid_internal.h"
 
 typedef _Float16 f16;
@@ -20,41 +30,56 @@ namespace {
 
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(uintptr_t)(p))
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int AMODE, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const Gemm16Params p) {
-    constexpr int TM = 2, TN = BN / 64;
-    constexpr int A_BYTES = 128 * 128;  // 128 rows x 64 f16
-    constexpr int B_BYTES = BN * 128;
-    constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int BJ = BN / 32;         // B wave-instructions per wave per K-tile
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+template <int AMODE, int BN, int BK, int NST>
+__global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) {
+    constexpr int BM = 256;
+    constexpr int WM = BN == 256 ? 2 : 4;         // waves along M
+    constexpr int WN = 8 / WM;                    // waves along N
+    constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int ROWB = BK * 2;                  // bytes per LDS row
+    constexpr int CH = ROWB / 16;                 // 16-B chunks per row
+    constexpr int RPI = 1024 / ROWB;              // rows per DMA wave-instruction
+    constexpr int RPB = 256 / ROWB;               // rows per 256-B bank row
+    constexpr int KS = BK / 16;                   // MFMA k-steps per tile
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int AJ = BM / RPI / 8;              // A DMA instructions per wave per tile
+    constexpr int B_INST = BN / RPI;
+    constexpr int BJ = B_INST >= 8 ? B_INST / 8 : 1;
+    constexpr int G = AJ + BJ;
+    static_assert(NST * STAGE <= 160 * 1024, "LDS ring too large");
+    __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     const int nnt = p.N / BN;
     const int nwg = gridDim.x;
     int mtile, ntile;
-    {
+    {   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD)
         const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
         mtile = L / nnt;
         ntile = L - mtile * nnt;
     }
-    const int m_blk = mtile * 128, n_blk = ntile * BN;
+    const int m_blk = mtile * BM, n_blk = ntile * BN;
 
-    // ---- per-lane source descriptors: wave-instruction j of this wave fills tile rows (wave*4+j)*8 .. +8
-    int a_chunk[4];
-    long long a_base[4];  // dense: element offset of the row
-    int a_img[4], a_iy0[4], a_ix0[4];
+    // ---- DMA descriptors: one wave-instruction fills RPI rows; wave w issues A instructions w*AJ + j
+    int a_chunk[AJ], a_img[AJ], a_iy0[AJ], a_ix0[AJ];
+    bool a_ok[AJ];
+    long long a_base[AJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave * 32 + j * 8 + (lane >> 3);
-        a_chunk[j] = (lane & 7) ^ ((row >> 1) & 7);
-        const int m = m_blk + row;
+    for (int j = 0; j < AJ; ++j) {
+        const int row = (wave * AJ + j) * RPI + lane / CH;
+        a_chunk[j] = (lane % CH) ^ ((row / RPB) % CH);
+        int m = m_blk + row;
+        a_ok[j] = m < p.M;
+        if (!a_ok[j]) m = 0;  // rows past M (ragged last tile) read the zero page / row 0 and are never stored
         if constexpr (AMODE == A16_DENSE) {
             a_base[j] = (long long)m * p.lda;
         } else {
@@ -66,50 +91,52 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const Gemm16Params p) 
             a_img[j] = img;
         }
     }
-    int b_chunk[BJ];
+    int b_chunk[BJ], b_row[BJ];
     long long b_base[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int row = wave * (BN / 4) + j * 8 + (lane >> 3);
-        b_chunk[j] = (lane & 7) ^ ((row >> 1) & 7);
+        // fewer than 8 B instructions (BN = 64, BK = 32): waves 4-7 repeat waves 0-3 (same bytes to the same place) so
+        // that every wave issues the same number of DMAs and the counted waits stay uniform
+        const int inst = B_INST >= 8 ? wave * BJ + j : wave % B_INST;
+        b_row[j] = inst * RPI;
+        const int row = inst * RPI + lane / CH;
+        b_chunk[j] = (lane % CH) ^ ((row / RPB) % CH);
         b_base[j] = (long long)(n_blk + row) * p.ldb;
     }
 
-    auto stage = [&](int kt, int buf) {
-        char* As = lds + buf * STAGE;
+    auto stage = [&](int kt, int slot) {
+        char* As = lds + slot * STAGE;
         char* Bs = As + A_BYTES;
-        const int k0 = kt * 64;
+        const int k0 = kt * BK;
         if constexpr (AMODE == A16_DENSE) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < AJ; ++j)
                 __builtin_amdgcn_global_load_lds(GPTR(p.A + a_base[j] + k0 + a_chunk[j] * 8),
-                                                 LPTR(As + (wave * 32 + j * 8) * 128), 16, 0, 0);
+                                                 LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
         } else if constexpr (AMODE == A16_IM2COL) {
-            const int tap = k0 / p.Cin;
+            const int tap = k0 / p.Cin;          // K order (tap, channel); Cin % BK == 0
             const int c0 = k0 - tap * p.Cin;
             const int r = tap / p.S, s = tap - r * p.S;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < AJ; ++j) {
                 const int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const bool ok = a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const f16* src = ok ? p.A + (((long long)a_img[j] * p.H + iy) * p.W + ix) * p.Cin + c0 + a_chunk[j] * 8
                                     : p.zero_page;
-                __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(As + (wave * 32 + j * 8) * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
             }
-        } else {  // A16_STEM: zero-padded NHWC4 input, k = r*32 + s*4 + c, one K-tile = kernel rows 2kt, 2kt+1
+        } else {  // A16_STEM: zero-padded NHWC4 image, k = r*32 + s*4 + c; a 16-B chunk = one pixel pair of one kernel row
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 2 * kt + (a_chunk[j] >> 2);
-                const int sp = a_chunk[j] & 3;
-                // a_iy0 = 2*oy - 3, padded row index = a_iy0 + 3 + r; same for columns (pairs of pixels)
-                const long long pix = ((long long)a_img[j] * p.Hp + (a_iy0[j] + 3 + r)) * p.Wp + (a_ix0[j] + 3 + 2 * sp);
-                __builtin_amdgcn_global_load_lds(GPTR(p.A + pix * 4), LPTR(As + (wave * 32 + j * 8) * 128), 16, 0, 0);
+            for (int j = 0; j < AJ; ++j) {
+                const int kq = kt * CH + a_chunk[j];   // chunk index along K: kernel row = kq / 4, pixel pair = kq % 4
+                const long long pix = ((long long)a_img[j] * p.Hp + (a_iy0[j] + 3 + (kq >> 2))) * p.Wp +
+                                      (a_ix0[j] + 3 + 2 * (kq & 3));
+                __builtin_amdgcn_global_load_lds(GPTR(p.A + pix * 4), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
             }
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
-            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0 + b_chunk[j] * 8),
-                                             LPTR(Bs + (wave * (BN / 4) + j * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0 + b_chunk[j] * 8), LPTR(Bs + b_row[j] * ROWB), 16, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -120,40 +147,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const Gemm16Params p) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    const int nk = p.K / 64;
-    const int swz = (li >> 1) & 7;
-    const int a_row_off = (wm * 64 + li) * 128;
-    const int b_row_off = (wn * (BN / 2) + li) * 128;
+    const int nk = p.K / BK;
+    const int swz = (li / RPB) % CH;
+    const int a_row_off = (wm * WTM + li) * ROWB;
+    const int b_row_off = (wn * WTN + li) * ROWB;
 
-    stage(0, 0);
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stage(s, s);
+
+    int slot_c = 0, slot_i = NST - 1;  // ring slots of the tile being computed / refilled
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const char* As = lds + buf * STAGE;
+        const int rem = nk - 1 - kt;
+        if (NST > 2 && rem >= NST - 2) WAIT_VMCNT((NST - 2) * G);
+        else if (NST > 3 && rem == 1) WAIT_VMCNT(G);
+        else WAIT_VMCNT(0);
+        RAW_BARRIER();
+        if (kt + NST - 1 < nk) stage(kt + NST - 1, slot_i);
+        const char* As = lds + slot_c * STAGE;
         const char* Bs = As + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KS; ++kk) {
             const int pos = ((kk * 2 + lh) ^ swz) * 16;
             half8 af[TM], bf[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *(const half8*)(As + a_row_off + a * 32 * 128 + pos);
+            for (int a = 0; a < TM; ++a) af[a] = *(const half8*)(As + a_row_off + a * 32 * ROWB + pos);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = *(const half8*)(Bs + b_row_off + b * 32 * 128 + pos);
+            for (int b = 0; b < TN; ++b) bf[b] = *(const half8*)(Bs + b_row_off + b * 32 * ROWB + pos);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        __syncthreads();  // drains this tile's DMA (vmcnt(0)) and orders reads of `buf` before its next refill
+        slot_c = slot_c + 1 == NST ? 0 : slot_c + 1;
+        slot_i = slot_i + 1 == NST ? 0 : slot_i + 1;
     }
+    __syncthreads();
 
     // ------------------------------------------------------------------ epilogue (fp32 math, f16 stores)
-    float* stat_lds = (float*)lds;
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* stat_lds = (float*)lds;  // [WM][BN][2]
+    const int ldc = (int)p.ldc;
+    f16* Cb = p.C + (long long)m_blk * ldc + n_blk;
+    const f16* Rb = p.residual ? p.residual + (long long)m_blk * ldc + n_blk : nullptr;
+    const int row0 = wm * WTM + 4 * lh;
+    const int m_valid = p.M - m_blk;  // rows of this tile that exist (>= 256 except for a ragged last tile)
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-        const int lcol = wn * (BN / 2) + b * 32 + li;
+        const int lcol = wn * WTN + b * 32 + li;
         const int col = n_blk + lcol;
         float cs = 1.f, sh = 0.f;
         if (p.col_scale) { cs = p.col_scale[col]; sh = p.col_shift[col]; }
@@ -162,15 +204,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const Gemm16Params p) 
         for (int a = 0; a < TM; ++a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m_blk + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const long long idx = (long long)row * p.ldc + col;
+                const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
+                const int off = rl * ldc + lcol;
                 float v = acc[a][b][e];
-                if (p.col_scale) v = v * cs + sh;
-                if (p.residual) v += (float)p.residual[idx];
-                if (p.relu) v = fmaxf(v, 0.f);
-                s1 += v;
-                s2 += v * v;
-                p.C[idx] = (f16)v;
+                if (rl < m_valid) {
+                    if (p.col_scale) v = v * cs + sh;
+                    if (Rb) v += (float)Rb[off];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    s1 += v;
+                    s2 += v * v;
+                    Cb[off] = (f16)v;
+                }
             }
         }
         if (p.stats) {
@@ -183,39 +227,79 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const Gemm16Params p) 
         }
     }
     if (p.stats) {
+        // statistics are kept per 128-row tile (= per image for the 16x8 maps): the block covers two of them
         __syncthreads();
-        if (tid < BN) {
-            float* o = p.stats + ((long long)mtile * p.N + n_blk + tid) * 2;
-            o[0] = stat_lds[tid * 2 + 0] + stat_lds[(BN + tid) * 2 + 0];
-            o[1] = stat_lds[tid * 2 + 1] + stat_lds[(BN + tid) * 2 + 1];
+        for (int t = tid; t < 2 * BN; t += 512) {
+            const int half = t / BN, c = t - half * BN;
+            if (half * 128 >= m_valid) continue;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM / 2; ++w) {
+                t1 += stat_lds[((half * (WM / 2) + w) * BN + c) * 2 + 0];
+                t2 += stat_lds[((half * (WM / 2) + w) * BN + c) * 2 + 1];
+            }
+            float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + c) * 2;
+            o[0] = t1;
+            o[1] = t2;
         }
     }
 }
 
-template <int AMODE>
-int launch_bn16(reid_ctx* ctx, const Gemm16Params& p) {
-    const int nmt = p.M / 128;
-    if (p.N % 128 == 0) {
-        hipLaunchKernelGGL((gemm_f16_kernel<AMODE, 128>), dim3(nmt * (p.N / 128)), dim3(256), 0, ctx->stream, p);
-    } else {
-        hipLaunchKernelGGL((gemm_f16_kernel<AMODE, 64>), dim3(nmt * (p.N / 64)), dim3(256), 0, ctx->stream, p);
+template <int AMODE, int BN, int BK, int NST>
+int launch_cfg(reid_ctx* ctx, const Gemm16Params& p) {
+    if (p.K % BK != 0 || (AMODE == A16_IM2COL && p.Cin % BK != 0)) {
+        reid_set_error("gemm_f16: K=%d / Cin=%d not a multiple of BK=%d", p.K, p.Cin, BK);
+        return REID_ERR_ARG;
     }
+    hipLaunchKernelGGL((gemm_f16_kernel<AMODE, BN, BK, NST>), dim3(((p.M + 255) / 256) * (p.N / BN)), dim3(512), 0, ctx->stream, p);
     LAUNCH_CHECK();
     return REID_OK;
+}
+
+// tile / ring configuration: cfg = BN*1000 + BK*10 + NST (ctx->f16_cfg forces one, 0 = heuristic)
+template <int AMODE>
+int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
+    int cfg = ctx->f16_cfg;
+    if (cfg == 0 || p.N % (cfg / 1000) != 0) {
+        // measured per layer shape with tools/bench_conv_f16.py (256 crops): Cout 64 -> 64642 (454 TF), 128 -> 128323
+        // (624 TF), 256 -> 128642 (679 TF), 512 -> 256642 (953 TF) when that still gives >= 192 blocks
+        const long long mt = (p.M + 255) / 256;
+        const bool k64 = p.K % 64 == 0 && (AMODE != A16_IM2COL || p.Cin % 64 == 0);
+        const int bn = p.N % 256 == 0 && mt * (p.N / 256) >= 192 ? 256 : (p.N % 128 == 0 ? 128 : 64);
+        if (!k64) cfg = bn * 1000 + 320 + (bn == 256 ? 4 : 3);
+        else if (bn == 128 && p.N == 128) cfg = 128323;
+        else cfg = bn * 1000 + 642;
+    }
+    switch (cfg) {
+        case 256324: return launch_cfg<AMODE, 256, 32, 4>(ctx, p);
+        case 256323: return launch_cfg<AMODE, 256, 32, 3>(ctx, p);
+        case 256642: return launch_cfg<AMODE, 256, 64, 2>(ctx, p);
+        case 128324: return launch_cfg<AMODE, 128, 32, 4>(ctx, p);
+        case 128323: return launch_cfg<AMODE, 128, 32, 3>(ctx, p);
+        case 128643: return launch_cfg<AMODE, 128, 64, 3>(ctx, p);
+        case 128642: return launch_cfg<AMODE, 128, 64, 2>(ctx, p);
+        case 64323: return launch_cfg<AMODE, 64, 32, 3>(ctx, p);
+        case 64324: return launch_cfg<AMODE, 64, 32, 4>(ctx, p);
+        case 64643: return launch_cfg<AMODE, 64, 64, 3>(ctx, p);
+        case 64642: return launch_cfg<AMODE, 64, 64, 2>(ctx, p);
+        default:
+            reid_set_error("gemm_f16: unknown tile configuration %d", cfg);
+            return REID_ERR_ARG;
+    }
 }
 
 }  // namespace
 
 int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, double flops, double bytes) {
-    ARG_CHECK(p.M > 0 && p.M % 128 == 0 && p.N % 64 == 0 && p.K % 64 == 0 && p.ldb % 8 == 0);
-    if (amode == A16_IM2COL) ARG_CHECK(p.Cin % 64 == 0 && p.K == p.R * p.S * p.Cin && p.zero_page);
-    if (amode == A16_STEM) ARG_CHECK(p.K == 256 && p.Hp >= p.H + 6 && p.Wp >= p.W + 8);
+    ARG_CHECK(p.M > 0 && p.M % 128 == 0 && p.N % 64 == 0 && p.K % 32 == 0 && p.ldb % 8 == 0);
+    if (amode == A16_IM2COL) ARG_CHECK(p.Cin % 32 == 0 && p.K == p.R * p.S * p.Cin && p.zero_page);
+    if (amode == A16_STEM) ARG_CHECK((p.K == 256 || p.K == 224) && p.Hp >= p.H + 6 && p.Wp >= p.W + 8);
     if (amode == A16_DENSE) ARG_CHECK(p.lda % 8 == 0);
     prof_begin(ctx, kind, flops, bytes);
     int st = REID_ERR_ARG;
-    if (amode == A16_IM2COL) st = launch_bn16<A16_IM2COL>(ctx, p);
-    else if (amode == A16_STEM) st = launch_bn16<A16_STEM>(ctx, p);
-    else if (amode == A16_DENSE) st = launch_bn16<A16_DENSE>(ctx, p);
+    if (amode == A16_IM2COL) st = launch_any<A16_IM2COL>(ctx, p);
+    else if (amode == A16_STEM) st = launch_any<A16_STEM>(ctx, p);
+    else if (amode == A16_DENSE) st = launch_any<A16_DENSE>(ctx, p);
     else reid_set_error("launch_gemm_f16: unsupported amode %d", amode);
     prof_end(ctx);
     return st;

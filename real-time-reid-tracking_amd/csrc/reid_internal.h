@@ -106,7 +106,8 @@ int launch_se_combine_f16(reid_ctx*, const _Float16* y, const _Float16* sc, cons
 int launch_gem_neck_f16(reid_ctx*, const _Float16* x, int n_img, int hw, int c, const float* p, const float* scale,
                         const float* shift, float* gem_out, float* emb);
 int launch_f32_to_f16(reid_ctx*, const float* x, size_t n, _Float16* out);
-int launch_stem_w16(reid_ctx*, const float* stem_w_f32, _Float16* out);   // [64][8][24] -> [64][8][8][4]
+int launch_stem_w16(reid_ctx*, const float* stem_w_f32, _Float16* out);
+int launch_conv_w16_chunked(reid_ctx*, const float* w_f32, int cout, int rs, int cin, _Float16* out);  // -> [Cout][Cin/64][RS][64]   // [64][8][24] -> [64][8][8][4]
 int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int kind, double flops, double bytes);
 
 // elementwise / reduction kernels (elementwise.hip)
@@ -175,6 +176,7 @@ struct reid_ctx {
     int last_n = 0;  // crops in the last embed chunk (for reid_debug_stage)
     bool debug_keep = false;
     bool last_f16 = false;
+    int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
     float* stage_ptr[11] = {nullptr};
 };
 
