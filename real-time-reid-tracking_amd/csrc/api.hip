@@ -290,7 +290,7 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         b.ds_scale = b.ds ? get(n + ".ds.scale", b.c) : nullptr;
         b.ds_shift = b.ds ? get(n + ".ds.shift", b.c) : nullptr;
         b.se_w1 = get(n + ".se.w1", (size_t)b.mid * b.c);
-        b.se_w2 = get(n + ".se.w2", (size_t)b.c * b.mid);
+        b.se_w2 = get(n + ".se.w2t", (size_t)b.c * b.mid);   // [mid][C]
     }
     w.gem_p = get("gem.p", 1);
     w.neck_scale = get("neck.scale", 512);
@@ -502,7 +502,7 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
 
     if (is_u8) REID_TRY(launch_prep_u8_pad_f16(ctx, (const uint8_t*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
     else REID_TRY(launch_prep_f32_pad_f16(ctx, (const float*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
-    REID_TRY(conv_gemm16(ctx, A16_STEM, pad_in, n, IMG_H, IMG_W, 4, w.stem_w16, 64, 7, 7, 2, 3, 256, w.stem_scale, w.stem_shift,
+    REID_TRY(conv_gemm16(ctx, A16_STEM, pad_in, n, IMG_H, IMG_W, 4, w.stem_w16, 64, 7, 7, 2, 3, 224, w.stem_scale, w.stem_shift,
                          nullptr, 0, nullptr, stem, PAD_H, PAD_W));
     REID_TRY(launch_maxpool3s2_f16(ctx, stem, n, 128, 64, 64, pool));
     float* stage[11];
@@ -523,11 +523,18 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
         const int Ho = (H + 2 - 3) / k.stride + 1, Wo = (W + 2 - 3) / k.stride + 1;
         const int hw = Ho * Wo, tiles = hw / 128;
         const int half = k.ibn ? k.c / 2 : 0;
-        REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.conv1_w), k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr,
-                             nullptr, nullptr, 0, stats, c1));
-        REID_TRY(launch_norm_finalize(ctx, stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift,
-                                      a_scale, a_shift));
-        REID_TRY(launch_affine_relu_f16(ctx, c1, a_scale, a_shift, n, hw, k.c));
+        if (k.ibn) {
+            // conv1 raw + per-(image, channel) statistics, then InstanceNorm/BN + ReLU in place
+            REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.conv1_w), k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr,
+                                 nullptr, nullptr, 0, stats, c1));
+            REID_TRY(launch_norm_finalize(ctx, stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift,
+                                          a_scale, a_shift));
+            REID_TRY(launch_affine_relu_f16(ctx, c1, a_scale, a_shift, n, hw, k.c));
+        } else {
+            // plain BatchNorm (layer 4): BN + ReLU go straight into the conv1 epilogue
+            REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.conv1_w), k.c, 3, 3, k.stride, 1, 9 * k.cin,
+                                 k.bn1_scale, k.bn1_shift, nullptr, 1, nullptr, c1));
+        }
         REID_TRY(conv_gemm16(ctx, A16_IM2COL, c1, n, Ho, Wo, k.c, w.h(k.conv2_w), k.c, 3, 3, 1, 1, 9 * k.c, k.bn2_scale,
                              k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, stats, y));
         const f16* shortcut = cur;

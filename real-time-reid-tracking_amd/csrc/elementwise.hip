@@ -135,7 +135,7 @@ __global__ void norm_finalize_kernel(const float* __restrict__ stats, int tiles,
 }
 
 // ---- SEBlock (SERes18_IBN.py:32-41): s = sigmoid(W2 . relu(W1 . avgpool(y))), no bias, norm layer disabled (:36).
-// avgpool comes from the conv2 epilogue's per-tile column sums.  One block per image.
+// avgpool comes from the conv2 epilogue's per-tile column sums.  One block per image.  w1: [mid][c], w2: [mid][c] (fc2^T).
 __global__ __launch_bounds__(256) void se_finalize_kernel(const float* __restrict__ stats, int tiles, int c, int mid,
                                                           int hw, const float* __restrict__ w1,
                                                           const float* __restrict__ w2, float* __restrict__ s) {
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(256) void se_finalize_kernel(const float* __restric
         if (lane == 0) hid[m] = fmaxf(acc, 0.f);
     }
     __syncthreads();
-    for (int ch = tid; ch < c; ch += 256) {
+    for (int ch = tid; ch < c; ch += 256) {   // w2 is stored transposed, [mid][c]: coalesced across threads
         float acc = 0.f;
-        for (int m = 0; m < mid; ++m) acc += w2[ch * mid + m] * hid[m];
+        for (int m = 0; m < mid; ++m) acc += w2[m * c + ch] * hid[m];
         s[(long long)img * c + ch] = 1.0f / (1.0f + expf(-acc));
     }
 }

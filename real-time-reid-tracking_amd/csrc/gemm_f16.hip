@@ -187,19 +187,37 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
 
     // ------------------------------------------------------------------ epilogue (fp32 math, f16 stores)
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float* stat_lds = (float*)lds;  // [WM][BN][2]
     const int ldc = (int)p.ldc;
     f16* Cb = p.C + (long long)m_blk * ldc + n_blk;
     const f16* Rb = p.residual ? p.residual + (long long)m_blk * ldc + n_blk : nullptr;
     const int row0 = wm * WTM + 4 * lh;
     const int m_valid = p.M - m_blk;  // rows of this tile that exist (>= 256 except for a ragged last tile)
+
+    // The residual tile [256][BN] f16 is brought into the (now free) LDS ring by DMA and read from there: per-lane
+    // 2-byte global loads would be 128 latency-serialised round trips per lane (measured +40 us per launch).
+    constexpr bool RES_LDS = BM * BN * 2 <= NST * STAGE;
+    if (RES_LDS && Rb) {
+        constexpr int RROW = BN * 2, RCH = RROW / 16, RRPI = 1024 / RROW, RJ = BM / RRPI / 8;
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            const int inst = wave * RJ + j;
+            const int row = inst * RRPI + lane / RCH;
+            const f16* src = row < m_valid ? Rb + (long long)row * ldc + (lane % RCH) * 8 : p.zero_page;
+            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(lds + inst * 1024), 16, 0, 0);
+        }
+        __syncthreads();  // drains the DMA (vmcnt(0)) and publishes it
+    }
+    const f16* Rl = (const f16*)lds;
+
+    float s1[TN], s2[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int lcol = wn * WTN + b * 32 + li;
         const int col = n_blk + lcol;
         float cs = 1.f, sh = 0.f;
         if (p.col_scale) { cs = p.col_scale[col]; sh = p.col_shift[col]; }
-        float s1 = 0.f, s2 = 0.f;
+        s1[b] = 0.f;
+        s2[b] = 0.f;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -209,25 +227,29 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
                 float v = acc[a][b][e];
                 if (rl < m_valid) {
                     if (p.col_scale) v = v * cs + sh;
-                    if (Rb) v += (float)Rb[off];
+                    if (Rb) v += RES_LDS ? (float)Rl[rl * BN + lcol] : (float)Rb[off];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    s1 += v;
-                    s2 += v * v;
+                    s1[b] += v;
+                    s2[b] += v * v;
                     Cb[off] = (f16)v;
                 }
-            }
-        }
-        if (p.stats) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lh == 0) {
-                stat_lds[(wm * BN + lcol) * 2 + 0] = s1;
-                stat_lds[(wm * BN + lcol) * 2 + 1] = s2;
             }
         }
     }
     if (p.stats) {
         // statistics are kept per 128-row tile (= per image for the 16x8 maps): the block covers two of them
+        float* stat_lds = (float*)lds;  // [WM][BN][2]
+        if (RES_LDS && Rb) __syncthreads();  // every wave has finished reading the residual tile
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * WTN + b * 32 + li;
+            const float t1 = s1[b] + __shfl_xor(s1[b], 32);
+            const float t2 = s2[b] + __shfl_xor(s2[b], 32);
+            if (lh == 0) {
+                stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
+                stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
+            }
+        }
         __syncthreads();
         for (int t = tid; t < 2 * BN; t += 512) {
             const int half = t / BN, c = t - half * BN;

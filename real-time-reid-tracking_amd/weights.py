@@ -124,7 +124,8 @@ def pack_seres18(state_dict):
             pk.add(sh + ".ds.shift", b)
         mid = synth.se_mid(c)
         pk.add(sh + ".se.w1", np.asarray(sd[name + ".seblock.fc1.weight"], np.float32).reshape(mid, c))
-        pk.add(sh + ".se.w2", np.asarray(sd[name + ".seblock.fc2.weight"], np.float32).reshape(c, mid))
+        # fc2 stored transposed [mid][C]: the SE kernel reads it with consecutive threads on consecutive channels
+        pk.add(sh + ".se.w2t", np.ascontiguousarray(np.asarray(sd[name + ".seblock.fc2.weight"], np.float32).reshape(c, mid).T))
     p = sd.get("avgpooling.p", np.asarray([3.0], np.float32))   # GeM init p=3 (attention_pooling.py:52)
     pk.add("gem.p", np.asarray(p, np.float32).reshape(1))
     s, b = fold_bn(sd, "bnneck")

@@ -60,7 +60,7 @@ def test_pack_seres18_layout():
     g, v = sd["basicBlock41.block_pre.bn1.weight"], sd["basicBlock41.block_pre.bn1.running_var"]
     np.testing.assert_allclose(blob[off:off + cnt], g / np.sqrt(v + 1e-5), rtol=1e-6)
     assert tab["b11.n1.in_gamma"][1] == 32 and tab["b11.n1.bn_scale"][1] == 32 and tab["b41.n1.bn_scale"][1] == 512
-    assert tab["b31.se.w1"][1] == 16 * 256 and tab["b42.se.w2"][1] == 512 * 32
+    assert tab["b31.se.w1"][1] == 16 * 256 and tab["b42.se.w2t"][1] == 512 * 32
 
 
 def test_pack_accepts_dataparallel_and_renorm_checkpoints():
