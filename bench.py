@@ -44,6 +44,18 @@ def host_cores():
     return n
 
 
+def traffic_from_profile(f16):
+    """HBM-side bytes per launch of the conv-GEMM class from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
+    per the gfx950 correction, WRITE_SIZE as is); cannot be measured from inside the process."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_conv_f16.json")
+    if not f16 or not os.path.exists(path):
+        return None
+    try:
+        return round(json.load(open(path))["hbm_bytes_per_launch"], 1)
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(sd, budget_s=12.0):
     """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload:
     batch 64 (reference default --bs 64), all host cores."""
@@ -60,7 +72,7 @@ def cpu_baseline(sd, budget_s=12.0):
         embs.append(seres18.embed_u8(sd, crops))
         n += 64
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 1024:
+        if el > budget_s or n >= 8192:
             break
     emb = np.concatenate(embs, 0)
     x = np.tile(emb, (max(1, 1024 // emb.shape[0]) + 1, 1))[:1024]
@@ -79,9 +91,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--crops", type=int, default=4096, help="crops per GPU per step (BASELINE config 2: 4096)")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "128")))
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "512")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f32"),
+    ap.add_argument("--single", action="store_true", help="measure only --precision (skip the other arithmetic)")
+    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f16"),
                     help="f32 = exact fp32 MFMA; f16 = fp16 storage / fp32 accumulate (1e-3 cosine tolerance of north_star)")
     args = ap.parse_args()
 
@@ -107,19 +120,17 @@ def main():
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
     eng.set_chunk(args.chunk)
-    eng.set_precision(1 if args.precision == "f16" else 0)
     sd = synth.seres18_state_dict(0, gem_p=3.0)
     blob, manifest, _ = weights.pack_seres18(sd)
     eng.load_seres18(blob, manifest)
 
     n, d = args.crops, 512
-    # synthetic crops, resident in HBM before the timed region (a 16-crop tile repeated with a per-rank roll)
+    # synthetic crops, resident in HBM before the timed region (256 distinct crops per rank, repeated)
     base = synth.crops_u8(256, seed=1 + rank)
     crops = torch.from_numpy(base).cuda().repeat((n + 255) // 256, 1, 1, 1)[:n].contiguous()
     emb = torch.empty((n, d), dtype=torch.float32, device="cuda")
     gathered = torch.empty((n * world, d), dtype=torch.float32, device="cuda") if world > 1 else emb
     distmat = torch.empty((n, n * world), dtype=torch.float32, device="cuda")
-
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 
     def step(timed=None):
@@ -139,57 +150,88 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run(precision, steps, warmup):
+        """Timed region per the bench contract + a profiled repeat of the same steps for the roofline object."""
+        eng.set_precision(1 if precision == "f16" else 0)
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # split of one step (embed / all-gather+distmat), HIP events on the launch stream
+        step(timed=True)
+        torch.cuda.synchronize()
+        embed_ms, match_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+        # roofline of the dominant kernel class (implicit-GEMM convolutions): the same steps again with every launch
+        # of the class bracketed by HIP events on its stream
+        eng.profile_reset()
+        eng.profile(True)
+        tp = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        prof_ms = (time.perf_counter() - tp) * 1e3 / steps
+        conv, dgm, elt = (eng.profile_get(k) for k in (_ffi.K_CONV_GEMM, _ffi.K_DIST_GEMM, _ffi.K_ELEMENTWISE))
+        eng.profile(False)
+        f16 = precision == "f16"
+        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+        conv_tflops = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        return {
+            "value": round(n * world * steps / elapsed, 1), "ms_per_step": round(elapsed * 1e3 / steps, 3),
+            "embed_ms": round(embed_ms, 3), "embed_crops_per_s_per_gpu": round(n / (embed_ms * 1e-3), 1),
+            "distmat_ms": round(match_ms, 3),
+            "whole_net_fraction_of_mfma_peak": round(FLOP_PER_CROP * n / (embed_ms * 1e-3) / 1e12 / peak, 4),
+            "whole_net_fraction_of_hbm_roofline": round(FUSED_BYTES_PER_CROP * (0.5 if f16 else 1.0) * n / (embed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "roofline": {
+                "kernel": ("gemm_f16_kernel<im2col> (implicit-GEMM convolutions, v_mfma_f32_32x32x16_f16, LDS-DMA ring)" if f16 else
+                           "gemm_f32_kernel<im2col> (implicit-GEMM convolutions, v_mfma_f32_32x32x2_f32)"),
+                "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile(f16),
+                "launches": conv["launches"], "avg_launch_us": round(conv["ms"] * 1e3 / max(1, conv["launches"]), 2),
+                "algorithmic_gflop_per_launch": round(conv["flops"] / max(1, conv["launches"]) / 1e9, 3),
+                "algorithmic_bytes_per_launch": round(conv["bytes"] / max(1, conv["launches"]), 1),
+                "profiled_ms_per_step": round(prof_ms, 3),
+            },
+            "other_kernels": {
+                "distmat_gemm": {"ms_per_launch": round(dgm["ms"] / max(1, dgm["launches"]), 3),
+                                 "tflops": round(dgm["flops"] / max(dgm["ms"], 1e-9) / 1e9, 2),
+                                 "gbs": round(dgm["bytes"] / max(dgm["ms"], 1e-9) / 1e6, 1)},
+                "elementwise": {"ms_per_step": round(elt["ms"] / steps, 3),
+                                "gbs": round(elt["bytes"] / max(elt["ms"], 1e-9) / 1e6, 1)},
+            },
+        }
 
-    # split of one step (embed / all-gather+distmat), HIP events on the launch stream
-    step(timed=True)
-    torch.cuda.synchronize()
-    embed_ms, match_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    main_res = run(args.precision, args.steps, args.warmup)
+    other = "f32" if args.precision == "f16" else "f16"
+    other_res = run(other, max(1, min(2, args.steps)), 1) if not args.single else None
 
-    # roofline of the dominant kernel (implicit-GEMM convolution): the same K steps again with every launch of the
-    # class bracketed by HIP events on its stream
-    eng.profile_reset()
-    eng.profile(True)
-    tp = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    # parity inside the bench: the two precisions agree on the embeddings of this rank (cosine) and on row arg-mins
+    eng.set_precision(1)
+    eng.embed_u8_dev(crops.data_ptr(), 256, emb.data_ptr())
+    e16 = emb[:256].clone()
+    eng.set_precision(0)
+    eng.embed_u8_dev(crops.data_ptr(), 256, emb.data_ptr())
     torch.cuda.synchronize()
-    prof_ms_per_step = (time.perf_counter() - tp) * 1e3 / args.steps
-    conv = eng.profile_get(_ffi.K_CONV_GEMM)
-    dgm = eng.profile_get(_ffi.K_DIST_GEMM)
-    elt = eng.profile_get(_ffi.K_ELEMENTWISE)
-    eng.profile(False)
-
-    # parity spot check inside the bench: row arg-min of the block this rank computed
-    idx = torch.empty(8, dtype=torch.int32, device="cuda")
-    eng.argmin_rows_dev(emb.data_ptr(), 8, gathered.data_ptr(), n * world, d, _ffi.METRIC_L2, idx.data_ptr())
-    torch.cuda.synchronize()
+    e32 = emb[:256]
+    cos_err = float((1 - torch.nn.functional.cosine_similarity(e16, e32, dim=1)).max().item())
 
     if rank == 0:
-        total_crops = n * world * args.steps
-        ms_per_step = elapsed * 1e3 / args.steps
-        conv_tflops = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         f16 = args.precision == "f16"
-        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "crops/sec embedded + NxM distmat ms, ResNet18-SE 128x256",
-            "value": round(total_crops / elapsed, 1),
+            "value": main_res["value"],
             "unit": "crops/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -198,34 +240,14 @@ def main():
             "config": {"workload": "BASELINE configs[1]: ResNet18-SE embed %d uint8 crops (128x256) per GPU + %dx%d L2 distmat"
                                    % (n, n, n * world),
                        "crops_per_gpu": n, "embed_dim": d, "chunk": args.chunk,
+                       "arithmetic": ("fp16 storage, fp32 accumulate (north_star tolerance 1e-3 cosine; measured below)" if f16
+                                      else "exact fp32 (v_mfma_f32_32x32x2_f32)"),
                        "sharding": "crops sharded by rank, one RCCL all-gather of [N,512] embeddings" if world > 1 else "single GPU"},
-            "embed_ms": round(embed_ms, 3),
-            "embed_crops_per_s_per_gpu": round(n / (embed_ms * 1e-3), 1),
-            "distmat_ms": round(match_ms, 3),
-            "whole_net_fraction_of_mfma_peak": round(FLOP_PER_CROP * n / (embed_ms * 1e-3) / 1e12 / peak, 4),
-            "whole_net_fraction_of_hbm_roofline": round(FUSED_BYTES_PER_CROP * (0.5 if f16 else 1.0) * n / (embed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-            "roofline": {
-                "kernel": ("gemm_f16_kernel<im2col> (implicit-GEMM convolutions, v_mfma_f32_32x32x16_f16, LDS-DMA staging)" if f16 else
-                           "gemm_f32_kernel<im2col> (3x3/1x1/7x7 implicit-GEMM convolutions, v_mfma_f32_32x32x2_f32)"),
-                "bound": "mfma",
-                "achieved": round(conv_tflops, 2),
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": round(conv_tflops / peak, 4),
-                "traffic": None,
-                "launches": conv["launches"],
-                "avg_launch_us": round(conv["ms"] * 1e3 / max(1, conv["launches"]), 2),
-                "algorithmic_gflop_per_launch": round(conv["flops"] / max(1, conv["launches"]) / 1e9, 3),
-                "profiled_ms_per_step": round(prof_ms_per_step, 3),
-            },
-            "other_kernels": {
-                "distmat_gemm": {"ms_per_launch": round(dgm["ms"] / max(1, dgm["launches"]), 3),
-                                 "tflops": round(dgm["flops"] / max(dgm["ms"], 1e-9) / 1e9, 2),
-                                 "gbs": round(dgm["bytes"] / max(dgm["ms"], 1e-9) / 1e6, 1)},
-                "elementwise": {"ms_per_step": round(elt["ms"] / args.steps, 3),
-                                "gbs": round(elt["bytes"] / max(elt["ms"], 1e-9) / 1e6, 1)},
-            },
+            "f16_vs_f32_max_cosine_err": cos_err,
         }
+        out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
+        if other_res is not None:
+            out[other + "_path"] = other_res
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out))
