@@ -213,6 +213,43 @@ def gen_factory():
     print("factory:", res["get_model_name"])
 
 
+def gen_swin():
+    """Reference swin_t (version v1) with a stubbed timm (only trunc_normal_ / Mlp are imported, swin_transformer.py:12-13)."""
+    from reid_amd import synth
+    tl = types.ModuleType("timm.models.layers")
+    tl.trunc_normal_ = torch.nn.init.trunc_normal_
+    tl.Mlp = type("Mlp", (nn.Module,), {"__init__": lambda self, *a, **k: nn.Module.__init__(self)})
+    for n in ("timm", "timm.models"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["timm.models.layers"] = tl
+    from reid.backbones.swin_transformer import swin_t  # the reference's own class
+
+    seed, n = 0, 2
+    sd_np = synth.swin_state_dict(seed)
+    model = swin_t(num_classes=751, loss="triplet")
+    res = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model.eval()
+    x = torch.from_numpy(synth.images_f32(n, seed))
+    taps = {}
+    hooks = [getattr(model, name).register_forward_hook(lambda m, i, o, name=name: taps.__setitem__(name, o.detach().clone()))
+             for name in ("sfe", "stage1", "stage2", "stage3", "stage4", "norm", "avgpool")]
+    with torch.no_grad():
+        logits, emb = model(x)          # eval returns (y, x_norm), swin_transformer.py:422-423
+    for h in hooks:
+        h.remove()
+    out = {"seed": np.int64(seed), "n": np.int64(n), "emb": emb.numpy(), "logits": logits.numpy()}
+    for k, v in taps.items():
+        if v.dim() == 4:
+            out["tap_" + k] = _sample(v)
+        else:
+            out["tap_" + k] = v[:, :: max(1, v.shape[1] // 8)].contiguous().numpy() if v.dim() == 3 else v.numpy()
+        out["mean_" + k] = np.float64(v.double().mean().item())
+        out["absmean_" + k] = np.float64(v.double().abs().mean().item())
+    np.savez_compressed(os.path.join(OUT, "swin_seed0.npz"), **out)
+    print("swin emb", emb.shape, "absmean taps", {k: round(float(out["absmean_" + k]), 3) for k in taps})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -221,3 +258,4 @@ if __name__ == "__main__":
     gen_matching()
     gen_factory()
     gen_seres18()
+    gen_swin()

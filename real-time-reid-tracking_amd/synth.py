@@ -140,3 +140,88 @@ def clustered_embeddings(nq, ng, d=512, n_ids=751, n_cams=6, seed=4, sigma=0.3):
     qf = (qf / np.linalg.norm(qf, axis=1, keepdims=True)).astype(np.float32)
     gf = (gf / np.linalg.norm(gf, axis=1, keepdims=True)).astype(np.float32)
     return qf, ql, qc, gf, gl, gc
+
+
+# ------------------------------------------------------------------------------------------------ Swin-T (v1)
+SWIN_DIMS = (96, 192, 384, 768)
+SWIN_LAYERS = (2, 2, 6, 2)
+SWIN_HEADS = (3, 6, 12, 24)
+
+
+def _lin(rng, sd, prefix, cout, cin, bias=True, gain=1.0):
+    sd[prefix + ".weight"] = rng.normal(0.0, np.sqrt(gain / cin), (cout, cin)).astype(np.float32)
+    if bias:
+        sd[prefix + ".bias"] = rng.normal(0.0, 0.1, cout).astype(np.float32)
+
+
+def _ln(rng, sd, prefix, c):
+    sd[prefix + ".weight"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    sd[prefix + ".bias"] = rng.normal(0.0, 0.1, c).astype(np.float32)
+
+
+def _swin_mask(ws, disp, upper_lower):
+    """create_mask of reid/backbones/swin_transformer.py:95-108 (0 / -inf), restated."""
+    m = np.zeros((ws * ws, ws * ws), np.float32)
+    idx = np.arange(ws * ws)
+    key = idx // ws if upper_lower else idx % ws
+    hi = key >= ws - disp
+    m[np.not_equal.outer(hi, hi)] = -np.inf
+    return m
+
+
+def swin_state_dict(seed=0, num_class=751):
+    """numpy ``state_dict`` with exactly the keys/shapes of ``swin_t(version='v1').state_dict()``
+    (reid/backbones/swin_transformer.py:339-395,508-513; 40.8 M parameters)."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    sd["sfe.conv1.weight"] = rng.normal(0, np.sqrt(1.0 / 12), (12, 3, 2, 2)).astype(np.float32)
+    sd["sfe.conv1.bias"] = rng.normal(0, 0.1, 12).astype(np.float32)
+    sd["sfe.conv2.weight"] = rng.normal(0, np.sqrt(2.0 / 48), (48, 12, 2, 2)).astype(np.float32)
+    sd["sfe.conv2.bias"] = rng.normal(0, 0.1, 48).astype(np.float32)
+    sd["sfe.norm.instancenorm.weight"] = rng.uniform(0.5, 1.5, 6).astype(np.float32)
+    sd["sfe.norm.instancenorm.bias"] = rng.normal(0, 0.1, 6).astype(np.float32)
+    _bn(rng, sd, "sfe.norm.batchnorm", 6)
+    _lin(rng, sd, "sfe.fc", 96, 48, gain=2.0)
+    cin = 96
+    for si, (c, nl, _h) in enumerate(zip(SWIN_DIMS, SWIN_LAYERS, SWIN_HEADS)):
+        st = "stage%d" % (si + 1)
+        down = 4 if si == 0 else 2
+        _lin(rng, sd, st + ".patch_partition.linear", c, cin * down * down)   # stage1's is never used (patch_merge=False)
+        for li in range(nl // 2):
+            for bi in range(2):
+                pre = "%s.layers.%d.%d" % (st, li, bi)
+                _ln(rng, sd, pre + ".attention_block.fn.norm", c)
+                if bi == 1:
+                    sd[pre + ".attention_block.fn.fn.upper_lower_mask"] = _swin_mask(7, 3, True)
+                    sd[pre + ".attention_block.fn.fn.left_right_mask"] = _swin_mask(7, 3, False)
+                sd[pre + ".attention_block.fn.fn.pos_embedding"] = rng.normal(0, 0.5, (13, 13)).astype(np.float32)
+                _lin(rng, sd, pre + ".attention_block.fn.fn.to_qkv", 3 * c, c, bias=False)
+                _lin(rng, sd, pre + ".attention_block.fn.fn.to_out", c, c, gain=0.5)
+                _lin(rng, sd, pre + ".attention_block.fn.fn.post_proj", c, c, gain=0.5)
+                _ln(rng, sd, pre + ".mlp_block.fn.norm", c)
+                _lin(rng, sd, pre + ".mlp_block.fn.fn.net.0", 4 * c, c, gain=2.0)
+                _lin(rng, sd, pre + ".mlp_block.fn.fn.net.3", c, 4 * c, gain=0.5)
+        cin = c
+    _ln(rng, sd, "norm", 96)
+    _bn(rng, sd, "bottleneck", 96)
+    sd["mlp_head.0.weight"] = rng.normal(0, 0.05, (num_class, 96)).astype(np.float32)
+    sd["img_channel_align.weight"] = rng.normal(0, np.sqrt(0.5 / (96 * 64)), (768, 96, 8, 8)).astype(np.float32)
+    sd["img_channel_align.bias"] = rng.normal(0, 0.1, 768).astype(np.float32)
+    for name, ci, co in (("stage4_channel_align", 768, 384), ("stage3_channel_align", 384, 192), ("stage2_channel_align", 192, 96)):
+        sd[name + ".weight"] = rng.normal(0, np.sqrt(0.5 / (ci * 4)), (ci, co, 4, 4)).astype(np.float32)
+        sd[name + ".bias"] = rng.normal(0, 0.1, co).astype(np.float32)
+    sd["avgpool.p"] = np.asarray([float(rng.uniform(2.5, 3.5))], np.float32)
+    return sd
+
+
+def images_f32(n, seed=0, h=224, w=224):
+    """Normalised float images [n,3,h,w] in [-1,1] with low-frequency structure (Swin needs 224x224)."""
+    rng = np.random.default_rng(seed)
+    yy = np.linspace(0, 1, h, dtype=np.float32)[None, None, :, None]
+    xx = np.linspace(0, 1, w, dtype=np.float32)[None, None, None, :]
+    a = rng.uniform(-1, 1, (n, 3, 1, 1)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, 3, 1, 1)).astype(np.float32)
+    f = rng.uniform(1, 5, (n, 3, 1, 1)).astype(np.float32)
+    x = 0.5 * a * yy + 0.5 * b * xx + 0.3 * np.sin(2 * np.pi * f * yy) * np.cos(2 * np.pi * f * xx)
+    x = x + rng.normal(0, 0.15, (n, 3, h, w)).astype(np.float32)
+    return np.clip(x, -1, 1).astype(np.float32)

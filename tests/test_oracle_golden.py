@@ -98,3 +98,25 @@ def test_preprocess_known_answers():
     # (iii) downscale 4 -> 2 without antialias: samples at 0.5 and 2.5 -> mean of neighbours
     ramp = np.arange(4, dtype=np.float32)[None, :, None].repeat(4, 0)
     np.testing.assert_allclose(matching.resize_bilinear(ramp, (2, 2))[:, :, 0], [[0.5, 2.5], [0.5, 2.5]], atol=1e-7)
+
+
+def test_swin_oracle_matches_reference(golden_dir):
+    """oracle/swin.py against the reference's own swin_t (v1) outputs on seeded weights, 224x224, N=2 (Q14)."""
+    from oracle import swin
+    g = np.load(os.path.join(golden_dir, "swin_seed0.npz"))
+    seed, n = int(g["seed"]), int(g["n"])
+    sd = synth.swin_state_dict(seed)
+    taps = {}
+    emb, logits = swin.forward(sd, torch.from_numpy(synth.images_f32(n, seed)), taps)
+    np.testing.assert_allclose(emb.numpy(), g["emb"], rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=5e-4, atol=5e-3)
+    cos = (emb.numpy() * g["emb"]).sum(1) / np.linalg.norm(emb.numpy(), axis=1) / np.linalg.norm(g["emb"], axis=1)
+    assert (1 - cos).max() < 1e-6
+    # reference stage modules return NCHW; the restatement keeps NHWC tokens
+    for name in ("sfe", "stage1", "stage2", "stage3", "stage4"):
+        mine = taps[name].permute(0, 3, 1, 2)
+        np.testing.assert_allclose(_sample(mine), g["tap_" + name], rtol=5e-4, atol=5e-4, err_msg=name)
+        assert abs(float(mine.double().mean()) - float(g["mean_" + name])) < 2e-4
+    # masks of the shifted blocks as emitted by synth == the reference's create_mask (loaded strict=True in gen_golden)
+    m = sd["stage1.layers.0.1.attention_block.fn.fn.upper_lower_mask"]
+    assert np.isinf(m[0, 48]) and m[0, 27] == 0 and np.isinf(m[48, 0]) and m[48, 28] == 0
