@@ -112,6 +112,14 @@ int reid_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, float* d_emb
 int reid_ctx_set_debug_keep(reid_ctx* ctx, int on);   /* give every stage its own buffer (tests only) */
 int reid_debug_stage(reid_ctx* ctx, int stage, float* out_host, size_t max_floats, size_t* count);
 
+/* ---- Swin-T backbone (reference "v1": reid/backbones/swin_transformer.py:339-427, swin_t :508-513) -------------------
+ * Packed weights from reid_amd.weights.pack_swin.  Input: normalised float images fp32[n][3][h][w] NCHW with h, w multiples
+ * of 224 (the reference rejects 128x256); output: 96-d BatchNorm'd embedding (x_norm, :421) and logits. */
+int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats, const char* manifest);
+int reid_swin_dims(reid_ctx* ctx, int* embed_dim, int* num_class);
+int reid_swin_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, int h, int w, float* emb, float* logits);
+int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int h, int w, float* d_emb, float* d_logits);
+
 /* ---- matching ----------------------------------------------------------------------------- */
 /* out[m][n] = metric(x[m][d], y[n][d])        reid/losses/utils.py:12-35, reid/evaluate.py:58 */
 int reid_distmat(reid_ctx* ctx, const float* x, int m, const float* y, int n, int d, int metric, float* out);

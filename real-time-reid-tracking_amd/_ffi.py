@@ -40,6 +40,10 @@ _SIGS = {
     "reid_embed_ragged_u8": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "reid_embed_f32_nchw": (_i, [_vp, _vp, _i, _vp, _vp]),
     "reid_embed_f32_nchw_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "reid_swin_load": (_i, [_vp, _vp, _sz, C.c_char_p]),
+    "reid_swin_dims": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "reid_swin_embed_f32_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "reid_swin_embed_f32_nchw_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "reid_ctx_set_debug_keep": (_i, [_vp, _i]),
     "reid_debug_stage": (_i, [_vp, _i, _vp, _sz, C.POINTER(_sz)]),
     "reid_distmat": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),

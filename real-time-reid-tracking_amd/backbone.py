@@ -146,3 +146,83 @@ class SERes18IBN:
 def seres18_ibn(num_classes=751, loss="triplet", pretrained=False, use_gpu=True, **kwargs):
     """Factory with the registry's calling convention (models/__init__.py:116-121)."""
     return SERes18IBN(num_classes=num_classes, loss=loss, pretrained=pretrained, use_gpu=use_gpu, **kwargs)
+
+
+class SwinT:
+    """The reference's custom Swin-T, version "v1" (reid/backbones/swin_transformer.py:339-427, swin_t :508-513): conv stem,
+    4 stages of (W-MSA, SW-MSA) blocks, top-down ConvTranspose fusion, LN -> GeM_1D -> BatchNorm1d(96).
+
+    ``model(x)`` -> embedding [N,96] (x_norm); ``model(x, return_logits=True)`` -> (logits, embedding), the order of the
+    reference's eval-mode tuple (:422-423).  ``x``: float [N,3,H,W] with H, W multiples of 224 - the
+    reference itself rejects 128x256.  Unlike the reference (Q14) N = 1 works.
+    """
+
+    embed_dim = 96
+
+    def __init__(self, num_classes=751, loss="softmax", pretrained=False, use_gpu=True, seed=0, **_):
+        self.num_classes = num_classes
+        self.loss = loss
+        self.training = False
+        self._device = 0
+        self._sd = synth.swin_state_dict(seed, num_class=num_classes)
+        self._dirty = True
+        if pretrained:
+            import warnings
+            warnings.warn("no pretrained Swin weights are reachable offline (pretrained_urls is empty in the reference, "
+                          "swin_transformer.py:19); keeping the seeded random initialisation")
+
+    to = SERes18IBN.to
+    cuda = SERes18IBN.cuda
+    half = SERes18IBN.half
+    float = SERes18IBN.float
+    eval = SERes18IBN.eval
+    train = SERes18IBN.train
+    parameters = SERes18IBN.parameters
+    state_dict = SERes18IBN.state_dict
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = weights.normalize_state_dict(state_dict)
+        missing = [k for k in self._sd if k not in sd]
+        unexpected = [k for k in sd if k not in self._sd]
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
+        for k, v in sd.items():
+            if k in self._sd and tuple(self._sd[k].shape) == tuple(v.shape):
+                self._sd[k] = np.asarray(v).astype(self._sd[k].dtype)
+        self._dirty = True
+        return missing, unexpected
+
+    def _engine(self):
+        eng = get_engine(self._device)
+        if self._dirty or getattr(eng, "_swin_owner", None) is not self:
+            blob, manifest, _ = weights.pack_swin(self._sd)
+            eng.load_swin(blob, manifest)
+            eng._swin_owner = self
+            self._dirty = False
+        return eng
+
+    def warmup(self, imgsz=(1, 3, 224, 224)):
+        self(np.zeros(imgsz, np.float32))
+        return self
+
+    def __call__(self, x, view_index=None, return_logits=False):
+        if view_index is not None:
+            raise NotImplementedError("side-information embedding (swin_transformer.py:301-302) is not used by the plugin path")
+        is_torch = hasattr(x, "detach")
+        if is_torch:
+            dev = x.device
+            x_np = x.detach().float().cpu().numpy()
+        else:
+            x_np = np.asarray(x, np.float32)
+        emb, logits = self._engine().swin_embed_f32_nchw(x_np, logits=True)
+        if is_torch:
+            import torch
+            emb, logits = torch.from_numpy(emb).to(dev), torch.from_numpy(logits).to(dev)
+        return (logits, emb) if return_logits else emb
+
+    forward = __call__
+
+
+def swin_t(num_classes=751, loss="softmax", pretrained=False, use_gpu=True, **kwargs):
+    """Registry constructor, same name as the reference's (swin_transformer.py:508)."""
+    return SwinT(num_classes=num_classes, loss=loss, pretrained=pretrained, use_gpu=use_gpu, **kwargs)

@@ -49,6 +49,7 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     if (!ctx) return REID_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    swin_release(ctx);
     for (auto& kv : ctx->ws) hipFree(kv.second.first);
     if (ctx->se18.blob) hipFree(ctx->se18.blob);
     if (ctx->se18.blob16) hipFree(ctx->se18.blob16);
@@ -342,7 +343,7 @@ static int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int 
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x;
-    p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.S = S; p.stride = stride; p.pad_y = pad; p.pad_x = pad;
     p.Ho = (H + 2 * pad - R) / stride + 1;
     p.Wo = (W + 2 * pad - S) / stride + 1;
     p.a_scale = a_scale; p.a_shift = a_shift; p.a_relu = a_relu;

@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
             const int img = m / hw, rem = m - img * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             rw.img[j] = img;
-            rw.iy0[j] = oy * p.stride - p.pad;
-            rw.ix0[j] = ox * p.stride - p.pad;
+            rw.iy0[j] = oy * p.stride - p.pad_y;
+            rw.ix0[j] = ox * p.stride - p.pad_x;
         }
     }
 
@@ -231,7 +231,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
             for (int e = 0; e < 16; ++e) {
                 const int row = m_blk + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const bool ok = colok && row < p.M;
-                const long long idx = (long long)row * p.ldc + col;
+                long long orow = row;
+                if constexpr (EPI == E_BIAS) {
+                    if (p.scat_h > 0) {   // ConvTranspose2d(4,2,1) output parity: (img, j, i) -> (img, 2j+py, 2i+px)
+                        const int hw = p.scat_h * p.scat_w;
+                        const int img = row / hw, rem = row - img * hw;
+                        const int j = rem / p.scat_w, i = rem - j * p.scat_w;
+                        orow = ((long long)img * 2 * p.scat_h + 2 * j + p.scat_py) * (2 * p.scat_w) + 2 * i + p.scat_px;
+                    }
+                }
+                const long long idx = orow * p.ldc + col;
                 float v = acc[a][b][e];
                 if constexpr (EPI == E_CONV) {
                     if (p.col_scale) v = v * cs + sh;
@@ -240,6 +249,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
                     if (ok) { s1 += v; s2 += v * v; }
                 } else if constexpr (EPI == E_BIAS) {
                     v += sh;
+                    if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU() (erf form)
                 } else {
                     float rs = 0.f;
                     if (ok && p.row_sq) rs = p.row_sq[row];
@@ -250,6 +260,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
                         case REID_METRIC_COS: v = 1.0f - v / (sqrtf(rs) * cq); break;
                         default: break;
                     }
+                }
+                if constexpr (EPI == E_BIAS) {
+                    if (p.residual && ok) v += p.residual[idx];
                 }
                 if (ok) p.C[idx] = v;
             }
@@ -307,6 +320,7 @@ int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int 
     if (amode == A_DENSE && epi == E_DIST) st = launch_bn<A_DENSE, E_DIST>(ctx, p);
     else if (amode == A_DENSE && epi == E_BIAS) st = launch_bn<A_DENSE, E_BIAS>(ctx, p);
     else if (amode == A_IM2COL && epi == E_CONV) st = launch_bn<A_IM2COL, E_CONV>(ctx, p);
+    else if (amode == A_IM2COL && epi == E_BIAS) st = launch_bn<A_IM2COL, E_BIAS>(ctx, p);
     else if (amode == A_STEM_F32 && epi == E_CONV) st = launch_bn<A_STEM_F32, E_CONV>(ctx, p);
     else if (amode == A_STEM_U8 && epi == E_CONV) st = launch_bn<A_STEM_U8, E_CONV>(ctx, p);
     else reid_set_error("launch_gemm_f32: unsupported (amode=%d, epi=%d)", amode, epi);

@@ -45,14 +45,14 @@ enum AMode {
 enum EpiMode {
     E_CONV = 0,  // optional col scale/shift, residual, relu, per-(m-tile, col) sum/sumsq partials
     E_DIST = 1,  // distance epilogue from row/col squared norms
-    E_BIAS = 2   // optional bias[n]
+    E_BIAS = 2   // optional bias[n], GELU, residual, ConvTranspose parity scatter
 };
 
 struct GemmParams {
     const void* A;
     long long lda;
     // im2col geometry
-    int H, W, Cin, Ho, Wo, R, S, stride, pad;
+    int H, W, Cin, Ho, Wo, R, S, stride, pad_y, pad_x;
     const float* a_scale;  // [img][Cin] input transform x' = relu?(x*scale+shift) applied to in-bounds pixels
     const float* a_shift;
     int a_relu;
@@ -66,6 +66,10 @@ struct GemmParams {
     const float* residual;
     int relu;
     float* stats;          // [M/128][N][2] or null
+    // E_BIAS extras: act 1 = exact (erf) GELU after the bias; residual is added after the activation.
+    // scat_h > 0: row m = (img, j, i) of a scat_h x scat_w grid is written to pixel (2j+scat_py, 2i+scat_px) of the
+    // 2x up-sampled grid (one output parity of a ConvTranspose2d(4, 2, 1)); residual uses the same index.
+    int act, scat_h, scat_w, scat_py, scat_px;
     const float* row_sq;   // E_DIST
     const float* col_sq;
     int metric;
@@ -180,6 +184,7 @@ struct reid_ctx {
     float* stage_ptr[11] = {nullptr};
 };
 
+void swin_release(reid_ctx* ctx);   // frees the Swin weights held for this context (swin.hip)
 int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out);  // grow-only named workspace
 void prof_begin(reid_ctx* ctx, int kind, double flops, double bytes);
 void prof_end(reid_ctx* ctx);

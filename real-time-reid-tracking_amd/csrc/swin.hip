@@ -1,0 +1,605 @@
+// Swin-T (reference "v1": reid/backbones/swin_transformer.py) on the device: token layout [image][y][x][C] fp32.
+// Every Linear / patch-merge / 8x8 conv / ConvTranspose is a launch of the f32 MFMA GEMM (gemm_f32.hip) with fused
+// bias / GELU / residual epilogues; this file holds the kernels that are not GEMMs (stem, LayerNorm, window attention,
+// LN + GeM_1D + BN tail) and the launch sequence.
+//
+// Cyclic shift: LayerNorm and every Linear are per-token, so the roll(-3,-3) ... roll(+3,+3) pair of a shifted block
+// (swin_transformer.py:193-194,230-231) is folded into the attention kernel's indexing alone: window position (y', x')
+// reads and writes token ((y'+3) % H, (x'+3) % W).
+#include "reid_internal.h"
+#include <math.h>
+#include <string.h>
+#include <sstream>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- ShadowFeatureExtraction part 1 (swin_transformer.py:297): conv2x2 s2 (3 -> 12, bias), NCHW in, NHWC12 out
+__global__ void sfe_conv1_kernel(const float* __restrict__ x, int n, int h, int w, const float* __restrict__ wgt,
+                                 const float* __restrict__ bias, float* __restrict__ out) {
+    const int ho = h / 2, wo = w / 2;
+    const long long total = (long long)n * ho * wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % wo);
+        const long long t = i / wo;
+        const int oy = (int)(t % ho);
+        const int img = (int)(t / ho);
+        float in[12];  // (kh, kw, c)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    in[(kh * 2 + kw) * 3 + c] = x[(((long long)img * 3 + c) * h + 2 * oy + kh) * w + 2 * ox + kw];
+        float* o = out + i * 12;
+#pragma unroll
+        for (int co = 0; co < 12; ++co) {
+            float acc = bias[co];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc += wgt[co * 12 + k] * in[k];
+            o[co] = acc;
+        }
+    }
+}
+
+// ---- MixedNorm statistics (swin_transformer.py:42-54): per image, channels 0..5 InstanceNorm (biased var, eps 1e-5),
+// channels 6..11 eval BatchNorm (folded on the host) -> per-(image, channel) affine
+__global__ __launch_bounds__(256) void sfe_norm_kernel(const float* __restrict__ y, int hw, const float* __restrict__ in_g,
+                                                       const float* __restrict__ in_b, const float* __restrict__ bn_s,
+                                                       const float* __restrict__ bn_t, float* __restrict__ ab) {
+    __shared__ double red[4][12];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s1[6], s2[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
+    const float* yi = y + (long long)img * hw * 12;
+    for (int p = tid; p < hw; p += 256) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double v = yi[(long long)p * 12 + c];
+            s1[c] += v;
+            s2[c] += v * v;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1[c] += __shfl_xor(s1[c], o); s2[c] += __shfl_xor(s2[c], o); }
+        if (lane == 0) { red[wave][c] = s1[c]; red[wave][6 + c] = s2[c]; }
+    }
+    __syncthreads();
+    if (tid < 12) {
+        float a, b;
+        if (tid < 6) {
+            const double t1 = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            const double t2 = red[0][6 + tid] + red[1][6 + tid] + red[2][6 + tid] + red[3][6 + tid];
+            const double mean = t1 / hw;
+            double var = t2 / hw - mean * mean;
+            if (var < 0) var = 0;
+            const double inv = 1.0 / sqrt(var + 1e-5);
+            a = (float)(inv * in_g[tid]);
+            b = (float)(in_b[tid] - mean * inv * in_g[tid]);
+        } else {
+            a = bn_s[tid - 6];
+            b = bn_t[tid - 6];
+        }
+        ab[img * 24 + tid] = a;
+        ab[img * 24 + 12 + tid] = b;
+    }
+}
+
+// ---- ShadowFeatureExtraction part 2 (:297-303): MixedNorm + ReLU -> conv2x2 s2 (12 -> 48, bias) -> ReLU -> Linear(48 -> 96)
+// one thread per token; weights in LDS
+__global__ __launch_bounds__(256) void sfe_conv2_fc_kernel(const float* __restrict__ y, const float* __restrict__ ab, int n,
+                                                           int h1, int w1, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, const float* __restrict__ wf,
+                                                           const float* __restrict__ bf, float* __restrict__ tok) {
+    __shared__ float sw2[48 * 48], swf[96 * 48], sb2[48], sbf[96];
+    for (int i = threadIdx.x; i < 48 * 48; i += 256) sw2[i] = w2[i];
+    for (int i = threadIdx.x; i < 96 * 48; i += 256) swf[i] = wf[i];
+    if (threadIdx.x < 48) sb2[threadIdx.x] = b2[threadIdx.x];
+    if (threadIdx.x < 96) sbf[threadIdx.x] = bf[threadIdx.x];
+    __syncthreads();
+    const int ho = h1 / 2, wo = w1 / 2;
+    const long long total = (long long)n * ho * wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % wo);
+        const long long t = i / wo;
+        const int oy = (int)(t % ho);
+        const int img = (int)(t / ho);
+        const float* a = ab + img * 24;
+        float in[48];  // (kh, kw, c)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 2; ++kw) {
+                const float* src = y + (((long long)img * h1 + 2 * oy + kh) * w1 + 2 * ox + kw) * 12;
+#pragma unroll
+                for (int c = 0; c < 12; ++c) in[(kh * 2 + kw) * 12 + c] = fmaxf(src[c] * a[c] + a[12 + c], 0.f);
+            }
+        float mid[48];
+#pragma unroll 4
+        for (int co = 0; co < 48; ++co) {
+            float acc = sb2[co];
+#pragma unroll
+            for (int k = 0; k < 48; ++k) acc += sw2[co * 48 + k] * in[k];
+            mid[co] = fmaxf(acc, 0.f);
+        }
+        float* o = tok + i * 96;
+#pragma unroll 4
+        for (int co = 0; co < 96; ++co) {
+            float acc = sbf[co];
+#pragma unroll
+            for (int k = 0; k < 48; ++k) acc += swf[co * 48 + k] * mid[k];
+            o[co] = acc;
+        }
+    }
+}
+
+// ---- LayerNorm over the channel dimension, one wave per token (C <= 768)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long ntok, int c, float eps,
+                                                        const float* __restrict__ g, const float* __restrict__ b,
+                                                        float* __restrict__ out) {
+    const long long tok = blockIdx.x * 4LL + (threadIdx.x >> 6);
+    if (tok >= ntok) return;
+    const int lane = threadIdx.x & 63;
+    const float* xi = x + tok * c;
+    float v[12];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int ch = lane + 64 * j;
+        v[j] = ch < c ? xi[ch] : 0.f;
+        s += v[j];
+    }
+    const float mean = wsum(s) / c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int ch = lane + 64 * j;
+        const float d = ch < c ? v[j] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wsum(q) / c + eps);
+    float* oi = out + tok * c;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < c) oi[ch] = (v[j] - mean) * rstd * g[ch] + b[ch];
+    }
+}
+
+// ---- WindowAttention v1 (swin_transformer.py:191-232): one wave per (image, window, head); lane = query token (49 of
+// 64 lanes active), K and V of the window/head in LDS (read as broadcasts), softmax in registers.
+// qkv: [tokens][3C] (q | k | v, head-major inside each), out: [tokens][C].
+__global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ qkv, int n_img, int H, int W, int heads,
+                                                          int shifted, const float* __restrict__ pos, float* __restrict__ out) {
+    __shared__ float kv[4][2][49 * 32];
+    __shared__ float spos[169];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 169; i += 256) spos[i] = pos[i];
+    const int nwh = H / 7, nww = W / 7;
+    const long long task = blockIdx.x * 4LL + wave;
+    const long long ntask = (long long)n_img * nwh * nww * heads;
+    const bool live = task < ntask;
+    const int C = heads * 32;
+    int head = 0, wx = 0, wy = 0, img = 0;
+    if (live) {
+        head = (int)(task % heads);
+        long long t = task / heads;
+        wx = (int)(t % nww);
+        t /= nww;
+        wy = (int)(t % nwh);
+        img = (int)(t / nwh);
+    }
+    const int sh = shifted ? 3 : 0;
+    const int iy = lane / 7, ix = lane - iy * 7;
+    const bool act = live && lane < 49;
+    long long tok = 0;
+    if (act) {
+        const int y = (wy * 7 + iy + sh) % H, x = (wx * 7 + ix + sh) % W;
+        tok = ((long long)img * H + y) * W + x;
+    }
+    float q[32];
+    if (act) {
+        const float* base = qkv + tok * 3 * C + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            const f32x4 a = *(const f32x4*)(base + d);
+            const f32x4 b = *(const f32x4*)(base + C + d);
+            const f32x4 c = *(const f32x4*)(base + 2 * C + d);
+            q[d] = a.x; q[d + 1] = a.y; q[d + 2] = a.z; q[d + 3] = a.w;
+            *(f32x4*)&kv[wave][0][lane * 32 + d] = b;
+            *(f32x4*)&kv[wave][1][lane * 32 + d] = c;
+        }
+    }
+    __syncthreads();
+    if (!act) return;
+    const bool last_row = shifted && wy == nwh - 1, last_col = shifted && wx == nww - 1;
+    float s[49];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 49; ++j) {
+        const float* kj = &kv[wave][0][j * 32];
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) acc += q[d] * kj[d];
+        const int jy = j / 7, jx = j - jy * 7;
+        acc = acc * 0.17677669529663687f + spos[(jy - iy + 6) * 13 + (jx - ix + 6)];   // 32^-0.5, relative position bias
+        // masks of the last window row / column of a shifted block (create_mask, :95-108)
+        if (last_row && ((iy >= 4) != (jy >= 4))) acc = -INFINITY;
+        if (last_col && ((ix >= 4) != (jx >= 4))) acc = -INFINITY;
+        s[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < 49; ++j) {
+        s[j] = expf(s[j] - mx);
+        den += s[j];
+    }
+    const float inv = 1.0f / den;
+    float o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 49; ++j) {
+        const float pj = s[j] * inv;
+        const float* vj = &kv[wave][1][j * 32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] += pj * vj[d];
+    }
+    float* dst = out + tok * C + head * 32;
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) {
+        f32x4 v = {o[d], o[d + 1], o[d + 2], o[d + 3]};
+        *(f32x4*)(dst + d) = v;
+    }
+}
+
+// ---- tail (:414-420): LayerNorm(96, eps 1e-6) per token -> GeM_1D over the tokens -> BatchNorm1d.  One block per image.
+__global__ __launch_bounds__(256) void swin_tail_kernel(const float* __restrict__ x, int ntok, const float* __restrict__ g,
+                                                        const float* __restrict__ b, const float* __restrict__ p_ptr,
+                                                        const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                                        float* __restrict__ gem_out, float* __restrict__ emb) {
+    __shared__ float part[4][96];
+    const int img = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float p = p_ptr[0];
+    const float g0 = g[lane], b0 = b[lane];
+    const float g1 = lane < 32 ? g[64 + lane] : 0.f, b1 = lane < 32 ? b[64 + lane] : 0.f;
+    float a0 = 0.f, a1 = 0.f;
+    for (int t = wave; t < ntok; t += 4) {
+        const float* xi = x + ((long long)img * ntok + t) * 96;
+        const float v0 = xi[lane], v1 = lane < 32 ? xi[64 + lane] : 0.f;
+        const float mean = wsum(v0 + v1) / 96.f;
+        const float d0 = v0 - mean, d1 = lane < 32 ? v1 - mean : 0.f;
+        const float rstd = 1.0f / sqrtf(wsum(d0 * d0 + d1 * d1) / 96.f + 1e-6f);
+        a0 += powf(fmaxf(d0 * rstd * g0 + b0, 1e-6f), p);
+        if (lane < 32) a1 += powf(fmaxf(d1 * rstd * g1 + b1, 1e-6f), p);
+    }
+    part[wave][lane] = a0;
+    if (lane < 32) part[wave][64 + lane] = a1;
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        const int c = threadIdx.x;
+        const float m = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / (float)ntok;
+        const float gm = powf(m, 1.0f / p);
+        if (gem_out) gem_out[img * 96 + c] = gm;
+        emb[img * 96 + c] = gm * bn_s[c] + bn_t[c];
+    }
+}
+
+inline int grid_for(long long work, int block) {
+    long long g = (work + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM helpers
+int linear(reid_ctx* ctx, const float* x, long long m, int k, const float* w, const float* bias, int n, int act,
+           const float* residual, float* out) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.lda = k;
+    p.B = w; p.ldb = k;
+    p.M = (int)m; p.N = n; p.K = k;
+    p.C = out; p.ldc = n;
+    p.col_shift = bias; p.act = act; p.residual = residual;
+    return launch_gemm_f32(ctx, A_DENSE, E_BIAS, p, REID_K_CONV_GEMM, 2.0 * m * n * k, 4.0 * ((double)m * k + (double)n * k + (double)m * n));
+}
+
+// generic NHWC conv as implicit GEMM with bias (+residual); scatter for ConvTranspose parities
+int conv_bias(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, const float* w, const float* bias, int Cout, int R,
+              int S, int stride, int pad_y, int pad_x, int Ho, int Wo, const float* residual, float* out, int scat_h = 0,
+              int scat_w = 0, int py = 0, int px = 0) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = x;
+    p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.S = S; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.Ho = Ho; p.Wo = Wo;
+    p.B = w; p.ldb = R * S * Cin;
+    p.M = n * Ho * Wo; p.N = Cout; p.K = R * S * Cin;
+    p.C = out; p.ldc = Cout;
+    p.col_shift = bias; p.residual = residual;
+    p.scat_h = scat_h; p.scat_w = scat_w; p.scat_py = py; p.scat_px = px;
+    const double flops = 2.0 * p.M * Cout * p.K;
+    return launch_gemm_f32(ctx, A_IM2COL, E_BIAS, p, REID_K_CONV_GEMM, flops,
+                           4.0 * ((double)n * H * W * Cin + (double)Cout * p.K + (double)p.M * Cout));
+}
+
+const int kDims[4] = {96, 192, 384, 768}, kLayers[4] = {2, 2, 6, 2}, kHeads[4] = {3, 6, 12, 24};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ weights
+struct SwinBlockW {
+    const float *ln1_g, *ln1_b, *qkv_w, *pos, *out_w, *out_b, *post_w, *post_b, *ln2_g, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+struct SwinWeights {
+    bool loaded = false;
+    float* blob = nullptr;
+    int num_class = 0;
+    const float *c1_w, *c1_b, *in_g, *in_b, *bn_s, *bn_t, *c2_w, *c2_b, *fc_w, *fc_b;
+    SwinBlockW blk[12];
+    const float *merge_w[4], *merge_b[4];
+    const float *img_w, *img_b, *t_w[3], *t_b[3];
+    const float *tail_g, *tail_b, *tail_p, *neck_s, *neck_t, *cls_w;
+};
+
+static std::map<reid_ctx*, SwinWeights>& swin_registry() {
+    static std::map<reid_ctx*, SwinWeights> r;
+    return r;
+}
+
+void swin_release(reid_ctx* ctx) {
+    auto& r = swin_registry();
+    auto it = r.find(ctx);
+    if (it != r.end()) {
+        if (it->second.blob) (void)hipFree(it->second.blob);
+        r.erase(it);
+    }
+}
+
+extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats, const char* manifest) {
+    ARG_CHECK(ctx && blob && manifest && n_floats > 0);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::map<std::string, std::pair<size_t, size_t>> tab;
+    {
+        std::istringstream in(manifest);
+        std::string name;
+        size_t off, cnt;
+        while (in >> name >> off >> cnt) {
+            if (off + cnt > n_floats || off % 4 != 0) {
+                reid_set_error("swin manifest entry '%s' out of range or not 16-byte aligned", name.c_str());
+                return REID_ERR_ARG;
+            }
+            tab[name] = {off, cnt};
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    swin_release(ctx);
+    SwinWeights w;
+    HIP_TRY(hipMalloc((void**)&w.blob, n_floats * sizeof(float)));
+    HIP_TRY(hipMemcpy(w.blob, blob, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    bool missing = false;
+    std::string first;
+    auto get = [&](const std::string& name, size_t expect) -> const float* {
+        auto it = tab.find(name);
+        if (it == tab.end() || (expect && it->second.second != expect)) {
+            if (!missing) first = name;
+            missing = true;
+            return nullptr;
+        }
+        return w.blob + it->second.first;
+    };
+    w.c1_w = get("sfe.conv1.w", 144); w.c1_b = get("sfe.conv1.b", 12);
+    w.in_g = get("sfe.in_gamma", 6); w.in_b = get("sfe.in_beta", 6);
+    w.bn_s = get("sfe.bn_scale", 6); w.bn_t = get("sfe.bn_shift", 6);
+    w.c2_w = get("sfe.conv2.w", 48 * 48); w.c2_b = get("sfe.conv2.b", 48);
+    w.fc_w = get("sfe.fc.w", 96 * 48); w.fc_b = get("sfe.fc.b", 96);
+    int bi = 0;
+    for (int s = 0; s < 4; ++s) {
+        const size_t c = kDims[s];
+        const std::string st = "s" + std::to_string(s + 1);
+        if (s > 0) {
+            w.merge_w[s] = get(st + ".merge.w", c * 4 * kDims[s - 1]);
+            w.merge_b[s] = get(st + ".merge.b", c);
+        }
+        for (int j = 0; j < kLayers[s]; ++j, ++bi) {
+            const std::string b = st + ".b" + std::to_string(j);
+            SwinBlockW& k = w.blk[bi];
+            k.ln1_g = get(b + ".ln1.g", c); k.ln1_b = get(b + ".ln1.b", c);
+            k.qkv_w = get(b + ".qkv.w", 3 * c * c); k.pos = get(b + ".pos", 169);
+            k.out_w = get(b + ".out.w", c * c); k.out_b = get(b + ".out.b", c);
+            k.post_w = get(b + ".post.w", c * c); k.post_b = get(b + ".post.b", c);
+            k.ln2_g = get(b + ".ln2.g", c); k.ln2_b = get(b + ".ln2.b", c);
+            k.fc1_w = get(b + ".fc1.w", 4 * c * c); k.fc1_b = get(b + ".fc1.b", 4 * c);
+            k.fc2_w = get(b + ".fc2.w", 4 * c * c); k.fc2_b = get(b + ".fc2.b", c);
+        }
+    }
+    w.img_w = get("align.img.w", 768 * 64 * 96); w.img_b = get("align.img.b", 768);
+    for (int t = 0; t < 3; ++t) {   // ConvTranspose 768->384, 384->192, 192->96: four parity GEMMs each
+        const size_t ci = kDims[3 - t], co = kDims[2 - t];
+        w.t_w[t] = get("align.t" + std::to_string(t) + ".w", 4 * co * 4 * ci);
+        w.t_b[t] = get("align.t" + std::to_string(t) + ".b", co);
+    }
+    w.tail_g = get("tail.ln.g", 96); w.tail_b = get("tail.ln.b", 96); w.tail_p = get("tail.p", 1);
+    w.neck_s = get("tail.bn_scale", 96); w.neck_t = get("tail.bn_shift", 96);
+    auto cls = tab.find("cls.w");
+    if (cls != tab.end() && cls->second.second % 96 == 0) {
+        w.cls_w = w.blob + cls->second.first;
+        w.num_class = (int)(cls->second.second / 96);
+    } else {
+        w.cls_w = nullptr;
+    }
+    if (missing) {
+        reid_set_error("reid_swin_load: manifest entry '%s' missing or of unexpected size", first.c_str());
+        (void)hipFree(w.blob);
+        return REID_ERR_ARG;
+    }
+    w.loaded = true;
+    swin_registry()[ctx] = w;
+    return REID_OK;
+}
+
+extern "C" int reid_swin_dims(reid_ctx* ctx, int* embed_dim, int* num_class) {
+    ARG_CHECK(ctx);
+    auto it = swin_registry().find(ctx);
+    if (it == swin_registry().end()) {
+        reid_set_error("no Swin weights loaded");
+        return REID_ERR_STATE;
+    }
+    if (embed_dim) *embed_dim = 96;
+    if (num_class) *num_class = it->second.num_class;
+    return REID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// x: fp32 NCHW [n][3][h][w] on the device; h, w multiples of 224
+static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int n, int h, int wd, float* d_emb, float* d_logits) {
+    const int H1 = h / 4, W1 = wd / 4;
+    const long long T1 = (long long)n * H1 * W1;   // tokens of stage 1
+    float *c1, *ab, *sfe, *xs[4], *lnb, *big, *att, *tmp, *f3, *f2, *f1, *gem;
+    REID_TRY(ctx_ws(ctx, "swin.c1", (size_t)n * (h / 2) * (wd / 2) * 12 * 4, (void**)&c1));
+    REID_TRY(ctx_ws(ctx, "swin.ab", (size_t)n * 24 * 4, (void**)&ab));
+    REID_TRY(ctx_ws(ctx, "swin.sfe", (size_t)T1 * 96 * 4, (void**)&sfe));
+    for (int s = 0; s < 4; ++s) {
+        char nm[32];
+        snprintf(nm, sizeof(nm), "swin.x%d", s);
+        REID_TRY(ctx_ws(ctx, nm, (size_t)T1 * 96 * 4 >> s, (void**)&xs[s]));   // tokens/4, channels*2 per stage
+    }
+    REID_TRY(ctx_ws(ctx, "swin.ln", (size_t)T1 * 96 * 4, (void**)&lnb));
+    REID_TRY(ctx_ws(ctx, "swin.big", (size_t)T1 * 384 * 4, (void**)&big));    // qkv (3C) and MLP hidden (4C)
+    REID_TRY(ctx_ws(ctx, "swin.att", (size_t)T1 * 96 * 4, (void**)&att));
+    REID_TRY(ctx_ws(ctx, "swin.tmp", (size_t)T1 * 96 * 4, (void**)&tmp));
+    REID_TRY(ctx_ws(ctx, "swin.f3", (size_t)T1 * 96 * 4 >> 2, (void**)&f3));   // [n,14,14,384]
+    REID_TRY(ctx_ws(ctx, "swin.f2", (size_t)T1 * 96 * 4 >> 1, (void**)&f2));   // [n,28,28,192]
+    REID_TRY(ctx_ws(ctx, "swin.f1", (size_t)T1 * 96 * 4, (void**)&f1));        // [n,56,56,96]
+    REID_TRY(ctx_ws(ctx, "swin.gem", (size_t)n * 96 * 4, (void**)&gem));
+
+    // stem
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, 0);
+    hipLaunchKernelGGL(sfe_conv1_kernel, dim3(grid_for((long long)n * (h / 2) * (wd / 2), 256)), dim3(256), 0, ctx->stream, x, n, h,
+                       wd, w.c1_w, w.c1_b, c1);
+    hipLaunchKernelGGL(sfe_norm_kernel, dim3(n), dim3(256), 0, ctx->stream, c1, (h / 2) * (wd / 2), w.in_g, w.in_b, w.bn_s, w.bn_t, ab);
+    hipLaunchKernelGGL(sfe_conv2_fc_kernel, dim3(grid_for(T1, 256)), dim3(256), 0, ctx->stream, c1, ab, n, h / 2, wd / 2, w.c2_w,
+                       w.c2_b, w.fc_w, w.fc_b, sfe);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+
+    int bi = 0, Hs = H1, Ws = W1;
+    const float* prev = sfe;
+    for (int s = 0; s < 4; ++s) {
+        const int C = kDims[s], heads = kHeads[s];
+        float* xcur = xs[s];
+        if (s == 0) {
+            HIP_TRY(hipMemcpyAsync(xcur, sfe, (size_t)T1 * 96 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            // PatchMerging = conv2x2 s2 with weights repacked to (kh, kw, c) order + bias (swin_transformer.py:263-275)
+            REID_TRY(conv_bias(ctx, prev, n, Hs, Ws, kDims[s - 1], w.merge_w[s], w.merge_b[s], C, 2, 2, 2, 0, 0, Hs / 2, Ws / 2, nullptr, xcur));
+            Hs /= 2;
+            Ws /= 2;
+        }
+        const long long T = (long long)n * Hs * Ws;
+        for (int j = 0; j < kLayers[s]; ++j, ++bi) {
+            const SwinBlockW& k = w.blk[bi];
+            const int shifted = j & 1;
+            // x = x + post_proj(to_out(attn(LN(x))))
+            prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
+            hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f, k.ln1_g, k.ln1_b, lnb);
+            prof_end(ctx);
+            REID_TRY(linear(ctx, lnb, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big));
+            prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 16);
+            const long long ntask = (long long)n * (Hs / 7) * (Ws / 7) * heads;
+            hipLaunchKernelGGL(window_attn_kernel, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, n, Hs, Ws, heads,
+                               shifted, k.pos, att);
+            prof_end(ctx);
+            LAUNCH_CHECK();
+            REID_TRY(linear(ctx, att, T, C, k.out_w, k.out_b, C, 0, nullptr, tmp));
+            REID_TRY(linear(ctx, tmp, T, C, k.post_w, k.post_b, C, 0, xcur, xcur));
+            // x = x + fc2(gelu(fc1(LN(x))))
+            prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
+            hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f, k.ln2_g, k.ln2_b, lnb);
+            prof_end(ctx);
+            REID_TRY(linear(ctx, lnb, T, C, k.fc1_w, k.fc1_b, 4 * C, 1, nullptr, big));
+            REID_TRY(linear(ctx, big, T, 4 * C, k.fc2_w, k.fc2_b, C, 0, xcur, xcur));
+        }
+        prev = xcur;
+    }
+    // top-down fusion (:405-412): f = stage4 + Conv8x8s8(sfe); then three ConvTranspose2d(4, 2, 1) + stage outputs
+    const int H4 = H1 / 8, W4 = W1 / 8;
+    REID_TRY(conv_bias(ctx, sfe, n, H1, W1, 96, w.img_w, w.img_b, 768, 8, 8, 8, 0, 0, H4, W4, xs[3], tmp));
+    const float* fin = tmp;
+    float* fouts[3] = {f3, f2, f1};
+    int Hi = H4, Wi = W4;
+    for (int t = 0; t < 3; ++t) {
+        const int ci = kDims[3 - t], co = kDims[2 - t];
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                REID_TRY(conv_bias(ctx, fin, n, Hi, Wi, ci, w.t_w[t] + (size_t)(py * 2 + px) * co * 4 * ci, w.t_b[t], co, 2, 2, 1, 1 - py,
+                                   1 - px, Hi, Wi, xs[2 - t], fouts[t], Hi, Wi, py, px));
+        fin = fouts[t];
+        Hi *= 2;
+        Wi *= 2;
+    }
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T1 * 96 * 4);
+    hipLaunchKernelGGL(swin_tail_kernel, dim3(n), dim3(256), 0, ctx->stream, fin, H1 * W1, w.tail_g, w.tail_b, w.tail_p, w.neck_s,
+                       w.neck_t, gem, d_emb);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    if (d_logits) {
+        if (!w.cls_w) {
+            reid_set_error("logits requested but the Swin blob has no classifier");
+            return REID_ERR_STATE;
+        }
+        REID_TRY(linear(ctx, d_emb, n, 96, w.cls_w, nullptr, w.num_class, 0, nullptr, d_logits));
+    }
+    return REID_OK;
+}
+
+extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int h, int w, float* d_emb, float* d_logits) {
+    ARG_CHECK(ctx && d_x && d_emb && n >= 0 && h > 0 && w > 0 && h % 224 == 0 && w % 224 == 0);
+    auto it = swin_registry().find(ctx);
+    if (it == swin_registry().end() || !it->second.loaded) {
+        reid_set_error("reid_swin_embed_*: call reid_swin_load first");
+        return REID_ERR_STATE;
+    }
+    const SwinWeights& sw = it->second;
+    const int chunk = ctx->chunk < 64 ? ctx->chunk : 64;
+    const size_t img = (size_t)3 * h * w;
+    for (int i = 0; i < n; i += chunk) {
+        const int m = n - i < chunk ? n - i : chunk;
+        REID_TRY(swin_forward(ctx, sw, d_x + (size_t)i * img, m, h, w, d_emb + (size_t)i * 96,
+                              d_logits ? d_logits + (size_t)i * sw.num_class : nullptr));
+    }
+    return REID_OK;
+}
+
+extern "C" int reid_swin_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, int h, int w, float* emb, float* logits) {
+    ARG_CHECK(ctx && x && emb && n >= 0);
+    if (n == 0) return REID_OK;
+    auto it = swin_registry().find(ctx);
+    if (it == swin_registry().end()) {
+        reid_set_error("reid_swin_embed_*: call reid_swin_load first");
+        return REID_ERR_STATE;
+    }
+    const int nc = it->second.num_class;
+    const size_t img = (size_t)3 * h * w;
+    float *d_in, *d_emb, *d_log = nullptr;
+    REID_TRY(ctx_ws(ctx, "io.in", (size_t)n * img * 4, (void**)&d_in));
+    REID_TRY(ctx_ws(ctx, "io.emb", (size_t)n * 512 * 4, (void**)&d_emb));
+    if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
+    HIP_TRY(hipMemcpyAsync(d_in, x, (size_t)n * img * 4, hipMemcpyHostToDevice, ctx->stream));
+    REID_TRY(reid_swin_embed_f32_nchw_dev(ctx, d_in, n, h, w, d_emb, d_log));
+    HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 96 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}

@@ -101,6 +101,24 @@ class Engine:
         check(self.lib.reid_seres18_dims(self.h, C.byref(d), C.byref(nc)))
         self.embed_dim, self.num_class = d.value, nc.value
 
+    def load_swin(self, blob, manifest):
+        blob = _f32(blob)
+        check(self.lib.reid_swin_load(self.h, _ptr(blob), blob.size, manifest.encode()))
+        d, nc = C.c_int(), C.c_int()
+        check(self.lib.reid_swin_dims(self.h, C.byref(d), C.byref(nc)))
+        self.swin_dim, self.swin_num_class = d.value, nc.value
+
+    def swin_embed_f32_nchw(self, x, logits=False):
+        """float32[n,3,h,w] (h, w multiples of 224) -> float32[n,96] (and logits)."""
+        x = _f32(x)
+        if x.ndim != 4 or x.shape[1] != 3 or x.shape[2] % 224 or x.shape[3] % 224:
+            raise ValueError("swin_embed_f32_nchw expects float32[n,3,224k,224m], got %s" % (x.shape,))
+        n = x.shape[0]
+        emb = np.empty((n, self.swin_dim), np.float32)
+        lg = np.empty((n, self.swin_num_class), np.float32) if logits else None
+        check(self.lib.reid_swin_embed_f32_nchw(self.h, _ptr(x), n, x.shape[2], x.shape[3], _ptr(emb), _ptr(lg)))
+        return (emb, lg) if logits else emb
+
     # ---- embedding
     def _outs(self, n, want_logits):
         emb = np.empty((n, self.embed_dim), np.float32)

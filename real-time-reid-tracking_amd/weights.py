@@ -138,3 +138,87 @@ def pack_seres18(state_dict):
         pk.add("cls.w", w)
     blob, manifest = pk.finish()
     return blob, manifest, {"arch": "seres18_ibn", "embed_dim": 512, "num_class": num_class}
+
+
+# ------------------------------------------------------------------------------------------------ Swin-T (v1)
+def _convt_parity(w):
+    """ConvTranspose2d(4, 2, 1) weight [Cin][Cout][4][4] -> [py][px][Cout][r][s][Cin]: the four output-parity 2x2
+    convolutions.  Output row 2j+py takes input rows j-1+r (py=0: kernel rows 3,1) or j+r (py=1: kernel rows 2,0)."""
+    w = np.asarray(w, np.float32)
+    ci, co = w.shape[:2]
+    taps = ((3, 1), (2, 0))
+    out = np.empty((2, 2, co, 2, 2, ci), np.float32)
+    for py in range(2):
+        for px in range(2):
+            for r in range(2):
+                for s in range(2):
+                    out[py, px, :, r, s, :] = w[:, :, taps[py][r], taps[px][s]].T
+    return out
+
+
+def pack_swin(state_dict):
+    """state_dict of swin_t(version='v1') (reid/backbones/swin_transformer.py) -> (blob, manifest, info) for reid_swin_load.
+    Dropped: stage1.patch_partition (never applied, patch_merge=False :357-359), the constant shift masks (recomputed in
+    the attention kernel), num_batches_tracked."""
+    sd = normalize_state_dict(state_dict)
+    if "sfe.conv1.weight" not in sd or "stage4.layers.0.1.attention_block.fn.fn.to_qkv.weight" not in sd:
+        raise KeyError("state_dict is not a swin_t (v1) checkpoint")
+    f = lambda k: np.asarray(sd[k], np.float32)
+    pk = Packer()
+    pk.add("sfe.conv1.w", f("sfe.conv1.weight").transpose(0, 2, 3, 1))       # [12][(kh,kw,c)]
+    pk.add("sfe.conv1.b", f("sfe.conv1.bias"))
+    pk.add("sfe.in_gamma", f("sfe.norm.instancenorm.weight"))
+    pk.add("sfe.in_beta", f("sfe.norm.instancenorm.bias"))
+    s, b = fold_bn(sd, "sfe.norm.batchnorm")
+    pk.add("sfe.bn_scale", s)
+    pk.add("sfe.bn_shift", b)
+    pk.add("sfe.conv2.w", f("sfe.conv2.weight").transpose(0, 2, 3, 1))       # [48][(kh,kw,c)]
+    pk.add("sfe.conv2.b", f("sfe.conv2.bias"))
+    pk.add("sfe.fc.w", f("sfe.fc.weight"))
+    pk.add("sfe.fc.b", f("sfe.fc.bias"))
+    cin = 96
+    for si, (c, nl) in enumerate(zip(synth.SWIN_DIMS, synth.SWIN_LAYERS)):
+        st, out = "stage%d" % (si + 1), "s%d" % (si + 1)
+        if si > 0:
+            w = f(st + ".patch_partition.linear.weight")                     # [C][(c_in, kh, kw)] (nn.Unfold order)
+            pk.add(out + ".merge.w", w.reshape(c, cin, 2, 2).transpose(0, 2, 3, 1))   # -> [C][(kh, kw, c_in)]
+            pk.add(out + ".merge.b", f(st + ".patch_partition.linear.bias"))
+        j = 0
+        for li in range(nl // 2):
+            for bi in range(2):
+                pre = "%s.layers.%d.%d" % (st, li, bi)
+                a, m, o = pre + ".attention_block.fn", pre + ".mlp_block.fn", "%s.b%d" % (out, j)
+                pk.add(o + ".ln1.g", f(a + ".norm.weight"))
+                pk.add(o + ".ln1.b", f(a + ".norm.bias"))
+                pk.add(o + ".qkv.w", f(a + ".fn.to_qkv.weight"))
+                pk.add(o + ".pos", f(a + ".fn.pos_embedding").reshape(169))
+                pk.add(o + ".out.w", f(a + ".fn.to_out.weight"))
+                pk.add(o + ".out.b", f(a + ".fn.to_out.bias"))
+                pk.add(o + ".post.w", f(a + ".fn.post_proj.weight"))
+                pk.add(o + ".post.b", f(a + ".fn.post_proj.bias"))
+                pk.add(o + ".ln2.g", f(m + ".norm.weight"))
+                pk.add(o + ".ln2.b", f(m + ".norm.bias"))
+                pk.add(o + ".fc1.w", f(m + ".fn.net.0.weight"))
+                pk.add(o + ".fc1.b", f(m + ".fn.net.0.bias"))
+                pk.add(o + ".fc2.w", f(m + ".fn.net.3.weight"))
+                pk.add(o + ".fc2.b", f(m + ".fn.net.3.bias"))
+                j += 1
+        cin = c
+    pk.add("align.img.w", f("img_channel_align.weight").transpose(0, 2, 3, 1))   # [768][8][8][96]
+    pk.add("align.img.b", f("img_channel_align.bias"))
+    for t, name in enumerate(("stage4_channel_align", "stage3_channel_align", "stage2_channel_align")):
+        pk.add("align.t%d.w" % t, _convt_parity(sd[name + ".weight"]))
+        pk.add("align.t%d.b" % t, f(name + ".bias"))
+    pk.add("tail.ln.g", f("norm.weight"))
+    pk.add("tail.ln.b", f("norm.bias"))
+    pk.add("tail.p", np.asarray(sd.get("avgpool.p", [3.0]), np.float32).reshape(1))
+    s, b = fold_bn(sd, "bottleneck")
+    pk.add("tail.bn_scale", s)
+    pk.add("tail.bn_shift", b)
+    num_class = 0
+    if "mlp_head.0.weight" in sd:
+        w = f("mlp_head.0.weight")
+        num_class = w.shape[0]
+        pk.add("cls.w", w)
+    blob, manifest = pk.finish()
+    return blob, manifest, {"arch": "swin_transformer", "embed_dim": 96, "num_class": num_class}

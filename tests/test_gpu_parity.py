@@ -259,3 +259,39 @@ def test_f16_path_rank_parity(eng_w0):
     decided = (srt[:, 1] - srt[:, 0]) > 2e-3           # fp16 storage: ranks are asserted where the gap exceeds its noise
     assert decided.sum() >= 32
     assert (d_gpu.argmin(1)[decided] == d_ref.argmin(1)[decided]).all()
+
+
+# ----------------------------------------------------------------------------- Swin-T (v1)
+def test_swin_embed_matches_reference_fixture(eng, golden_dir):
+    """224x224, N=2 (Q14), eval mode.  Tolerance: 1e-3 cosine (north_star); fp32 path held to 1e-5."""
+    from oracle import swin
+    g = np.load(os.path.join(golden_dir, "swin_seed0.npz"))
+    seed, n = int(g["seed"]), int(g["n"])
+    sd = synth.swin_state_dict(seed)
+    blob, manifest, info = weights.pack_swin(sd)
+    eng.load_swin(blob, manifest)
+    x = synth.images_f32(n, seed)
+    emb, logits = eng.swin_embed_f32_nchw(x, logits=True)
+    ref_emb, ref_logits = swin.forward(sd, torch.from_numpy(x))
+    for mine, ref in ((emb, g["emb"]), (emb, ref_emb.numpy()), (logits, g["logits"])):
+        assert np.abs(mine - ref).max() / np.abs(ref).max() < 2e-4
+    cos = (emb * g["emb"]).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(g["emb"], axis=1)
+    assert (1 - cos).max() < 1e-5
+    # N = 1 works here although the reference breaks on it (SURVEY Q14); 448x224 is accepted as in the reference
+    emb1 = eng.swin_embed_f32_nchw(x[:1])
+    np.testing.assert_allclose(emb1, emb[:1], rtol=1e-4, atol=1e-4 * np.abs(emb).max())
+    x2 = synth.images_f32(1, 3, h=448, w=224)
+    e2 = eng.swin_embed_f32_nchw(x2)
+    r2, _ = swin.forward(sd, torch.from_numpy(x2))
+    assert np.abs(e2 - r2.numpy()).max() / np.abs(r2.numpy()).max() < 2e-4
+
+
+def test_swin_backbone_object(eng):
+    from reid_amd import models
+    from oracle import swin
+    m = models.build_model("swin_transformer", num_classes=751, loss="triplet", pretrained=False).eval()
+    x = torch.from_numpy(synth.images_f32(3, 7))
+    out = m(x)
+    assert isinstance(out, torch.Tensor) and tuple(out.shape) == (3, 96)
+    ref, _ = swin.forward(synth.swin_state_dict(0), x)
+    assert np.abs(out.numpy() - ref.numpy()).max() / np.abs(ref.numpy()).max() < 2e-4

@@ -127,3 +127,49 @@ def test_build_model_registry():
         m.to("cpu")
     with pytest.raises(NotImplementedError):
         models.build_model("seres18_ibn", 751, loss="arcface")
+
+
+def test_pack_swin_layout():
+    sd = synth.swin_state_dict(0)
+    blob, manifest, info = weights.pack_swin(sd)
+    assert info == {"arch": "swin_transformer", "embed_dim": 96, "num_class": 751}
+    tab = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in manifest.strip().split("\n")}
+    assert all(off % 4 == 0 for off, _ in tab.values())
+    assert "s1.merge.w" not in tab and not any("mask" in k for k in tab)      # unused tensors dropped
+    assert len([k for k in tab if k.endswith(".qkv.w")]) == 12
+    # patch merging: nn.Unfold feature order (c, kh, kw) -> (kh, kw, c)
+    off, cnt = tab["s2.merge.w"]
+    w = blob[off:off + cnt].reshape(192, 2, 2, 96)
+    src = sd["stage2.patch_partition.linear.weight"]
+    assert w[5, 1, 0, 17] == src[5, 17 * 4 + 1 * 2 + 0]
+    # ConvTranspose2d(4,2,1) parity blocks: output row 2j+0 <- input rows j-1 (kernel row 3), j (kernel row 1)
+    off, cnt = tab["align.t0.w"]
+    w = blob[off:off + cnt].reshape(2, 2, 384, 2, 2, 768)
+    src = sd["stage4_channel_align.weight"]
+    assert w[0, 1, 7, 0, 1, 33] == src[33, 7, 3, 0] and w[1, 0, 7, 1, 0, 33] == src[33, 7, 0, 3]
+    # the parity decomposition reproduces torch's conv_transpose2d on a small case
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    wt = rng.normal(size=(5, 3, 4, 4)).astype(np.float32)
+    x = rng.normal(size=(1, 5, 4, 6)).astype(np.float32)
+    ref = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(wt), None, 2, 1).numpy()
+    par = weights._convt_parity(wt)
+    out = np.zeros_like(ref)
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    for py in range(2):
+        for px in range(2):
+            for j in range(4):
+                for i in range(6):
+                    acc = np.zeros(3, np.float32)
+                    for r in range(2):
+                        for s in range(2):
+                            acc += par[py, px, :, r, s, :] @ xp[0, :, j + py + r, i + px + s]
+                    out[0, :, 2 * j + py, 2 * i + px] = acc
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_build_model_swin_registry():
+    from reid_amd import models
+    m = models.build_model("swin_transformer", num_classes=751, loss="triplet", pretrained=False, use_gpu=True)
+    assert m.embed_dim == 96 and len(m.state_dict()) == len(synth.swin_state_dict(0))
