@@ -119,6 +119,10 @@ class Engine:
         check(self.lib.reid_swin_embed_f32_nchw(self.h, _ptr(x), n, x.shape[2], x.shape[3], _ptr(emb), _ptr(lg)))
         return (emb, lg) if logits else emb
 
+    def swin_embed_dev(self, d_x, n, h, w, d_emb, d_logits=None):
+        check(self.lib.reid_swin_embed_f32_nchw_dev(self.h, C.c_void_p(d_x), int(n), int(h), int(w), C.c_void_p(d_emb),
+                                                    C.c_void_p(d_logits or 0)))
+
     # ---- embedding
     def _outs(self, n, want_logits):
         emb = np.empty((n, self.embed_dim), np.float32)
