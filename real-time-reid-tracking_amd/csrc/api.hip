@@ -37,6 +37,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     reid_ctx* c = new reid_ctx();
     c->device = device;
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
+    if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipEventCreate(&c->t0));
@@ -474,6 +475,14 @@ static int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H
     const double flops = 2.0 * p.M * Cout * ktrue;
     const double bytes = ((double)n * H * W * (amode == A16_STEM ? 4 : Cin) + (double)p.M * Cout + (double)Cout * ktrue +
                           (residual ? (double)p.M * Cout : 0.0)) * 2.0;
+    // 3x3 stride-1 convs: the LDS-halo kernel where it measured faster (tools/bench_conv_f16.py, 256 crops): 32x16 maps
+    // 621 vs 561 TF, 16x8 x256ch 776 vs 681 TF; the implicit GEMM keeps Cout = 64 (451 vs 373 TF) and Cout = 512 when its
+    // 256x256 tiles still fill the chip (963 vs 943 TF)
+    if (amode == A16_IM2COL && ctx->f16_halo && conv3x3_f16_supported(p)) {
+        const long long blocks256 = (long long)((p.M + 255) / 256) * (Cout / 256);
+        const bool gemm_better = Cout == 64 || (Cout % 256 == 0 && Cout >= 512 && blocks256 >= 192);
+        if (ctx->f16_halo == 2 || !gemm_better) return launch_conv3x3_f16(ctx, p, REID_K_CONV_GEMM, flops, bytes);
+    }
     return launch_gemm_f16(ctx, amode, p, REID_K_CONV_GEMM, flops, bytes);
 }
 
@@ -968,7 +977,9 @@ extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, 
     for (size_t o = 0; o < nin; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nin - o < src_n ? nin - o : src_n, x + o));
     for (size_t o = 0; o < nw; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nw - o < src_n ? nw - o : src_n, wt + o));
     const int c0 = ctx->f16_cfg;
-    ctx->f16_cfg = cfg;
+    const int h0 = ctx->f16_halo;
+    ctx->f16_halo = cfg >= 2000000 ? 2 : 0;   // 2xxxxxx: force the LDS-halo kernel
+    ctx->f16_cfg = cfg % 2000000;
     int st = REID_OK;
     for (int i = 0; i < 2 && st == REID_OK; ++i)
         st = conv_gemm16(ctx, A16_IM2COL, x, n, h, w, cin, wt, cout, r, r, stride, pad, r * r * cin, nullptr, nullptr, nullptr, 0, nullptr, out);
@@ -978,6 +989,49 @@ extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, 
     float ms = 0.f;
     if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
     ctx->f16_cfg = c0;
+    ctx->f16_halo = h0;
     *ms_per_launch = ms / (iters > 0 ? iters : 1);
+    return st;
+}
+
+
+// Times one dense fp16 GEMM C[m][n] = A[m][k] . B[n][k]^T (experiments: separates the im2col gather from the tile loop).
+extern "C" int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, int iters, float* ms_per_launch,
+                                   unsigned long long* diag_host /* [64*8*4] or NULL */) {
+    ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded);
+    unsigned long long* d_diag = nullptr;
+    if (diag_host) {
+        REID_TRY(ctx_ws(ctx, "dbg.diag", 64 * 8 * 4 * 8, (void**)&d_diag));
+        HIP_TRY(hipMemsetAsync(d_diag, 0, 64 * 8 * 4 * 8, ctx->stream));
+    }
+    typedef _Float16 f16;
+    f16 *a, *b, *c;
+    REID_TRY(ctx_ws(ctx, "dbg.x", (size_t)m * k * 2, (void**)&a));
+    REID_TRY(ctx_ws(ctx, "dbg.w", (size_t)n * k * 2, (void**)&b));
+    REID_TRY(ctx_ws(ctx, "dbg.out", (size_t)m * n * 2, (void**)&c));
+    const size_t src_n = ctx->se18.n_floats;
+    for (size_t o = 0; o < (size_t)m * k; o += src_n)
+        REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, (size_t)m * k - o < src_n ? (size_t)m * k - o : src_n, a + o));
+    for (size_t o = 0; o < (size_t)n * k; o += src_n)
+        REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, (size_t)n * k - o < src_n ? (size_t)n * k - o : src_n, b + o));
+    Gemm16Params p;
+    memset(&p, 0, sizeof(p));
+    p.A = a; p.lda = k; p.B = b; p.ldb = k; p.M = m; p.N = n; p.K = k; p.C = c; p.ldc = n;
+    p.zero_page = ctx->se18.zero_page;
+    p.diag = d_diag;
+    const int c0 = ctx->f16_cfg;
+    ctx->f16_cfg = cfg;
+    int st = REID_OK;
+    for (int i = 0; i < 2 && st == REID_OK; ++i) st = launch_gemm_f16(ctx, A16_DENSE, p, REID_K_CONV_GEMM, 0, 0);
+    if (st == REID_OK) st = reid_timer_start(ctx);
+    for (int i = 0; i < iters && st == REID_OK; ++i) st = launch_gemm_f16(ctx, A16_DENSE, p, REID_K_CONV_GEMM, 0, 0);
+    float ms = 0.f;
+    if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
+    ctx->f16_cfg = c0;
+    *ms_per_launch = ms / (iters > 0 ? iters : 1);
+    if (st == REID_OK && diag_host) {
+        HIP_TRY(hipMemcpyAsync(diag_host, d_diag, 64 * 8 * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     return st;
 }

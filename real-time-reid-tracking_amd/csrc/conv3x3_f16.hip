@@ -1,0 +1,297 @@
+// 3x3 / stride-1 / pad-1 convolution, fp16 storage, fp32 accumulate, with the input HALO TILE kept in LDS.
+//
+// Why: the implicit-GEMM kernel (gemm_f16.hip) re-gathers the A operand from global memory for each of the nine taps.
+// Measured (tools/bench_feed.py, tools/diag_gemm_f16.py): a CU's L1/TA path delivers ~30 B/clk (67 GB/s from L2, 28 GB/s
+// from beyond), so a 256x256x64 tile needs ~2100 cycles of operand feed for 2048 cycles of MFMA, a 256x64 tile (Cout = 64)
+// is feed-capped at ~40 % of the MFMA peak, and the DMA issue alone costs ~900 cycles per wave per K-tile.
+// Here a block owns 256 output pixels (full-width rows of one image, or two whole 16x8 images), loads the (rows+2) x (W+2)
+// halo of its input ONCE per 64-channel chunk and reads the A fragments of all nine taps from it: the A traffic drops ~6x and
+// the per-tile feed falls to 13-21 KB (from 40-64 KB), below what the MFMAs of the tile cost.
+//
+// LDS: two halo buffers (chunk c and c+1) + a 3-slot ring of weight tiles [BN][64] (one tap of one chunk each).
+// Both images are lane-linear DMA targets with the source-side XOR swizzle of gemm_f16.hip (128-B rows: chunk c of pixel p at
+// position c ^ ((p >> 1) & 7)).  The MFMA row -> pixel map is chosen per geometry so that the 16 lanes of every
+// ds_read_b128 group address 16 pixels with distinct (halo index mod 16) at EVERY tap (a tap only shifts the index):
+//   W = 32: a 32-row MFMA tile = one image row;  W = 16: one lane group = one image row;
+//   W = 8 : one lane group = rows y and y+4 (halo pitch 10: 40 = 8 mod 16).
+#include "reid_internal.h"
+
+typedef _Float16 f16;
+typedef f16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(uintptr_t)(p))
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+// ds_read_b128 lane groups within a 32-lane half: {0-3,12-15,20-27} and {4-11,16-19,28-31}
+__device__ __forceinline__ int lane_group(int i) { return ((i >= 4 && i < 12) || (i >= 16 && i < 20) || i >= 28) ? 1 : 0; }
+__device__ __forceinline__ int lane_rank(int i) {
+    // position of lane i inside its group (0..15)
+    if (i < 4) return i;            // g0: 0-3   -> 0-3
+    if (i < 12) return i - 4;       // g1: 4-11  -> 0-7
+    if (i < 16) return i - 8;       // g0: 12-15 -> 4-7
+    if (i < 20) return i - 8;       // g1: 16-19 -> 8-11
+    if (i < 28) return i - 12;      // g0: 20-27 -> 8-15
+    return i - 16;                  // g1: 28-31 -> 12-15
+}
+
+// MFMA row (wave-row wm 0..3, 32-row tile a 0..1, row i 0..31) -> (image in block, y in tile, x)
+template <int TW, int IMGS>
+__device__ __forceinline__ void row_to_pixel(int wm, int a, int i, int& img, int& y, int& x) {
+    if constexpr (TW == 32) {          // block = 8 rows x 32: wave = 2 rows, tile = 1 row
+        img = 0; y = wm * 2 + a; x = i;
+    } else if constexpr (TW == 16) {   // block = 16 rows x 16: wave = 4 rows, tile = 2 rows, group = row
+        img = 0; y = wm * 4 + a * 2 + lane_group(i); x = lane_rank(i);
+    } else {                           // TW == 8, two 16x8 images: wave = 8 rows of one image, group = rows (y, y+4)
+        const int k = lane_rank(i);
+        img = wm >> 1; y = (wm & 1) * 8 + a * 2 + lane_group(i) + 4 * (k >> 3); x = k & 7;
+    }
+}
+
+template <int TW, int IMGS, int BN>
+__global__ __launch_bounds__(512, 2) void conv3x3_f16_kernel(const Gemm16Params p) {
+    constexpr int TH = 256 / (IMGS * TW);            // tile rows per image
+    constexpr int WP = TW + 2, HP = TH + 2;          // halo pitch / rows
+    constexpr int NPX = IMGS * HP * WP;              // halo pixels per block
+    constexpr int NPI = (NPX + 7) / 8;               // halo DMA instructions (8 pixels x 128 B each)
+    constexpr int HPW = (NPI + 7) / 8;               // halo instructions per wave (<= 6)
+    constexpr int HALO_BYTES = NPI * 1024;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int BJ = BN / 64;                      // B DMA instructions per wave per tile (BN/8 instructions, 8 waves)
+    constexpr int TN = BN / 64;                      // wave tile 64 x BN/2 -> TN 32-col MFMA tiles
+    constexpr int TM = 2;
+    static_assert(2 * HALO_BYTES + 3 * B_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(HPW <= 6, "halo pieces are issued one per tap");
+    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + 3 * B_BYTES];
+    char* halo = lds;
+    char* ring = lds + 2 * HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nnt = p.N / BN;
+    const int nwg = gridDim.x;
+    int mtile, ntile;
+    {   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD)
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        mtile = L / nnt;
+        ntile = L - mtile * nnt;
+    }
+    const int n_blk = ntile * BN;
+    // block -> (first image, first row): M rows [256*mtile, +256) in natural (image, y, x) order
+    const int tiles_per_img = p.H / TH;              // IMGS == 2 -> 1
+    const int img0 = IMGS == 2 ? mtile * 2 : mtile / tiles_per_img;
+    const int y0 = IMGS == 2 ? 0 : (mtile - img0 * tiles_per_img) * TH;
+    const int n_img = p.M / (p.H * p.W);
+
+    // ---- A fragment addressing: halo pixel index of this lane's row in tile a at tap (0,0)
+    int hp0[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        int im, y, x;
+        row_to_pixel<TW, IMGS>(wm, a, li, im, y, x);
+        hp0[a] = im * HP * WP + y * WP + x;          // tap (r,s) adds r*WP + s  (halo origin = pixel (-1,-1))
+    }
+    // ---- B descriptors: wave-instruction j fills ring rows (wave*BJ + j)*8 .. +8
+    int b_chunk[BJ];
+    long long b_base[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (wave * BJ + j) * 8 + (lane >> 3);
+        b_chunk[j] = (lane & 7) ^ ((row >> 1) & 7);
+        b_base[j] = (long long)(n_blk + row) * p.ldb;
+    }
+    // ---- halo descriptors: piece q = wave + 8*tap covers halo pixels q*8 .. +8 (lane/8), chunk position lane%8
+    auto issue_halo_piece = [&](int q, int chunk, int buf) {
+        const int hp = q * 8 + (lane >> 3);
+        const int im = hp / (HP * WP), rem = hp - im * (HP * WP);
+        const int hy = rem / WP, hx = rem - hy * WP;
+        const int gy = y0 - 1 + hy, gx = hx - 1, gi = img0 + im;
+        const bool ok = hp < NPX && gi < n_img && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const int c = (lane & 7) ^ ((hp >> 1) & 7);
+        const f16* src = ok ? p.A + (((long long)gi * p.H + gy) * p.W + gx) * p.Cin + chunk * 64 + c * 8 : p.zero_page;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(halo + buf * HALO_BYTES + q * 1024), 16, 0, 0);
+    };
+    auto issue_b_piece = [&](int t, int slot, int j) {   // tile t = (chunk, tap): weights [Cout][(tap, channel)]
+        const int chunk = t / 9, tap = t - chunk * 9;
+        const int k0 = tap * p.Cin + chunk * 64;
+        __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0 + b_chunk[j] * 8),
+                                         LPTR(ring + slot * B_BYTES + (wave * BJ + j) * 1024), 16, 0, 0);
+    };
+    auto issue_b = [&](int t, int slot) {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) issue_b_piece(t, slot, j);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int nchunk = p.Cin / 64;
+    const int nt = nchunk * 9;
+    const int b_row_off = (wn * (BN / 2) + li) * 128;
+    const int b_swz = (li >> 1) & 7;
+
+    // prologue: halo of chunk 0, weight tiles 0 and 1
+#pragma unroll
+    for (int k = 0; k < HPW; ++k)
+        if (wave + 8 * k < NPI) issue_halo_piece(wave + 8 * k, 0, 0);
+    issue_b(0, 0);
+    if (nt > 1) issue_b(1, 1);
+    int prev_b = nt > 1 ? 1 : 0;      // did the previous "iteration" issue a weight tile / a halo piece (for the counted wait)
+    int prev_h = 0;
+
+    int slot_c = 0, slot_i = 2, chunk = 0, tap = 0;
+    for (int t = 0; t < nt; ++t) {
+        // everything except what was issued in the previous iteration has landed after this wait
+        if (prev_b && prev_h) WAIT_VMCNT(BJ + 1);
+        else if (prev_b) WAIT_VMCNT(BJ);
+        else if (prev_h) WAIT_VMCNT(1);
+        else WAIT_VMCNT(0);
+        RAW_BARRIER();
+        prev_b = 0;
+        prev_h = 0;
+        if (t + 2 < nt) { issue_b(t + 2, slot_i); prev_b = 1; }
+        if (tap < HPW && chunk + 1 < nchunk && wave + 8 * tap < NPI) { issue_halo_piece(wave + 8 * tap, chunk + 1, (chunk + 1) & 1); prev_h = 1; }
+
+        const char* As = halo + (chunk & 1) * HALO_BYTES;
+        const char* Bs = ring + slot_c * B_BYTES;
+        const int r = tap / 3, s = tap - r * 3;
+        int a_off[TM], a_swz[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int hp = hp0[a] + r * WP + s;
+            a_off[a] = hp * 128;
+            a_swz[a] = (hp >> 1) & 7;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            half8 af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = *(const half8*)(As + a_off[a] + (((kk * 2 + lh) ^ a_swz[a]) * 16));
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = *(const half8*)(Bs + b_row_off + b * 32 * 128 + (((kk * 2 + lh) ^ b_swz) * 16));
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        slot_c = slot_c == 2 ? 0 : slot_c + 1;
+        slot_i = slot_i == 2 ? 0 : slot_i + 1;
+        if (++tap == 9) { tap = 0; ++chunk; }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ epilogue (fp32 math, f16 stores)
+    const int ldc = (int)p.ldc;
+    const int m_blk = mtile * 256;
+    f16* Cb = p.C + (long long)m_blk * ldc + n_blk;
+    const f16* Rb = p.residual ? p.residual + (long long)m_blk * ldc + n_blk : nullptr;
+    const int m_valid = p.M - m_blk;
+    if (Rb) {   // residual tile [256 natural-order rows][BN] via DMA into the free LDS
+        constexpr int RROW = BN * 2, RCH = RROW / 16, RRPI = 1024 / RROW, RJ = 256 / RRPI / 8;
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            const int inst = wave * RJ + j;
+            const int row = inst * RRPI + lane / RCH;
+            const f16* src = row < m_valid ? Rb + (long long)row * ldc + (lane % RCH) * 8 : p.zero_page;
+            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(lds + inst * 1024), 16, 0, 0);
+        }
+        __syncthreads();
+    }
+    const f16* Rl = (const f16*)lds;
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int lcol = wn * (BN / 2) + b * 32 + li;
+        const int col = n_blk + lcol;
+        float cs = 1.f, sh = 0.f;
+        if (p.col_scale) { cs = p.col_scale[col]; sh = p.col_shift[col]; }
+        s1[b] = 0.f;
+        s2[b] = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * lh;   // C row of the 32x32 MFMA
+                int im, y, x;
+                row_to_pixel<TW, IMGS>(wm, a, i, im, y, x);
+                const int rl = (im * TH + y) * TW + x;             // natural row inside the block
+                float v = acc[a][b][e];
+                if (rl < m_valid) {
+                    if (p.col_scale) v = v * cs + sh;
+                    if (Rb) v += (float)Rl[rl * BN + lcol];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    s1[b] += v;
+                    s2[b] += v * v;
+                    Cb[rl * ldc + lcol] = (f16)v;
+                }
+            }
+        }
+    }
+    if (p.stats) {   // per 128 natural rows: waves wm 0,1 own rows 0..127, wm 2,3 rows 128..255 in every geometry
+        float* stat_lds = (float*)lds;  // [4][BN][2]
+        if (Rb) __syncthreads();
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * (BN / 2) + b * 32 + li;
+            const float t1 = s1[b] + __shfl_xor(s1[b], 32);
+            const float t2 = s2[b] + __shfl_xor(s2[b], 32);
+            if (lh == 0) {
+                stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
+                stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 512) {
+            const int half = t / BN, c = t - half * BN;
+            if (half * 128 >= m_valid) continue;
+            float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + c) * 2;
+            o[0] = stat_lds[((half * 2) * BN + c) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + c) * 2 + 0];
+            o[1] = stat_lds[((half * 2) * BN + c) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + c) * 2 + 1];
+        }
+    }
+}
+
+template <int TW, int IMGS>
+int launch_geom(reid_ctx* ctx, const Gemm16Params& p) {
+    const int nmt = (p.M + 255) / 256;
+    if (p.N % 128 == 0) {
+        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128>), dim3(nmt * (p.N / 128)), dim3(512), 0, ctx->stream, p);
+    } else {
+        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64>), dim3(nmt * (p.N / 64)), dim3(512), 0, ctx->stream, p);
+    }
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+}  // namespace
+
+// true when the halo kernel covers this convolution (3x3, stride 1, pad 1, Cin % 64 == 0, one of the three map sizes)
+bool conv3x3_f16_supported(const Gemm16Params& p) {
+    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.Cin % 64 != 0 || p.N % 64 != 0) return false;
+    return (p.W == 32 && p.H % 8 == 0) || (p.W == 16 && p.H % 16 == 0) || (p.W == 8 && p.H == 16);
+}
+
+int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes) {
+    ARG_CHECK(conv3x3_f16_supported(p) && p.zero_page && p.ldb % 8 == 0 && p.M % 128 == 0);
+    prof_begin(ctx, kind, flops, bytes);
+    int st;
+    if (p.W == 32) st = launch_geom<32, 1>(ctx, p);
+    else if (p.W == 16) st = launch_geom<16, 1>(ctx, p);
+    else st = launch_geom<8, 2>(ctx, p);
+    prof_end(ctx);
+    return st;
+}

@@ -33,7 +33,7 @@ namespace {
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int AMODE, int BN, int BK, int NST>
+template <int AMODE, int BN, int BK, int NST, int STAG>
 __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) {
     constexpr int BM = 256;
     constexpr int WM = BN == 256 ? 2 : 4;         // waves along M
@@ -104,39 +104,38 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
         b_base[j] = (long long)(n_blk + row) * p.ldb;
     }
 
-    auto stage = [&](int kt, int slot) {
+    // one DMA piece (wave-instruction) of K-tile kt: q < AJ -> A piece q, else B piece q - AJ
+    auto stage_piece = [&](int kt, int slot, int q) {
         char* As = lds + slot * STAGE;
         char* Bs = As + A_BYTES;
         const int k0 = kt * BK;
+        if (q >= AJ) {
+            const int j = q - AJ;
+            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0 + b_chunk[j] * 8), LPTR(Bs + b_row[j] * ROWB), 16, 0, 0);
+            return;
+        }
+        const int j = q;
         if constexpr (AMODE == A16_DENSE) {
-#pragma unroll
-            for (int j = 0; j < AJ; ++j)
-                __builtin_amdgcn_global_load_lds(GPTR(p.A + a_base[j] + k0 + a_chunk[j] * 8),
-                                                 LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(p.A + a_base[j] + k0 + a_chunk[j] * 8), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
         } else if constexpr (AMODE == A16_IM2COL) {
-            const int tap = k0 / p.Cin;          // K order (tap, channel); Cin % BK == 0
+            // K order (tap, channel); Cin % BK == 0.  (A channel-chunk-major order that lets the nine taps re-read the same
+            // lines back to back was measured: no change.)
+            const int tap = k0 / p.Cin;
             const int c0 = k0 - tap * p.Cin;
             const int r = tap / p.S, s = tap - r * p.S;
-#pragma unroll
-            for (int j = 0; j < AJ; ++j) {
-                const int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
-                const bool ok = a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const f16* src = ok ? p.A + (((long long)a_img[j] * p.H + iy) * p.W + ix) * p.Cin + c0 + a_chunk[j] * 8
-                                    : p.zero_page;
-                __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
-            }
+            const int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
+            const bool ok = a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const f16* src = ok ? p.A + (((long long)a_img[j] * p.H + iy) * p.W + ix) * p.Cin + c0 + a_chunk[j] * 8 : p.zero_page;
+            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
         } else {  // A16_STEM: zero-padded NHWC4 image, k = r*32 + s*4 + c; a 16-B chunk = one pixel pair of one kernel row
-#pragma unroll
-            for (int j = 0; j < AJ; ++j) {
-                const int kq = kt * CH + a_chunk[j];   // chunk index along K: kernel row = kq / 4, pixel pair = kq % 4
-                const long long pix = ((long long)a_img[j] * p.Hp + (a_iy0[j] + 3 + (kq >> 2))) * p.Wp +
-                                      (a_ix0[j] + 3 + 2 * (kq & 3));
-                __builtin_amdgcn_global_load_lds(GPTR(p.A + pix * 4), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
-            }
+            const int kq = kt * CH + a_chunk[j];   // chunk index along K: kernel row = kq / 4, pixel pair = kq % 4
+            const long long pix = ((long long)a_img[j] * p.Hp + (a_iy0[j] + 3 + (kq >> 2))) * p.Wp + (a_ix0[j] + 3 + 2 * (kq & 3));
+            __builtin_amdgcn_global_load_lds(GPTR(p.A + pix * 4), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
         }
+    };
+    auto stage = [&](int kt, int slot) {
 #pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0 + b_chunk[j] * 8), LPTR(Bs + b_row[j] * ROWB), 16, 0, 0);
+        for (int q = 0; q < G; ++q) stage_piece(kt, slot, q);
     };
 
     f32x16 acc[TM][TN];
@@ -157,31 +156,117 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
         if (s < nk) stage(s, s);
 
     int slot_c = 0, slot_i = NST - 1;  // ring slots of the tile being computed / refilled
-    for (int kt = 0; kt < nk; ++kt) {
-        const int rem = nk - 1 - kt;
-        if (NST > 2 && rem >= NST - 2) WAIT_VMCNT((NST - 2) * G);
-        else if (NST > 3 && rem == 1) WAIT_VMCNT(G);
+    if constexpr (STAG == 0 || STAG == 2) {
+        // STAG == 2: diagnostic build of the same loop with s_memtime stamps (never used by the product path):
+        // cycles spent in [vmcnt wait] [barrier] [DMA issue] [fragment reads + MFMAs] summed over the K loop
+        unsigned long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, ta = 0, tb = 0;
+#define STAMP(v) if constexpr (STAG == 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int rem = nk - 1 - kt;
+            STAMP(ta);
+            if (NST > 2 && rem >= NST - 2) WAIT_VMCNT((NST - 2) * G);
+            else if (NST > 3 && rem == 1) WAIT_VMCNT(G);
+            else WAIT_VMCNT(0);
+            STAMP(tb);
+            t_wait += tb - ta;
+            RAW_BARRIER();
+            STAMP(ta);
+            t_bar += ta - tb;
+            // (Issuing the refill in pieces between the MFMA clusters of the k-steps instead was measured: 5-15 % slower.)
+            if (kt + NST - 1 < nk) stage(kt + NST - 1, slot_i);
+            STAMP(tb);
+            t_issue += tb - ta;
+            const char* As = lds + slot_c * STAGE;
+            const char* Bs = As + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int pos = ((kk * 2 + lh) ^ swz) * 16;
+                half8 af[TM], bf[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[a] = *(const half8*)(As + a_row_off + a * 32 * ROWB + pos);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[b] = *(const half8*)(Bs + b_row_off + b * 32 * ROWB + pos);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+            STAMP(ta);
+            t_comp += ta - tb;
+            slot_c = slot_c + 1 == NST ? 0 : slot_c + 1;
+            slot_i = slot_i + 1 == NST ? 0 : slot_i + 1;
+        }
+        if constexpr (STAG == 2) {
+            if (p.diag && lane == 0 && blockIdx.x < 64) {
+                unsigned long long* d = p.diag + ((long long)blockIdx.x * 8 + wave) * 4;
+                d[0] = t_wait; d[1] = t_bar; d[2] = t_issue; d[3] = t_comp;
+            }
+        }
+#undef STAMP
+    } else {
+        // Staggered schedule.  Waves w and w+4 share a SIMD; all eight running the same phase at the same time leaves
+        // the matrix pipe idle whenever they are all reading LDS / issuing DMA (measured: ~1 PF ceiling even on a dense
+        // 8192^3 GEMM).  Each K-tile is split into a LOAD half (issue the ring refill, read every fragment of the tile
+        // into registers) and an MFMA half (registers only); waves 4-7 run half a tile behind waves 0-3, with a block
+        // barrier between half-slots, so one group's LOAD half always sits beside the other group's MFMA half:
+        //     slot 2t   : A = LOAD(t)            B = MFMA(t-1)
+        //     slot 2t+1 : A = MFMA(t) + wait     B = LOAD(t) + wait
+        // "wait" = this wave's own DMA pieces of tile t+1, counted; the barrier after it publishes the tile to all.
+        static_assert(NST >= 3, "the staggered schedule needs at least three ring slots");
+        const bool grpA = wave < 4;
+        half8 af[KS][TM], bf[KS][TN];
+        auto load_half = [&](int kt) {
+            if (kt + NST - 1 < nk) stage(kt + NST - 1, slot_i);
+            const char* As = lds + slot_c * STAGE;
+            const char* Bs = As + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int pos = ((kk * 2 + lh) ^ swz) * 16;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[kk][a] = *(const half8*)(As + a_row_off + a * 32 * ROWB + pos);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[kk][b] = *(const half8*)(Bs + b_row_off + b * 32 * ROWB + pos);
+            }
+            slot_c = slot_c + 1 == NST ? 0 : slot_c + 1;
+            slot_i = slot_i + 1 == NST ? 0 : slot_i + 1;
+        };
+        auto mfma_half = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][a], bf[kk][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto wait_next = [&](int kt) {   // own pieces of tile kt+1 (tiles kt+2 .. may stay in flight)
+            const int rem = nk - 2 - kt;  // tiles issued after kt+1
+            if (rem >= NST - 2) WAIT_VMCNT((NST - 2) * G);
+            else if (NST > 3 && rem == 1) WAIT_VMCNT(G);
+            else WAIT_VMCNT(0);
+        };
+        // tile 0 landed for everyone
+        if (nk - 1 >= NST - 2) WAIT_VMCNT((NST - 2) * G);
+        else if (NST > 3 && nk - 1 == 1) WAIT_VMCNT(G);
         else WAIT_VMCNT(0);
         RAW_BARRIER();
-        if (kt + NST - 1 < nk) stage(kt + NST - 1, slot_i);
-        const char* As = lds + slot_c * STAGE;
-        const char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const int pos = ((kk * 2 + lh) ^ swz) * 16;
-            half8 af[TM], bf[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *(const half8*)(As + a_row_off + a * 32 * ROWB + pos);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = *(const half8*)(Bs + b_row_off + b * 32 * ROWB + pos);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        for (int kt = 0; kt <= nk; ++kt) {
+            if (grpA) {
+                if (kt < nk) load_half(kt);
+            } else {
+                if (kt > 0) mfma_half();
+            }
+            RAW_BARRIER();
+            if (kt < nk) {
+                if (grpA) mfma_half();
+                else load_half(kt);
+                wait_next(kt);
+            }
+            RAW_BARRIER();
         }
-        slot_c = slot_c + 1 == NST ? 0 : slot_c + 1;
-        slot_i = slot_i + 1 == NST ? 0 : slot_i + 1;
     }
     __syncthreads();
 
@@ -267,13 +352,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
     }
 }
 
-template <int AMODE, int BN, int BK, int NST>
+template <int AMODE, int BN, int BK, int NST, int STAG = 0>
 int launch_cfg(reid_ctx* ctx, const Gemm16Params& p) {
     if (p.K % BK != 0 || (AMODE == A16_IM2COL && p.Cin % BK != 0)) {
         reid_set_error("gemm_f16: K=%d / Cin=%d not a multiple of BK=%d", p.K, p.Cin, BK);
         return REID_ERR_ARG;
     }
-    hipLaunchKernelGGL((gemm_f16_kernel<AMODE, BN, BK, NST>), dim3(((p.M + 255) / 256) * (p.N / BN)), dim3(512), 0, ctx->stream, p);
+    hipLaunchKernelGGL((gemm_f16_kernel<AMODE, BN, BK, NST, STAG>), dim3(((p.M + 255) / 256) * (p.N / BN)), dim3(512), 0, ctx->stream, p);
     LAUNCH_CHECK();
     return REID_OK;
 }
@@ -282,7 +367,7 @@ int launch_cfg(reid_ctx* ctx, const Gemm16Params& p) {
 template <int AMODE>
 int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
     int cfg = ctx->f16_cfg;
-    if (cfg == 0 || p.N % (cfg / 1000) != 0) {
+    if (cfg == 0 || p.N % ((cfg % 1000000) / 1000) != 0) {
         // measured per layer shape with tools/bench_conv_f16.py (256 crops): Cout 64 -> 64642 (454 TF), 128 -> 128323
         // (624 TF), 256 -> 128642 (679 TF), 512 -> 256642 (953 TF) when that still gives >= 192 blocks
         const long long mt = (p.M + 255) / 256;
@@ -304,6 +389,20 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
         case 64324: return launch_cfg<AMODE, 64, 32, 4>(ctx, p);
         case 64643: return launch_cfg<AMODE, 64, 64, 3>(ctx, p);
         case 64642: return launch_cfg<AMODE, 64, 64, 2>(ctx, p);
+        // staggered schedule: +1000000
+        case 1256324: return launch_cfg<AMODE, 256, 32, 4, 1>(ctx, p);
+        case 1256323: return launch_cfg<AMODE, 256, 32, 3, 1>(ctx, p);
+        case 1128324: return launch_cfg<AMODE, 128, 32, 4, 1>(ctx, p);
+        case 1128323: return launch_cfg<AMODE, 128, 32, 3, 1>(ctx, p);
+        case 1128643: return launch_cfg<AMODE, 128, 64, 3, 1>(ctx, p);
+        case 1064643: return launch_cfg<AMODE, 64, 64, 3, 1>(ctx, p);
+        case 1064324: return launch_cfg<AMODE, 64, 32, 4, 1>(ctx, p);
+        case 1064323: return launch_cfg<AMODE, 64, 32, 3, 1>(ctx, p);
+        // diagnostic (stamped) builds of the plain loop: +3000000
+        case 3256642: return launch_cfg<AMODE, 256, 64, 2, 2>(ctx, p);
+        case 3128643: return launch_cfg<AMODE, 128, 64, 3, 2>(ctx, p);
+        case 3128642: return launch_cfg<AMODE, 128, 64, 2, 2>(ctx, p);
+        case 3256324: return launch_cfg<AMODE, 256, 32, 4, 2>(ctx, p);
         default:
             reid_set_error("gemm_f16: unknown tile configuration %d", cfg);
             return REID_ERR_ARG;

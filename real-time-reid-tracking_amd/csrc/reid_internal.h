@@ -96,10 +96,13 @@ struct Gemm16Params {
     int relu;
     float* stats;
     const _Float16* zero_page;
+    unsigned long long* diag;   // diagnostic builds only: per-wave cycle sums [block<64][wave][4]
 };
 
 struct reid_ctx;
 int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, double flops, double bytes);
+bool conv3x3_f16_supported(const Gemm16Params& p);   // conv3x3_f16.hip: 3x3 s1 p1 with the input halo tile kept in LDS
+int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);
 // fp16 elementwise kernels (elementwise_f16.hip)
 int launch_prep_u8_pad_f16(reid_ctx*, const uint8_t* crops, int n, int h, int w, int hp, int wp, _Float16* out);
 int launch_prep_f32_pad_f16(reid_ctx*, const float* nhwc3, int n, int h, int w, int hp, int wp, _Float16* out);
@@ -180,6 +183,7 @@ struct reid_ctx {
     int last_n = 0;  // crops in the last embed chunk (for reid_debug_stage)
     bool debug_keep = false;
     bool last_f16 = false;
+    int f16_halo = 1;        // 3x3 stride-1 convs of the fp16 path use the LDS-halo kernel (REID_F16_HALO=0: implicit GEMM)
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
     float* stage_ptr[11] = {nullptr};
 };

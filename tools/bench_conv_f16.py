@@ -18,15 +18,31 @@ fn.restype = C.c_int
 fn.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_float)]
 layers = [("L1 64->64 64x32", 64, 32, 64, 64), ("L2 128->128 32x16", 32, 16, 128, 128),
           ("L3 256->256 16x8", 16, 8, 256, 256), ("L4 512->512 16x8", 16, 8, 512, 512)]
-cfgs = [256324, 256323, 256642, 128324, 128323, 128643, 128642, 64323, 64324, 64643, 64642]
+cfgs = [256642, 128643, 128642, 64642, 2000000]   # 2000000 = LDS-halo kernel (conv3x3_f16.hip)
 for name, h, w, cin, cout in layers:
     flops = 2.0 * n * h * w * cout * 9 * cin
     best = {}
     for rep in range(2):
         for cfg in cfgs:
-            if cout % (cfg // 1000):
+            if cfg < 2000000 and cout % ((cfg % 1000000) // 1000):
                 continue
             ms = C.c_float()
             check(fn(eng.h, n, h, w, cin, cout, 3, 1, 1, cfg, 10, C.byref(ms)))
             best[cfg] = min(ms.value, best.get(cfg, 1e9))
     print(name, " ".join("%d:%.0fTF" % (k, flops / (v * 1e-3) / 1e12) for k, v in sorted(best.items(), key=lambda kv: kv[1])))
+
+# dense GEMMs of the same sizes (no im2col gather): separates the gather from the tile loop
+gf = eng.lib.reid_debug_gemm_f16
+gf.restype = C.c_int
+gf.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(C.c_float), C.c_void_p]
+for name, m, nn, k in (("dense L4-size 32768x512x4608", n * 128, 512, 4608), ("dense 8192x8192x4096", 8192, 8192, 4096),
+                       ("dense L1-size %dx64x576" % (n * 2048), n * 2048, 64, 576)):
+    best = {}
+    for rep in range(2):
+        for cfg in cfgs:
+            if cfg >= 2000000 or nn % ((cfg % 1000000) // 1000):
+                continue
+            ms = C.c_float()
+            check(gf(eng.h, m, nn, k, cfg, 5, C.byref(ms), None))
+            best[cfg] = min(ms.value, best.get(cfg, 1e9))
+    print(name, " ".join("%d:%.0fTF" % (c, 2.0 * m * nn * k / (v * 1e-3) / 1e12) for c, v in sorted(best.items(), key=lambda kv: kv[1])))
