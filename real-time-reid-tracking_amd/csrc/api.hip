@@ -37,6 +37,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     reid_ctx* c = new reid_ctx();
     c->device = device;
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
+    if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -457,6 +458,7 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
 }
 
 // ------------------------------------------------------------------------------------------------ fp16 forward
+static unsigned long long* g_conv_diag = nullptr;   // experiments: stamps of the loader-wave conv kernel
 static int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H, int W, int Cin, const _Float16* wgt, int Cout,
                        int R, int S, int stride, int pad, int K, const float* col_scale, const float* col_shift,
                        const _Float16* residual, int relu, float* stats, _Float16* out, int Hp = 0, int Wp = 0) {
@@ -471,17 +473,16 @@ static int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H
     p.C = out; p.ldc = Cout;
     p.col_scale = col_scale; p.col_shift = col_shift; p.residual = residual; p.relu = relu; p.stats = stats;
     p.zero_page = ctx->se18.zero_page;
+    p.diag = g_conv_diag;
     const double ktrue = (double)R * S * (amode == A16_STEM ? 3 : Cin);
     const double flops = 2.0 * p.M * Cout * ktrue;
     const double bytes = ((double)n * H * W * (amode == A16_STEM ? 4 : Cin) + (double)p.M * Cout + (double)Cout * ktrue +
                           (residual ? (double)p.M * Cout : 0.0)) * 2.0;
-    // 3x3 stride-1 convs: the LDS-halo kernel where it measured faster (tools/bench_conv_f16.py, 256 crops): 32x16 maps
-    // 621 vs 561 TF, 16x8 x256ch 776 vs 681 TF; the implicit GEMM keeps Cout = 64 (451 vs 373 TF) and Cout = 512 when its
-    // 256x256 tiles still fill the chip (963 vs 943 TF)
+    // 3x3 stride-1 convs: the LDS-halo kernel (8 compute + 4 loader waves) where it measured faster (tools/bench_conv_f16.py,
+    // 256 crops): 32x16 maps 715 vs 604 TF, 16x8 x256ch 858 vs 745 TF, 16x8 x512ch 1015 vs 987 TF; the implicit GEMM keeps
+    // Cout = 64 (489 vs 447 TF: nine K-tiles only, the halo kernel's longer prologue does not amortise)
     if (amode == A16_IM2COL && ctx->f16_halo && conv3x3_f16_supported(p)) {
-        const long long blocks256 = (long long)((p.M + 255) / 256) * (Cout / 256);
-        const bool gemm_better = Cout == 64 || (Cout % 256 == 0 && Cout >= 512 && blocks256 >= 192);
-        if (ctx->f16_halo == 2 || !gemm_better) return launch_conv3x3_f16(ctx, p, REID_K_CONV_GEMM, flops, bytes);
+        if (ctx->f16_halo == 2 || Cout >= 128) return launch_conv3x3_f16(ctx, p, REID_K_CONV_GEMM, flops, bytes);
     }
     return launch_gemm_f16(ctx, amode, p, REID_K_CONV_GEMM, flops, bytes);
 }
@@ -978,8 +979,10 @@ extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, 
     for (size_t o = 0; o < nw; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nw - o < src_n ? nw - o : src_n, wt + o));
     const int c0 = ctx->f16_cfg;
     const int h0 = ctx->f16_halo;
-    ctx->f16_halo = cfg >= 2000000 ? 2 : 0;   // 2xxxxxx: force the LDS-halo kernel
-    ctx->f16_cfg = cfg % 2000000;
+    ctx->f16_halo = cfg >= 2000000 ? 2 : 0;   // 2xxxxxx: force the LDS-halo kernel, 2000001: with loader waves
+    const int l0 = ctx->f16_loader_waves;
+    if (cfg >= 2000000) ctx->f16_loader_waves = cfg & 1;
+    ctx->f16_cfg = cfg >= 2000000 ? 0 : cfg;
     int st = REID_OK;
     for (int i = 0; i < 2 && st == REID_OK; ++i)
         st = conv_gemm16(ctx, A16_IM2COL, x, n, h, w, cin, wt, cout, r, r, stride, pad, r * r * cin, nullptr, nullptr, nullptr, 0, nullptr, out);
@@ -990,6 +993,7 @@ extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, 
     if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
     ctx->f16_cfg = c0;
     ctx->f16_halo = h0;
+    ctx->f16_loader_waves = l0;
     *ms_per_launch = ms / (iters > 0 ? iters : 1);
     return st;
 }
@@ -1034,4 +1038,19 @@ extern "C" int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, 
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return st;
+}
+
+extern "C" int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long long* out_host /* [64*8*4] when disabling */) {
+    ARG_CHECK(ctx);
+    if (enable) {
+        REID_TRY(ctx_ws(ctx, "dbg.cdiag", 64 * 8 * 5 * 8, (void**)&g_conv_diag));
+        HIP_TRY(hipMemsetAsync(g_conv_diag, 0, 64 * 8 * 5 * 8, ctx->stream));
+    } else {
+        if (out_host && g_conv_diag) {
+            HIP_TRY(hipMemcpyAsync(out_host, g_conv_diag, 64 * 8 * 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        g_conv_diag = nullptr;
+    }
+    return REID_OK;
 }

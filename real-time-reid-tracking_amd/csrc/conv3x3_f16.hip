@@ -52,8 +52,20 @@ __device__ __forceinline__ void row_to_pixel(int wm, int a, int i, int& img, int
     }
 }
 
-template <int TW, int IMGS, int BN>
-__global__ __launch_bounds__(512, 2) void conv3x3_f16_kernel(const Gemm16Params p) {
+// Natural row (inside the block's 256 rows) of accumulator register e of MFMA tile (wm, a) in lane half lh.
+// C row i = (e&3) + 8*(e>>2) + 4*lh; for that i the ds_read_b128 lane group is lh ^ (q == 1 || q == 2) with q = e >> 2 and the
+// rank inside the group is simply e (check: q=0 -> lanes 0-3 / 4-7, q=1 -> 8-11 / 12-15, q=2 -> 16-19 / 20-23, q=3 -> 24-27 / 28-31).
+template <int TW, int IMGS>
+__device__ __forceinline__ int c_row_natural(int wm, int a, int e, int lh) {
+    const int q = e >> 2;
+    const int g = lh ^ ((q == 1 || q == 2) ? 1 : 0);
+    if constexpr (TW == 32) return (wm * 2 + a) * 32 + (e & 3) + 8 * q + 4 * lh;
+    else if constexpr (TW == 16) return (wm * 4 + a * 2 + g) * 16 + e;
+    else return ((wm >> 1) * 16 + (wm & 1) * 8 + a * 2 + g + 4 * (e >> 3)) * 8 + (e & 7);
+}
+
+template <int TW, int IMGS, int BN, int LW>
+__global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm16Params p) {
     constexpr int TH = 256 / (IMGS * TW);            // tile rows per image
     constexpr int WP = TW + 2, HP = TH + 2;          // halo pitch / rows
     constexpr int NPX = IMGS * HP * WP;              // halo pixels per block
@@ -66,10 +78,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_kernel(const Gemm16Params 
     constexpr int TM = 2;
     static_assert(2 * HALO_BYTES + 3 * B_BYTES <= 160 * 1024, "LDS budget");
     static_assert(HPW <= 6, "halo pieces are issued one per tap");
+    constexpr int NLW = 4;                            // loader waves (LW == 1): waves 8..11 issue every DMA piece
+    constexpr int BPL = BN / 8 / NLW;                 // weight pieces per loader wave per tile
+    static_assert(6 * 8 >= NPI, "halo pieces of the next chunk are issued over taps 0..7, six per tap");
     __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + 3 * B_BYTES];
     char* halo = lds;
     char* ring = lds + 2 * HALO_BYTES;
 
+    unsigned long long t_entry = 0, t_loop_end = 0;
+    if (p.diag) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -143,30 +160,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_kernel(const Gemm16Params 
     const int b_row_off = (wn * (BN / 2) + li) * 128;
     const int b_swz = (li >> 1) & 7;
 
-    // prologue: halo of chunk 0, weight tiles 0 and 1
-#pragma unroll
-    for (int k = 0; k < HPW; ++k)
-        if (wave + 8 * k < NPI) issue_halo_piece(wave + 8 * k, 0, 0);
-    issue_b(0, 0);
-    if (nt > 1) issue_b(1, 1);
-    int prev_b = nt > 1 ? 1 : 0;      // did the previous "iteration" issue a weight tile / a halo piece (for the counted wait)
-    int prev_h = 0;
-
-    int slot_c = 0, slot_i = 2, chunk = 0, tap = 0;
-    for (int t = 0; t < nt; ++t) {
-        // everything except what was issued in the previous iteration has landed after this wait
-        if (prev_b && prev_h) WAIT_VMCNT(BJ + 1);
-        else if (prev_b) WAIT_VMCNT(BJ);
-        else if (prev_h) WAIT_VMCNT(1);
-        else WAIT_VMCNT(0);
-        RAW_BARRIER();
-        prev_b = 0;
-        prev_h = 0;
-        if (t + 2 < nt) { issue_b(t + 2, slot_i); prev_b = 1; }
-        if (tap < HPW && chunk + 1 < nchunk && wave + 8 * tap < NPI) { issue_halo_piece(wave + 8 * tap, chunk + 1, (chunk + 1) & 1); prev_h = 1; }
-
+    const bool is_loader = LW && wave >= 8;
+    auto compute_tile = [&](int chunk, int tap, int slot) {
         const char* As = halo + (chunk & 1) * HALO_BYTES;
-        const char* Bs = ring + slot_c * B_BYTES;
+        const char* Bs = ring + slot * B_BYTES;
         const int r = tap / 3, s = tap - r * 3;
         int a_off[TM], a_swz[TM];
 #pragma unroll
@@ -188,9 +185,95 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_kernel(const Gemm16Params 
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        slot_c = slot_c == 2 ? 0 : slot_c + 1;
-        slot_i = slot_i == 2 ? 0 : slot_i + 1;
-        if (++tap == 9) { tap = 0; ++chunk; }
+    };
+
+    if constexpr (LW == 0) {
+        // prologue: halo of chunk 0, weight tiles 0 and 1
+#pragma unroll
+        for (int k = 0; k < HPW; ++k)
+            if (wave + 8 * k < NPI) issue_halo_piece(wave + 8 * k, 0, 0);
+        issue_b(0, 0);
+        if (nt > 1) issue_b(1, 1);
+        int prev_b = nt > 1 ? 1 : 0, prev_h = 0;   // what the previous iteration issued (for the counted wait)
+        int slot_c = 0, slot_i = 2, chunk = 0, tap = 0;
+        for (int t = 0; t < nt; ++t) {
+            // everything except what was issued in the previous iteration has landed after this wait
+            if (prev_b && prev_h) WAIT_VMCNT(BJ + 1);
+            else if (prev_b) WAIT_VMCNT(BJ);
+            else if (prev_h) WAIT_VMCNT(1);
+            else WAIT_VMCNT(0);
+            RAW_BARRIER();
+            prev_b = 0;
+            prev_h = 0;
+            if (t + 2 < nt) { issue_b(t + 2, slot_i); prev_b = 1; }
+            if (tap < HPW && chunk + 1 < nchunk && wave + 8 * tap < NPI) { issue_halo_piece(wave + 8 * tap, chunk + 1, (chunk + 1) & 1); prev_h = 1; }
+            compute_tile(chunk, tap, slot_c);
+            slot_c = slot_c == 2 ? 0 : slot_c + 1;
+            slot_i = slot_i == 2 ? 0 : slot_i + 1;
+            if (++tap == 9) { tap = 0; ++chunk; }
+        }
+    } else {
+        // Warp-specialised: waves 8..11 only move data (their DMA issue stalls - ~110 cycles per piece on the L1/TA path -
+        // no longer sit in the instruction stream of the MFMA waves), waves 0..7 only read LDS and issue MFMAs.  One block
+        // barrier per tile: a loader arrives once its pieces of the NEXT tile have landed, a compute wave once it has
+        // finished the current tile, so after barrier t tile t is complete in LDS and the slot of tile t-1 is free.
+        int slot_c = 0, slot_i = 2, chunk = 0, tap = 0;
+        if (is_loader) {
+            const int lw = wave - 8;
+            auto loader_b = [&](int t, int slot) {   // this loader's BPL pieces of weight tile t
+                const int ck = t / 9, tp = t - ck * 9;
+                const int k0 = tp * p.Cin + ck * 64;
+#pragma unroll
+                for (int j = 0; j < BPL; ++j) {
+                    const int inst = lw * BPL + j;
+                    const int row = inst * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ ((row >> 1) & 7);
+                    __builtin_amdgcn_global_load_lds(GPTR(p.B + (long long)(n_blk + row) * p.ldb + k0 + c * 8),
+                                                     LPTR(ring + slot * B_BYTES + inst * 1024), 16, 0, 0);
+                }
+            };
+            for (int q = lw; q < NPI; q += NLW) issue_halo_piece(q, 0, 0);
+            loader_b(0, 0);
+            if (nt > 1) loader_b(1, 1);
+            int last = nt > 1 ? BPL : 0;   // pieces in the most recently issued group
+            for (int t = 0; t < nt; ++t) {
+                // all but the most recent group (tile t+1's weights) have landed: tile t and its halo are complete
+                if (last == BPL + 2) WAIT_VMCNT(BPL + 2);
+                else if (last == BPL + 1) WAIT_VMCNT(BPL + 1);
+                else if (last == BPL) WAIT_VMCNT(BPL);
+                else WAIT_VMCNT(0);
+                RAW_BARRIER();
+                last = 0;
+                if (t + 2 < nt) { loader_b(t + 2, slot_i); last += BPL; }
+                if (tap < 8 && chunk + 1 < nchunk) {   // halo of the next chunk: six pieces per tap over taps 0..7
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int q = tap * 6 + lw + 4 * k;
+                        if (lw + 4 * k < 6 && q < NPI) { issue_halo_piece(q, chunk + 1, (chunk + 1) & 1); ++last; }
+                    }
+                }
+                slot_i = slot_i == 2 ? 0 : slot_i + 1;
+                if (++tap == 9) { tap = 0; ++chunk; }
+            }
+            WAIT_VMCNT(0);
+        } else {
+            unsigned long long t_bar = 0, t_comp = 0, ta = 0, tb = 0;
+            const bool dg = p.diag != nullptr;   // diagnostic stamps (experiments only)
+            for (int t = 0; t < nt; ++t) {
+                if (dg) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ta) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+                RAW_BARRIER();
+                if (dg) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb) :: "memory"); __builtin_amdgcn_sched_barrier(0); t_bar += tb - ta; }
+                compute_tile(chunk, tap, slot_c);
+                if (dg) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ta) :: "memory"); __builtin_amdgcn_sched_barrier(0); t_comp += ta - tb; }
+                slot_c = slot_c == 2 ? 0 : slot_c + 1;
+                if (++tap == 9) { tap = 0; ++chunk; }
+            }
+            if (dg && lane == 0 && blockIdx.x < 64) {
+                unsigned long long* d = p.diag + ((long long)blockIdx.x * 8 + wave) * 4;
+                d[0] = t_bar; d[1] = t_comp; d[2] = nt; d[3] = ta - t_entry;   // d[3]: kernel entry -> end of the K loop
+                t_loop_end = ta;
+            }
+        }
     }
     __syncthreads();
 
@@ -204,6 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_kernel(const Gemm16Params 
         constexpr int RROW = BN * 2, RCH = RROW / 16, RRPI = 1024 / RROW, RJ = 256 / RRPI / 8;
 #pragma unroll
         for (int j = 0; j < RJ; ++j) {
+            if (is_loader) break;
             const int inst = wave * RJ + j;
             const int row = inst * RRPI + lane / RCH;
             const f16* src = row < m_valid ? Rb + (long long)row * ldc + (lane % RCH) * 8 : p.zero_page;
@@ -212,23 +296,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_kernel(const Gemm16Params 
         __syncthreads();
     }
     const f16* Rl = (const f16*)lds;
+    constexpr int NTHR = LW ? 768 : 512;
+    // pass 1: BN / residual / ReLU in fp32, in place in the accumulators; per-column partial sums
     float s1[TN], s2[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
+        s1[b] = 0.f;
+        s2[b] = 0.f;
+        if (is_loader) continue;
         const int lcol = wn * (BN / 2) + b * 32 + li;
         const int col = n_blk + lcol;
         float cs = 1.f, sh = 0.f;
         if (p.col_scale) { cs = p.col_scale[col]; sh = p.col_shift[col]; }
-        s1[b] = 0.f;
-        s2[b] = 0.f;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int i = (e & 3) + 8 * (e >> 2) + 4 * lh;   // C row of the 32x32 MFMA
-                int im, y, x;
-                row_to_pixel<TW, IMGS>(wm, a, i, im, y, x);
-                const int rl = (im * TH + y) * TW + x;             // natural row inside the block
+                const int rl = c_row_natural<TW, IMGS>(wm, a, e, lh);   // natural row inside the block
                 float v = acc[a][b][e];
                 if (rl < m_valid) {
                     if (p.col_scale) v = v * cs + sh;
@@ -236,42 +320,67 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_kernel(const Gemm16Params 
                     if (p.relu) v = fmaxf(v, 0.f);
                     s1[b] += v;
                     s2[b] += v * v;
-                    Cb[rl * ldc + lcol] = (f16)v;
                 }
+                acc[a][b][e] = v;
             }
         }
     }
+    __syncthreads();   // every wave is done with the residual tile
     if (p.stats) {   // per 128 natural rows: waves wm 0,1 own rows 0..127, wm 2,3 rows 128..255 in every geometry
         float* stat_lds = (float*)lds;  // [4][BN][2]
-        if (Rb) __syncthreads();
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int lcol = wn * (BN / 2) + b * 32 + li;
             const float t1 = s1[b] + __shfl_xor(s1[b], 32);
             const float t2 = s2[b] + __shfl_xor(s2[b], 32);
-            if (lh == 0) {
+            if (lh == 0 && !is_loader) {
                 stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
                 stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
             }
         }
         __syncthreads();
-        for (int t = tid; t < 2 * BN; t += 512) {
+        for (int t = tid; t < 2 * BN; t += NTHR) {
             const int half = t / BN, c = t - half * BN;
             if (half * 128 >= m_valid) continue;
             float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + c) * 2;
             o[0] = stat_lds[((half * 2) * BN + c) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + c) * 2 + 0];
             o[1] = stat_lds[((half * 2) * BN + c) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + c) * 2 + 1];
         }
+        __syncthreads();
+    }
+    // pass 2: output tile in natural row order through LDS, then whole 16-byte pieces of a row per lane (see gemm_f16.hip)
+    f16* tile = (f16*)lds;
+    if (!is_loader) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * (BN / 2) + b * 32 + li;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tile[c_row_natural<TW, IMGS>(wm, a, e, lh) * BN + lcol] = (f16)acc[a][b][e];
+        }
+    }
+    __syncthreads();
+    constexpr int C8 = BN / 8;
+    for (int idx = tid; idx < 256 * C8; idx += NTHR) {
+        const int row = idx / C8, c8 = idx - row * C8;
+        if (row < m_valid) *(half8*)(Cb + (long long)row * ldc + c8 * 8) = *(const half8*)(tile + row * BN + c8 * 8);
+    }
+    if (LW && p.diag && !is_loader && lane == 0 && blockIdx.x < 64) {
+        unsigned long long te;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te) :: "memory");
+        p.diag[64 * 8 * 4 + blockIdx.x * 8 + wave] = te - t_loop_end;   // epilogue incl. store drain
     }
 }
 
-template <int TW, int IMGS>
+template <int TW, int IMGS, int LW>
 int launch_geom(reid_ctx* ctx, const Gemm16Params& p) {
     const int nmt = (p.M + 255) / 256;
+    const int threads = LW ? 768 : 512;
     if (p.N % 128 == 0) {
-        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128>), dim3(nmt * (p.N / 128)), dim3(512), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW>), dim3(nmt * (p.N / 128)), dim3(threads), 0, ctx->stream, p);
     } else {
-        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64>), dim3(nmt * (p.N / 64)), dim3(512), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64, LW>), dim3(nmt * (p.N / 64)), dim3(threads), 0, ctx->stream, p);
     }
     LAUNCH_CHECK();
     return REID_OK;
@@ -289,9 +398,15 @@ int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double fl
     ARG_CHECK(conv3x3_f16_supported(p) && p.zero_page && p.ldb % 8 == 0 && p.M % 128 == 0);
     prof_begin(ctx, kind, flops, bytes);
     int st;
-    if (p.W == 32) st = launch_geom<32, 1>(ctx, p);
-    else if (p.W == 16) st = launch_geom<16, 1>(ctx, p);
-    else st = launch_geom<8, 2>(ctx, p);
+    if (ctx->f16_loader_waves) {
+        if (p.W == 32) st = launch_geom<32, 1, 1>(ctx, p);
+        else if (p.W == 16) st = launch_geom<16, 1, 1>(ctx, p);
+        else st = launch_geom<8, 2, 1>(ctx, p);
+    } else {
+        if (p.W == 32) st = launch_geom<32, 1, 0>(ctx, p);
+        else if (p.W == 16) st = launch_geom<16, 1, 0>(ctx, p);
+        else st = launch_geom<8, 2, 0>(ctx, p);
+    }
     prof_end(ctx);
     return st;
 }

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
     }
     const f16* Rl = (const f16*)lds;
 
+    // pass 1: BN / residual / ReLU in fp32, in place in the accumulators; per-column partial sums
     float s1[TN], s2[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
@@ -308,23 +309,22 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
-                const int off = rl * ldc + lcol;
                 float v = acc[a][b][e];
                 if (rl < m_valid) {
                     if (p.col_scale) v = v * cs + sh;
-                    if (Rb) v += RES_LDS ? (float)Rl[rl * BN + lcol] : (float)Rb[off];
+                    if (Rb) v += RES_LDS ? (float)Rl[rl * BN + lcol] : (float)Rb[rl * ldc + lcol];
                     if (p.relu) v = fmaxf(v, 0.f);
                     s1[b] += v;
                     s2[b] += v * v;
-                    Cb[off] = (f16)v;
                 }
+                acc[a][b][e] = v;
             }
         }
     }
+    __syncthreads();   // every wave is done with the residual tile
     if (p.stats) {
         // statistics are kept per 128-row tile (= per image for the 16x8 maps): the block covers two of them
         float* stat_lds = (float*)lds;  // [WM][BN][2]
-        if (RES_LDS && Rb) __syncthreads();  // every wave has finished reading the residual tile
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int lcol = wn * WTN + b * 32 + li;
@@ -348,6 +348,39 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
             float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + c) * 2;
             o[0] = t1;
             o[1] = t2;
+        }
+        __syncthreads();
+    }
+    // pass 2: the output tile goes through LDS so that global stores are whole 16-byte pieces of a row (the per-lane
+    // 2-byte stores of the MFMA layout cost a third of the block's time: one block per CU, nothing overlaps the tail)
+    constexpr bool OUT_LDS = BM * BN * 2 <= NST * STAGE;
+    if constexpr (OUT_LDS) {
+        f16* tile = (f16*)lds;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tile[(row0 + a * 32 + (e & 3) + 8 * (e >> 2)) * BN + lcol] = (f16)acc[a][b][e];
+        }
+        __syncthreads();
+        constexpr int C8 = BN / 8;
+        for (int idx = tid; idx < BM * C8; idx += 512) {
+            const int row = idx / C8, c8 = idx - row * C8;
+            if (row < m_valid) *(half8*)(Cb + (long long)row * ldc + c8 * 8) = *(const half8*)(tile + row * BN + c8 * 8);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
+                    if (rl < m_valid) Cb[rl * ldc + lcol] = (f16)acc[a][b][e];
+                }
         }
     }
 }
