@@ -15,6 +15,7 @@
 //   W = 32: a 32-row MFMA tile = one image row;  W = 16: one lane group = one image row;
 //   W = 8 : one lane group = rows y and y+4 (halo pitch 10: 40 = 8 mod 16).
 #include "reid_internal.h"
+#include <type_traits>
 
 typedef _Float16 f16;
 typedef f16 half8 __attribute__((ext_vector_type(8)));
@@ -255,7 +256,9 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
                 slot_i = slot_i == 2 ? 0 : slot_i + 1;
                 if (++tap == 9) { tap = 0; ++chunk; }
             }
-            WAIT_VMCNT(0);
+            // Every piece has landed (the wait before the last barrier was vmcnt(0)): the loaders are done.  A finished
+            // wave no longer counts towards s_barrier, so the eight compute waves run the epilogue on their own.
+            return;
         } else {
             unsigned long long t_bar = 0, t_comp = 0, ta = 0, tb = 0;
             const bool dg = p.diag != nullptr;   // diagnostic stamps (experiments only)
@@ -287,7 +290,6 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         constexpr int RROW = BN * 2, RCH = RROW / 16, RRPI = 1024 / RROW, RJ = 256 / RRPI / 8;
 #pragma unroll
         for (int j = 0; j < RJ; ++j) {
-            if (is_loader) break;
             const int inst = wave * RJ + j;
             const int row = inst * RRPI + lane / RCH;
             const f16* src = row < m_valid ? Rb + (long long)row * ldc + (lane % RCH) * 8 : p.zero_page;
@@ -296,35 +298,49 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         __syncthreads();
     }
     const f16* Rl = (const f16*)lds;
-    constexpr int NTHR = LW ? 768 : 512;
-    // pass 1: BN / residual / ReLU in fp32, in place in the accumulators; per-column partial sums
+    constexpr int NTHR = 512;   // the loader waves of the LW variant have exited
+    // pass 1: BN / residual / ReLU in fp32, in place in the accumulators; per-column partial sums.  Straight-line and
+    // branch-free: rows past m_valid (ragged last tile) all belong to the waves of the second 128-row half, whose
+    // statistics and stores are skipped as a whole, so no per-element predicate is needed; flags become operands.
     float s1[TN], s2[TN];
+    const float lo = p.relu ? 0.f : -INFINITY;
+    auto pass1 = [&](auto with_res) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        s1[b] = 0.f;
-        s2[b] = 0.f;
-        if (is_loader) continue;
-        const int lcol = wn * (BN / 2) + b * 32 + li;
-        const int col = n_blk + lcol;
-        float cs = 1.f, sh = 0.f;
-        if (p.col_scale) { cs = p.col_scale[col]; sh = p.col_shift[col]; }
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * (BN / 2) + b * 32 + li;
+            const int col = n_blk + lcol;
+            const float cs = p.col_scale ? p.col_scale[col] : 1.f;
+            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+            float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
+            for (int a = 0; a < TM; ++a) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rl = c_row_natural<TW, IMGS>(wm, a, e, lh);   // natural row inside the block
-                float v = acc[a][b][e];
-                if (rl < m_valid) {
-                    if (p.col_scale) v = v * cs + sh;
-                    if (Rb) v += (float)Rl[rl * BN + lcol];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    s1[b] += v;
-                    s2[b] += v * v;
+                for (int eg = 0; eg < 4; ++eg) {   // four rows at a time keeps the live set inside the 168-VGPR budget
+                    float r[4];
+                    if constexpr (decltype(with_res)::value) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] = (float)Rl[c_row_natural<TW, IMGS>(wm, a, eg * 4 + e, lh) * BN + lcol];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[a][b][eg * 4 + e] * cs + sh;
+                        if constexpr (decltype(with_res)::value) v += r[e];
+                        v = fmaxf(v, lo);
+                        t1 += v;
+                        t2 += v * v;
+                        acc[a][b][eg * 4 + e] = v;
+                    }
                 }
-                acc[a][b][e] = v;
             }
+            s1[b] = t1;
+            s2[b] = t2;
         }
-    }
+    };
+    if (Rb) pass1(std::true_type{});
+    else pass1(std::false_type{});
+    unsigned long long te1 = 0, te2 = 0, te3 = 0, te4 = 0;
+#define ESTAMP(v) if (LW && p.diag) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    ESTAMP(te1);
     __syncthreads();   // every wave is done with the residual tile
     if (p.stats) {   // per 128 natural rows: waves wm 0,1 own rows 0..127, wm 2,3 rows 128..255 in every geometry
         float* stat_lds = (float*)lds;  // [4][BN][2]
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
             const int lcol = wn * (BN / 2) + b * 32 + li;
             const float t1 = s1[b] + __shfl_xor(s1[b], 32);
             const float t2 = s2[b] + __shfl_xor(s2[b], 32);
-            if (lh == 0 && !is_loader) {
+            if (lh == 0) {
                 stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
                 stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
             }
@@ -348,28 +364,31 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         }
         __syncthreads();
     }
+    ESTAMP(te2);
     // pass 2: output tile in natural row order through LDS, then whole 16-byte pieces of a row per lane (see gemm_f16.hip)
     f16* tile = (f16*)lds;
-    if (!is_loader) {
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int lcol = wn * (BN / 2) + b * 32 + li;
+    for (int b = 0; b < TN; ++b) {
+        const int lcol = wn * (BN / 2) + b * 32 + li;
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) tile[c_row_natural<TW, IMGS>(wm, a, e, lh) * BN + lcol] = (f16)acc[a][b][e];
-        }
+            for (int e = 0; e < 16; ++e) tile[c_row_natural<TW, IMGS>(wm, a, e, lh) * BN + lcol] = (f16)acc[a][b][e];
     }
+    ESTAMP(te3);
     __syncthreads();
     constexpr int C8 = BN / 8;
     for (int idx = tid; idx < 256 * C8; idx += NTHR) {
         const int row = idx / C8, c8 = idx - row * C8;
         if (row < m_valid) *(half8*)(Cb + (long long)row * ldc + c8 * 8) = *(const half8*)(tile + row * BN + c8 * 8);
     }
-    if (LW && p.diag && !is_loader && lane == 0 && blockIdx.x < 64) {
-        unsigned long long te;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te) :: "memory");
-        p.diag[64 * 8 * 4 + blockIdx.x * 8 + wave] = te - t_loop_end;   // epilogue incl. store drain
+    if (LW && p.diag && lane == 0 && blockIdx.x < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ESTAMP(te4);
+        if (wave == 0) {
+            unsigned long long* d2 = p.diag + 64 * 8 * 4 + blockIdx.x * 8;
+            d2[0] = te1 - t_loop_end; d2[1] = te2 - te1; d2[2] = te3 - te2; d2[3] = te4 - te3;   // pass1 | sync+stats | LDS writes | sync+stores+drain
+        }
     }
 }
 

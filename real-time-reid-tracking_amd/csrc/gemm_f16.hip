@@ -21,6 +21,7 @@
 // that keeps the ring in 160 KB of LDS.
 // Requirements: M % 128 == 0 (a ragged last 256-row tile is predicated), N % 64 == 0, K % BK == 0.
 #include "reid_internal.h"
+#include <type_traits>
 
 typedef _Float16 f16;
 typedef f16 half8 __attribute__((ext_vector_type(8)));
@@ -294,33 +295,46 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
     }
     const f16* Rl = (const f16*)lds;
 
-    // pass 1: BN / residual / ReLU in fp32, in place in the accumulators; per-column partial sums
+    // pass 1: BN / residual / ReLU in fp32, in place in the accumulators; per-column partial sums.  Straight-line and
+    // branch-free: rows past m_valid (ragged last tile) all belong to the waves of the second 128-row half, whose
+    // statistics and stores are skipped as a whole, so no per-element predicate is needed; flags become operands.
     float s1[TN], s2[TN];
+    const float lo = p.relu ? 0.f : -INFINITY;
+    auto pass1 = [&](auto with_res) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int lcol = wn * WTN + b * 32 + li;
-        const int col = n_blk + lcol;
-        float cs = 1.f, sh = 0.f;
-        if (p.col_scale) { cs = p.col_scale[col]; sh = p.col_shift[col]; }
-        s1[b] = 0.f;
-        s2[b] = 0.f;
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * WTN + b * 32 + li;
+            const int col = n_blk + lcol;
+            const float cs = p.col_scale ? p.col_scale[col] : 1.f;
+            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+            float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
+            for (int a = 0; a < TM; ++a) {
+                float r[16];
+                if constexpr (decltype(with_res)::value) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
-                float v = acc[a][b][e];
-                if (rl < m_valid) {
-                    if (p.col_scale) v = v * cs + sh;
-                    if (Rb) v += RES_LDS ? (float)Rl[rl * BN + lcol] : (float)Rb[rl * ldc + lcol];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    s1[b] += v;
-                    s2[b] += v * v;
+                    for (int e = 0; e < 16; ++e) {
+                        const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
+                        if constexpr (RES_LDS) r[e] = (float)Rl[rl * BN + lcol];
+                        else r[e] = rl < m_valid ? (float)Rb[rl * ldc + lcol] : 0.f;
+                    }
                 }
-                acc[a][b][e] = v;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[a][b][e] * cs + sh;
+                    if constexpr (decltype(with_res)::value) v += r[e];
+                    v = fmaxf(v, lo);
+                    t1 += v;
+                    t2 += v * v;
+                    acc[a][b][e] = v;
+                }
             }
+            s1[b] = t1;
+            s2[b] = t2;
         }
-    }
+    };
+    if (Rb) pass1(std::true_type{});
+    else pass1(std::false_type{});
     __syncthreads();   // every wave is done with the residual tile
     if (p.stats) {
         // statistics are kept per 128-row tile (= per image for the 16x8 maps): the block covers two of them

@@ -31,5 +31,6 @@ for name, h, w, cin, cout in (("L2 128->128 32x16", 32, 16, 128, 128), ("L3 256-
     print("%s: %.0f TF stamped; per tile: barrier %.0f  reads+mfma %.0f cycles (MFMA alone: 512/wave, 1024/SIMD); tiles %d"
           % (name, 2.0 * n * h * w * cout * 9 * cin / (ms.value * 1e-3) / 1e12, d[..., 0].mean() / nt, d[..., 1].mean() / nt, nt))
     loop = (d[..., 0] + d[..., 1]).mean()
-    print("     cycles per block: entry->loop end %.0f (loop itself %.0f, so prologue %.0f), epilogue %.0f; kernel time %.1f us"
-          % (d[..., 3].mean(), loop, d[..., 3].mean() - loop, epi.mean(), ms.value * 1e3))
+    e4 = epi[:, :4].mean(0)
+    print("     cycles per block: entry->loop end %.0f (loop itself %.0f, so prologue+stamps %.0f); epilogue: pass1 %.0f | sync+stats %.0f | LDS writes %.0f | sync+stores+drain %.0f; kernel %.1f us"
+          % (d[..., 3].mean(), loop, d[..., 3].mean() - loop, e4[0], e4[1], e4[2], e4[3], ms.value * 1e3))
