@@ -134,6 +134,12 @@ int reid_argmin_rows_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_
 int reid_knn(reid_ctx* ctx, const float* xq, int nq, const float* xb, int nb, int d, int k, float* D, int32_t* I);
 int reid_knn_dev(reid_ctx* ctx, const float* d_xq, int nq, const float* d_xb, int nb, int d, int k,
                  float* d_D, int32_t* d_I);
+/* k-reciprocal Jaccard re-ranking, compute_jaccard_distance reid/faiss_utils.py:147-244: x fp32[n][d] L2-normalised rows,
+ * rank int32[n][k1] neighbour lists or NULL (then reid_knn supplies them, self included), out fp32[n][n].
+ * 1 <= k1 <= 64, k1 <= n, k2 >= 1 (k2 == 1 skips the local query expansion, as in the reference). */
+int reid_rerank_jaccard(reid_ctx* ctx, const float* x, int n, int d, int k1, int k2, const int32_t* rank, float* out_nn);
+int reid_rerank_jaccard_dev(reid_ctx* ctx, const float* d_x, int n, int d, int k1, int k2, const int32_t* d_rank,
+                            float* d_out_nn);
 /* DIoU of one tlwh box against m candidates, fp64, bit-exact with numpy   modification_deepsort/iou_matching.py:5-47 */
 int reid_diou(reid_ctx* ctx, const double* box4, const double* cand_m4, int m, double* out_m);
 /* cost[t][m] = 1 - DIoU(tracks[t], dets[m])   ([external] deep_sort iou_cost loop over iou()) */

@@ -250,6 +250,48 @@ def gen_swin():
     print("swin emb", emb.shape, "absmean taps", {k: round(float(out["absmean_" + k]), 3) for k in taps})
 
 
+def gen_rerank():
+    """k-reciprocal Jaccard re-ranking (reid/faiss_utils.py:147-244) run from the reference's own function.
+
+    faiss (faiss-gpu 1.7.4) is absent: a stand-in module exposes only what `search_option=3` touches -
+    `get_num_gpus()` and an `IndexFlatL2` doing brute-force squared-L2 search in numpy (ties by index: faiss's own tie
+    order is unpinned).  Everything after the k-NN is the reference's code, unmodified.
+    """
+    from reid_amd import synth
+
+    class _IndexFlatL2:
+        def __init__(self, d):
+            self.d, self.xb = d, np.zeros((0, d), np.float32)
+
+        def add(self, x):
+            self.xb = np.concatenate([self.xb, np.asarray(x, np.float32)], 0)
+
+        def search(self, x, k):
+            x = np.asarray(x, np.float32)
+            dist = (x * x).sum(1)[:, None] + (self.xb * self.xb).sum(1)[None, :] - 2.0 * (x @ self.xb.T)
+            idx = np.argsort(dist, axis=1, kind="stable")[:, :k]
+            return np.take_along_axis(dist, idx, 1), idx.astype(np.int64)
+
+    fs = types.ModuleType("faiss")
+    fs.get_num_gpus = lambda: 0
+    fs.METRIC_L2 = 1   # default-argument value at faiss_utils.py:57, never used on this path
+    fs.IndexFlatL2 = _IndexFlatL2
+    sys.modules["faiss"] = fs
+    from reid.faiss_utils import compute_jaccard_distance
+
+    out = {}
+    for tag, n, d, ids, k1, k2, seed in (("a", 240, 48, 12, 20, 6, 21), ("b", 150, 32, 9, 7, 1, 22), ("c", 96, 16, 6, 5, 3, 23)):
+        _, _, _, gf, gl, _ = synth.clustered_embeddings(1, n, d=d, n_ids=ids, n_cams=2, seed=seed, sigma=0.6)
+        idx = _IndexFlatL2(d)
+        idx.add(gf)
+        _, rank = idx.search(gf, k1)
+        jac = compute_jaccard_distance(torch.from_numpy(gf), k1=k1, k2=k2, print_flag=False, search_option=3)
+        out.update({f"{tag}_x": gf, f"{tag}_rank": rank.astype(np.int32), f"{tag}_k": np.asarray([k1, k2]),
+                    f"{tag}_jaccard": jac.astype(np.float32)})
+        print("rerank", tag, n, d, "k1/k2", k1, k2, "mean jaccard", float(jac.mean()), "zeros", int((jac == 0).sum()))
+    np.savez_compressed(os.path.join(OUT, "rerank.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -259,3 +301,4 @@ if __name__ == "__main__":
     gen_factory()
     gen_seres18()
     gen_swin()
+    gen_rerank()

@@ -52,6 +52,8 @@ _SIGS = {
     "reid_argmin_rows_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "reid_knn": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "reid_knn_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "reid_rerank_jaccard": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "reid_rerank_jaccard_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "reid_diou": (_i, [_vp, _vp, _vp, _i, _vp]),
     "reid_diou_cost": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "reid_rank_eval": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

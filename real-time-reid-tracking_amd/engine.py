@@ -213,6 +213,27 @@ class Engine:
         check(self.lib.reid_knn(self.h, _ptr(xq), xq.shape[0], _ptr(xb), xb.shape[0], xq.shape[1], int(k), _ptr(D), _ptr(I)))
         return D, I
 
+    def knn_dev(self, d_xq, nq, d_xb, nb, d, k, d_D, d_I):
+        check(self.lib.reid_knn_dev(self.h, C.c_void_p(d_xq), int(nq), C.c_void_p(d_xb), int(nb), int(d), int(k),
+                                    C.c_void_p(d_D), C.c_void_p(d_I)))
+
+    def rerank_jaccard(self, x, k1=20, k2=6, rank=None):
+        """float32 [n, n] k-reciprocal Jaccard distance (reid/faiss_utils.py:147-244); rank: optional int32 [n, k1]."""
+        x = _f32(x)
+        n, d = x.shape
+        out = np.empty((n, n), np.float32)
+        if rank is not None:
+            rank = np.ascontiguousarray(rank, dtype=np.int32)
+            if rank.shape != (n, int(k1)):
+                raise ValueError(f"rank must be [{n}, {k1}], got {rank.shape}")
+        check(self.lib.reid_rerank_jaccard(self.h, _ptr(x), n, d, int(k1), int(k2), _ptr(rank) if rank is not None else None,
+                                           _ptr(out)))
+        return out
+
+    def rerank_jaccard_dev(self, d_x, n, d, k1, k2, d_out, d_rank=None):
+        check(self.lib.reid_rerank_jaccard_dev(self.h, C.c_void_p(d_x), int(n), int(d), int(k1), int(k2),
+                                               C.c_void_p(d_rank or 0), C.c_void_p(d_out)))
+
     def diou(self, bbox, candidates):
         b = np.ascontiguousarray(bbox, dtype=np.float64).reshape(4)
         c = np.ascontiguousarray(candidates, dtype=np.float64).reshape(-1, 4)

@@ -295,3 +295,45 @@ def test_swin_backbone_object(eng):
     assert isinstance(out, torch.Tensor) and tuple(out.shape) == (3, 96)
     ref, _ = swin.forward(synth.swin_state_dict(0), x)
     assert np.abs(out.numpy() - ref.numpy()).max() / np.abs(ref.numpy()).max() < 2e-4
+
+
+# ----------------------------------------------------------------------------- k-reciprocal re-ranking
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_rerank_jaccard_matches_reference_fixture(eng, golden_dir, tag):
+    """reid_rerank_jaccard against the reference's own compute_jaccard_distance output (tests/golden/rerank.npz), once
+    from the reference's neighbour lists and once from the library's own k-NN."""
+    z = np.load(os.path.join(golden_dir, "rerank.npz"))
+    x, k1, k2 = z[f"{tag}_x"], int(z[f"{tag}_k"][0]), int(z[f"{tag}_k"][1])
+    want = z[f"{tag}_jaccard"]
+    got = eng.rerank_jaccard(x, k1, k2, rank=z[f"{tag}_rank"])
+    # fp32 sums in a different order (softmax denominator, LDS-atomic min-sums): a few ulp of values in [0, 1]
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6)
+    _, knn_i = eng.knn(x, x, k1)
+    assert np.array_equal(knn_i, z[f"{tag}_rank"])          # no near-ties in these fixtures
+    got2 = eng.rerank_jaccard(x, k1, k2)
+    np.testing.assert_allclose(got2, want, rtol=0, atol=3e-6)
+    assert (got >= 0).all() and (got <= 1).all()
+
+
+def test_rerank_jaccard_oracle_sizes_and_host_mirror(eng):
+    """Larger N (persistent blocks loop, several rows per block), D = 1263 as the reference's descriptor, default k1/k2,
+    through the host mirror of reid/faiss_utils.py; checked against the oracle from the same neighbour lists."""
+    from oracle import rerank
+    from reid_amd import faiss_utils
+    _, _, _, x, _, _ = synth.clustered_embeddings(1, 1500, d=1263, n_ids=40, n_cams=2, seed=31, sigma=0.8)
+    _, rank = eng.knn(x, x, 20)
+    got = faiss_utils.compute_jaccard_distance(torch.from_numpy(x), print_flag=False, initial_rank=rank)
+    want = rerank.compute_jaccard_distance(x, 20, 6, initial_rank=rank)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6)
+    # properties: zero (up to rounding) on the diagonal of points that are their own nearest neighbour
+    own = rank[:, 0] == np.arange(len(x))
+    assert own.mean() > 0.99
+    assert np.abs(np.diag(got)[own]).max() < 1e-5
+
+
+def test_rerank_jaccard_argument_errors(eng):
+    x = np.zeros((8, 4), np.float32)
+    with pytest.raises(_ffi.ReidHipError):
+        eng.rerank_jaccard(x, k1=9, k2=2)      # k1 > n
+    with pytest.raises(_ffi.ReidHipError):
+        eng.rerank_jaccard(x, k1=65, k2=2)     # k1 > 64

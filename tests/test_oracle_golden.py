@@ -120,3 +120,28 @@ def test_swin_oracle_matches_reference(golden_dir):
     # masks of the shifted blocks as emitted by synth == the reference's create_mask (loaded strict=True in gen_golden)
     m = sd["stage1.layers.0.1.attention_block.fn.fn.upper_lower_mask"]
     assert np.isinf(m[0, 48]) and m[0, 27] == 0 and np.isinf(m[48, 0]) and m[48, 28] == 0
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_rerank_oracle_matches_reference(golden_dir, tag):
+    """oracle/rerank.py against the reference's compute_jaccard_distance (faiss_utils.py:147-244) run with a numpy
+    stand-in for faiss.IndexFlatL2 (oracle/gen_golden.py:gen_rerank).  k1/k2 = 20/6, 7/1 (no query expansion), 5/3."""
+    from oracle import rerank
+    z = np.load(os.path.join(golden_dir, "rerank.npz"))
+    x, k1, k2 = z[f"{tag}_x"], int(z[f"{tag}_k"][0]), int(z[f"{tag}_k"][1])
+    rank = rerank.knn_l2sqr(x, k1)
+    assert np.array_equal(rank, z[f"{tag}_rank"])
+    got = rerank.compute_jaccard_distance(x, k1, k2)
+    # identical integer steps; the softmax is torch's in the reference and numpy's here
+    np.testing.assert_allclose(got, z[f"{tag}_jaccard"], rtol=0, atol=2e-6)
+
+
+def test_rerank_reciprocal_sets_hand_case():
+    """k_reciprocal_neigh on a 4-point line: 0 and 1 are mutual nearest neighbours, 3 is nobody's."""
+    from oracle import rerank
+    x = np.asarray([[0.0], [1.0], [2.2], [10.0]], np.float32)
+    rank = rerank.knn_l2sqr(x, 2)
+    assert rank.tolist() == [[0, 1], [1, 0], [2, 1], [3, 2]]
+    assert rerank.k_reciprocal_neigh(rank, 0, 2).tolist() == [0, 1]
+    assert rerank.k_reciprocal_neigh(rank, 2, 2).tolist() == [2]      # 1 does not list 2
+    assert rerank.k_reciprocal_neigh(rank, 3, 2).tolist() == [3]
