@@ -144,6 +144,27 @@ int reid_rerank_jaccard_dev(reid_ctx* ctx, const float* d_x, int n, int d, int k
 int reid_diou(reid_ctx* ctx, const double* box4, const double* cand_m4, int m, double* out_m);
 /* cost[t][m] = 1 - DIoU(tracks[t], dets[m])   ([external] deep_sort iou_cost loop over iou()) */
 int reid_diou_cost(reid_ctx* ctx, const double* tracks_t4, int t, const double* dets_m4, int m, double* out_tm);
+/* ---- DeepSORT appearance metric with the feature bank on the device ---------------------------
+ * [external] deep_sort/sort/nn_matching.py NearestNeighborDistanceMetric (the per-frame consumer of Extractor.__call__;
+ * MAX_DIST / NN_BUDGET from modification_deepsort/deep_sort.yaml:3,9).  A bank holds, per track slot, the last `budget`
+ * d-dimensional features in HBM; the caller maps track ids to slots 0..max_tracks-1. */
+typedef struct reid_bank reid_bank;
+int reid_bank_create(reid_ctx* ctx, int max_tracks, int budget, int d, reid_bank** out);
+int reid_bank_destroy(reid_bank* bank);
+/* partial_fit: row i of feats[n][d] is appended to track slots[i], in call order (oldest samples fall out of the ring) */
+int reid_bank_update(reid_ctx* ctx, reid_bank* bank, const float* feats, const int32_t* slots, int n);
+int reid_bank_update_dev(reid_ctx* ctx, reid_bank* bank, const float* d_feats, const int32_t* slots, int n);
+/* forget tracks (targets missing from active_targets) so their slots can be reused */
+int reid_bank_clear(reid_ctx* ctx, reid_bank* bank, const int32_t* slots, int n);
+/* samples currently held for a slot (<= budget) */
+int reid_bank_count(reid_bank* bank, int slot, int* out);
+/* distance(): cost[t][m] = min over the samples of track slots[t] of metric(sample, dets[m]); metric REID_METRIC_COS
+ * (_nn_cosine_distance) or REID_METRIC_L2SQR (_nn_euclidean_distance).  max_dist >= 0 also applies
+ * linear_assignment.min_cost_matching's gate: cost > max_dist -> max_dist + 1e-5.  slots is a host array. */
+int reid_bank_cost(reid_ctx* ctx, reid_bank* bank, const int32_t* slots, int t, const float* dets, int m, int metric,
+                   float max_dist, float* out_tm);
+int reid_bank_cost_dev(reid_ctx* ctx, reid_bank* bank, const int32_t* slots, int t, const float* d_dets, int m, int metric,
+                       float max_dist, float* d_out_tm);
 /* retrieval evaluation, reid/evaluate.py:33-105: for every query the ranks of its good gallery items among
  * non-junk items (descending similarity gf@q).  cmc_sum int32[ng] = sum over valid queries of the CMC step,
  * ap double[nq], valid int32[nq] (0 when the query has no good item). */

@@ -52,6 +52,14 @@ _SIGS = {
     "reid_argmin_rows_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "reid_knn": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "reid_knn_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "reid_bank_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
+    "reid_bank_destroy": (_i, [_vp]),
+    "reid_bank_update": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "reid_bank_update_dev": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "reid_bank_clear": (_i, [_vp, _vp, _vp, _i]),
+    "reid_bank_count": (_i, [_vp, _i, C.POINTER(_i)]),
+    "reid_bank_cost": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, C.c_float, _vp]),
+    "reid_bank_cost_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, C.c_float, _vp]),
     "reid_rerank_jaccard": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "reid_rerank_jaccard_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "reid_diou": (_i, [_vp, _vp, _vp, _i, _vp]),

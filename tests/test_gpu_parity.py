@@ -337,3 +337,71 @@ def test_rerank_jaccard_argument_errors(eng):
         eng.rerank_jaccard(x, k1=9, k2=2)      # k1 > n
     with pytest.raises(_ffi.ReidHipError):
         eng.rerank_jaccard(x, k1=65, k2=2)     # k1 > 64
+
+
+# ----------------------------------------------------------------------------- DeepSORT feature bank
+@pytest.mark.parametrize("metric", ["cosine", "euclidean"])
+def test_nn_matching_bank_follows_oracle_over_a_stream(eng, metric):
+    """A 40-frame synthetic stream: tracks are born, updated (several samples per call, more than the budget over time)
+    and dropped; after every frame the device cost matrix equals the oracle's, raw and gated."""
+    from oracle import nn_matching as onm
+    from reid_amd.nn_matching import NearestNeighborDistanceMetric
+    rng = np.random.default_rng(5)
+    d, budget = 512, 7
+    ref = onm.NearestNeighborDistanceMetric(metric, 0.15, budget)
+    dev = NearestNeighborDistanceMetric(metric, 0.15, budget, max_tracks=48)
+    alive, next_id = [], 0
+    for frame in range(40):
+        for _ in range(rng.integers(0, 3)):                      # births
+            alive.append(next_id)
+            next_id += 1
+        if alive and rng.random() < 0.6:                         # a death (its slot is reused later)
+            alive.pop(rng.integers(len(alive)))
+        feats, targets = [], []
+        for t in alive:
+            # 0..2 new samples per track per frame; a new track always brings one (DeepSORT only lists confirmed tracks,
+            # which hold features - an active target without samples is a KeyError in the reference too)
+            for _ in range(max(int(rng.integers(0, 3)), 0 if t in ref.samples else 1)):
+                feats.append(rng.normal(0, 1, d).astype(np.float32) + 3.0 * np.sin(t + np.arange(d, dtype=np.float32)))
+                targets.append(t)
+        ref.partial_fit(feats, targets, alive)
+        dev.partial_fit(np.stack(feats) if feats else np.zeros((0, d), np.float32), targets, alive)
+        known = [t for t in alive if t in ref.samples]
+        assert sorted(known) == sorted(dev.targets) or set(known) <= set(dev.targets)
+        for t in known:
+            assert dev.samples_count(t) == len(ref.samples[t])
+        m = int(rng.integers(1, 40))
+        dets = rng.normal(0, 1, (m, d)).astype(np.float32) + 3.0 * np.sin(rng.integers(0, 12, (m, 1)) + np.arange(d, dtype=np.float32))
+        if not known:
+            continue
+        want = ref.distance(dets, known)
+        got = dev.distance(dets, known)
+        tol = 2e-6 if metric == "cosine" else 2e-6 * float(np.abs(want).max() + 1)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=tol)
+        thr = 0.15 if metric == "cosine" else float(np.median(want))
+        gated = dev.distance(dets, known, max_distance=thr)
+        far = want > thr + 10 * tol
+        near = want < thr - 10 * tol
+        np.testing.assert_allclose(gated[far], np.float32(thr) + np.float32(1e-5), rtol=1e-6)
+        np.testing.assert_allclose(gated[near], want[near], rtol=1e-5, atol=tol)
+
+
+def test_nn_matching_edge_cases(eng):
+    from reid_amd.nn_matching import NearestNeighborDistanceMetric
+    m = NearestNeighborDistanceMetric("cosine", 0.15, budget=3, max_tracks=2)
+    e = np.eye(8, dtype=np.float32)
+    m.partial_fit(e[:5], [1, 1, 1, 1, 1], [1])                   # five samples in one call, budget 3: e2, e3, e4 stay
+    assert m.samples_count(1) == 3
+    np.testing.assert_allclose(m.distance(e[:6], [1])[0], [1, 1, 0, 0, 0, 1], atol=1e-6)
+    assert m.distance(np.zeros((0, 8), np.float32), [1]).shape == (1, 0)
+    assert m.distance(e[:2], []).shape == (0, 2)
+    with pytest.raises(KeyError):
+        m.distance(e[:2], [99])
+    m.partial_fit(e[:1], [2], [1, 2])
+    with pytest.raises(RuntimeError):
+        m.partial_fit(e[:1], [3], [1, 2, 3])                     # bank of two tracks is full
+    m.partial_fit(np.zeros((0, 8), np.float32), [], [2])         # 1 dropped -> slot reusable
+    m.partial_fit(e[5:6], [3], [2, 3])
+    np.testing.assert_allclose(m.distance(e[5:6], [3, 2]), [[0.0], [1.0]], atol=1e-6)
+    with pytest.raises(ValueError):
+        NearestNeighborDistanceMetric("manhattan", 0.1)

@@ -173,3 +173,21 @@ def test_build_model_swin_registry():
     from reid_amd import models
     m = models.build_model("swin_transformer", num_classes=751, loss="triplet", pretrained=False, use_gpu=True)
     assert m.embed_dim == 96 and len(m.state_dict()) == len(synth.swin_state_dict(0))
+
+
+def test_nn_matching_oracle_known_answers():
+    """oracle/nn_matching.py (DeepSORT's published nn_matching, parity unpinned): hand-checked cosine / euclidean
+    nearest-sample costs, budget truncation and the min_cost_matching gate."""
+    from oracle import nn_matching as nm
+    m = nm.NearestNeighborDistanceMetric("cosine", 0.15, budget=2)
+    e = np.eye(4, dtype=np.float32)
+    m.partial_fit([e[0], e[1], e[2]], [7, 7, 7], [7])          # budget 2 keeps e1, e2
+    cost = m.distance(np.stack([e[0], e[1], (e[1] + e[2]) / np.sqrt(2)]).astype(np.float32), [7])
+    np.testing.assert_allclose(cost[0], [1.0, 0.0, 1 - 1 / np.sqrt(2)], atol=1e-6)
+    np.testing.assert_allclose(nm.gate(cost, 0.15)[0], [0.15 + 1e-5, 0.0, 0.15 + 1e-5])
+    m2 = nm.NearestNeighborDistanceMetric("euclidean", 1.0)
+    m2.partial_fit([e[0] * 2, e[1]], [1, 2], [1, 2])
+    np.testing.assert_allclose(m2.distance(e[:2], [1, 2]), [[1.0, 5.0], [2.0, 0.0]], atol=1e-6)
+    m2.partial_fit([], [], [2])                                 # target 1 is dropped
+    with pytest.raises(KeyError):
+        m2.distance(e[:1], [1])
