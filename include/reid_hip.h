@@ -102,6 +102,11 @@ int reid_embed_u8_dev(reid_ctx* ctx, const uint8_t* d_crops_nhwc, int n, float* 
  * packed = concatenated HxWx3 uint8 images, offsets[i] = byte offset of crop i, hw[2i],hw[2i+1] = its height,width */
 int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
                          float* emb, float* logits);
+/* crops as windows frame[y1:y2, x1:x2] of ONE uint8 HxWx3 frame (what DeepSort._get_features slices before calling the
+ * Extractor): the frame is uploaded once and each window is resized on the device.  boxes_xyxy int32[n][4], inside the
+ * frame and non-empty (an empty slice fails in the reference's cv2.resize as well). */
+int reid_embed_frame_u8(reid_ctx* ctx, const uint8_t* frame_hwc, int fh, int fw, const int32_t* boxes_xyxy, int n,
+                        float* emb, float* logits);
 /* normalised float images, fp32[n][3][256][128] NCHW: the model(im_batch) call of the plugin surface
  * (modification_tracking/models/__init__.py:93-121 returned object) */
 int reid_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, float* emb, float* logits);

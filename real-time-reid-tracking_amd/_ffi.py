@@ -38,6 +38,7 @@ _SIGS = {
     "reid_embed_u8": (_i, [_vp, _vp, _i, _vp, _vp]),
     "reid_embed_u8_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
     "reid_embed_ragged_u8": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "reid_embed_frame_u8": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "reid_embed_f32_nchw": (_i, [_vp, _vp, _i, _vp, _vp]),
     "reid_embed_f32_nchw_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
     "reid_swin_load": (_i, [_vp, _vp, _sz, C.c_char_p]),

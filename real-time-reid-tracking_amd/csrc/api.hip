@@ -700,7 +700,52 @@ extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const 
         const int m = n - i < ctx->chunk ? n - i : ctx->chunk;
         float* nhwc;
         REID_TRY(ctx_ws(ctx, "se18.in_nhwc", (size_t)m * img * 4, (void**)&nhwc));
-        REID_TRY(launch_resize_norm(ctx, d_pk, d_off + i, d_hw + 2 * i, m, IMG_H, IMG_W, nhwc));
+        REID_TRY(launch_resize_norm(ctx, d_pk, d_off + i, d_hw + 2 * i, m, IMG_H, IMG_W, 0, nhwc));
+        REID_TRY(seres18_run(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_log ? d_log + (size_t)i * nc : nullptr));
+    }
+    HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+// Crops given as windows of ONE frame: DeepSort._get_features ([external] deep_sort.py) slices ori_img[y1:y2, x1:x2] per box
+// on the host and Extractor._preprocess (feature_extractor.py:31-46) resizes each slice with cv2; here the frame is uploaded
+// once and every window is resized straight out of it on the device (same bilinear taps, clamped to the WINDOW's border).
+extern "C" int reid_embed_frame_u8(reid_ctx* ctx, const uint8_t* frame, int fh, int fw, const int32_t* boxes_xyxy, int n,
+                                   float* emb, float* logits) {
+    ARG_CHECK(ctx && frame && boxes_xyxy && emb && fh >= 1 && fw >= 1 && n >= 0);
+    if (n == 0) return REID_OK;
+    const int nc = ctx->se18.num_class;
+    std::vector<long long> off(n);
+    std::vector<int> hw(2 * n);
+    for (int i = 0; i < n; ++i) {
+        const int x1 = boxes_xyxy[4 * i], y1 = boxes_xyxy[4 * i + 1], x2 = boxes_xyxy[4 * i + 2], y2 = boxes_xyxy[4 * i + 3];
+        ARG_CHECK(x1 >= 0 && y1 >= 0 && x2 <= fw && y2 <= fh && x2 > x1 && y2 > y1);   // an empty slice fails in cv2.resize too
+        off[i] = ((long long)y1 * fw + x1) * 3;
+        hw[2 * i] = y2 - y1;
+        hw[2 * i + 1] = x2 - x1;
+    }
+    uint8_t* d_fr;
+    long long* d_off;
+    int* d_hw;
+    float *d_emb, *d_log = nullptr;
+    const size_t total = (size_t)fh * fw * 3;
+    REID_TRY(ctx_ws(ctx, "io.in", total, (void**)&d_fr));
+    REID_TRY(ctx_ws(ctx, "io.off", (size_t)n * 8, (void**)&d_off));
+    REID_TRY(ctx_ws(ctx, "io.hw", (size_t)n * 8, (void**)&d_hw));
+    REID_TRY(ctx_ws(ctx, "io.emb", (size_t)n * 512 * 4, (void**)&d_emb));
+    if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
+    HIP_TRY(hipMemcpyAsync(d_fr, frame, total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_off, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_hw, hw.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // off / hw are locals
+    const size_t img = (size_t)IMG_H * IMG_W * 3;
+    for (int i = 0; i < n; i += ctx->chunk) {
+        const int m = n - i < ctx->chunk ? n - i : ctx->chunk;
+        float* nhwc;
+        REID_TRY(ctx_ws(ctx, "se18.in_nhwc", (size_t)m * img * 4, (void**)&nhwc));
+        REID_TRY(launch_resize_norm(ctx, d_fr, d_off + i, d_hw + 2 * i, m, IMG_H, IMG_W, fw, nhwc));
         REID_TRY(seres18_run(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_log ? d_log + (size_t)i * nc : nullptr));
     }
     HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -44,8 +44,9 @@ __device__ __forceinline__ void lin_tap(int d, int dst, int src, int& s, float& 
     s = sx;
     f = fx;
 }
+// pitch: source row length in pixels (0: the crop's own width, packed crops; frame width when the crops are windows of a frame)
 __global__ void resize_norm_kernel(const uint8_t* __restrict__ packed, const long long* __restrict__ offsets,
-                                   const int* __restrict__ hw, int n, int H, int W, float* __restrict__ out) {
+                                   const int* __restrict__ hw, int n, int H, int W, int pitch, float* __restrict__ out) {
     const long long total = (long long)n * H * W;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int img = (int)(i / (H * W));
@@ -53,6 +54,7 @@ __global__ void resize_norm_kernel(const uint8_t* __restrict__ packed, const lon
         const int dy = rem / W, dx = rem - dy * W;
         const int h = hw[2 * img], w = hw[2 * img + 1];
         const uint8_t* src = packed + offsets[img];
+        const long long ps = pitch ? pitch : w;
         int sx, sy;
         float fx, fy;
         lin_tap(dx, W, w, sx, fx);
@@ -61,10 +63,10 @@ __global__ void resize_norm_kernel(const uint8_t* __restrict__ packed, const lon
         const float gx = __fsub_rn(1.0f, fx), gy = __fsub_rn(1.0f, fy);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float p00 = (float)src[((long long)sy * w + sx) * 3 + c] / 255.0f;
-            const float p01 = (float)src[((long long)sy * w + sx1) * 3 + c] / 255.0f;
-            const float p10 = (float)src[((long long)sy1 * w + sx) * 3 + c] / 255.0f;
-            const float p11 = (float)src[((long long)sy1 * w + sx1) * 3 + c] / 255.0f;
+            const float p00 = (float)src[(sy * ps + sx) * 3 + c] / 255.0f;
+            const float p01 = (float)src[(sy * ps + sx1) * 3 + c] / 255.0f;
+            const float p10 = (float)src[(sy1 * ps + sx) * 3 + c] / 255.0f;
+            const float p11 = (float)src[(sy1 * ps + sx1) * 3 + c] / 255.0f;
             const float r0 = __fadd_rn(__fmul_rn(p00, gx), __fmul_rn(p01, fx));
             const float r1 = __fadd_rn(__fmul_rn(p10, gx), __fmul_rn(p11, fx));
             const float v = __fadd_rn(__fmul_rn(r0, gy), __fmul_rn(r1, fy));
@@ -225,11 +227,11 @@ int launch_nchw_to_nhwc3(reid_ctx* ctx, const float* x, int n, int h, int w, flo
 }
 
 int launch_resize_norm(reid_ctx* ctx, const uint8_t* packed, const long long* offsets, const int* hw, int n, int H, int W,
-                       float* out) {
+                       int pitch, float* out) {
     const long long total = (long long)n * H * W;
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, total * 15.0);
     hipLaunchKernelGGL(resize_norm_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, packed, offsets, hw, n,
-                       H, W, out);
+                       H, W, pitch, out);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

@@ -120,7 +120,7 @@ int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int 
 // elementwise / reduction kernels (elementwise.hip)
 int launch_nchw_to_nhwc3(reid_ctx*, const float* x_nchw, int n, int h, int w, float* out_nhwc);
 int launch_resize_norm(reid_ctx*, const uint8_t* packed, const long long* offsets, const int* hw, int n, int H, int W,
-                       float* out_nhwc);
+                       int pitch, float* out_nhwc);
 int launch_maxpool3s2(reid_ctx*, const float* x, int n, int h, int w, int c, float* out);
 int launch_norm_finalize(reid_ctx*, const float* stats, int n_img, int tiles, int c, int half, int hw,
                          const float* in_gamma, const float* in_beta, const float* bn_scale, const float* bn_shift,

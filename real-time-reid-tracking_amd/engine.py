@@ -158,6 +158,18 @@ class Engine:
         check(self.lib.reid_embed_ragged_u8(self.h, _ptr(packed), _ptr(offs), _ptr(hw), n, _ptr(emb), _ptr(lg)))
         return (emb, lg) if logits else emb
 
+    def embed_frame_u8(self, frame, boxes_xyxy, logits=False):
+        """uint8[H,W,3] frame + int boxes [n,4] (x1,y1,x2,y2; crop = frame[y1:y2, x1:x2]) -> float32[n,512]."""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        if frame.ndim != 3 or frame.shape[2] != 3:
+            raise ValueError("frame must be uint8[H,W,3], got %s" % (frame.shape,))
+        boxes = np.ascontiguousarray(boxes_xyxy, dtype=np.int32).reshape(-1, 4)
+        n = boxes.shape[0]
+        emb, lg = self._outs(n, logits)
+        check(self.lib.reid_embed_frame_u8(self.h, _ptr(frame), frame.shape[0], frame.shape[1], _ptr(boxes), n, _ptr(emb),
+                                           _ptr(lg)))
+        return (emb, lg) if logits else emb
+
     def embed_f32_nchw(self, x, logits=False):
         x = _f32(x)
         if x.ndim != 4 or x.shape[1:] != (3, IMG_H, IMG_W):

@@ -46,9 +46,28 @@ class Extractor(object):
             raise RuntimeError("Extractor: expected a non-empty list of crops")   # torch.cat([]) raises, :44
         return [np.asarray(im) for im in im_crops]
 
-    def __call__(self, im_crops):
-        crops = self._preprocess(im_crops)
+    def _bind(self):
         if getattr(self.net, "_owner", None) is not self:      # another model was loaded on this device meanwhile
             self.net.load_seres18(*self._packed)
             self.net._owner = self
+
+    def __call__(self, im_crops):
+        crops = self._preprocess(im_crops)
+        self._bind()
         return self.net.embed_ragged_u8(crops)
+
+    def from_frame(self, bbox_xywh, ori_img):
+        """DeepSort._get_features(bbox_xywh, ori_img) ([external] deep_sort.py) in one call: centre-format boxes are
+        converted and clipped like DeepSort._xywh_to_xyxy (x1 = max(int(x - w/2), 0), x2 = min(int(x + w/2), W - 1), ...),
+        the frame goes to the device once and the windows are cut and resized there.  Returns float32 [N, 512]
+        (an empty array when there is no box, as the reference's `np.array([])` branch)."""
+        ori_img = np.asarray(ori_img)
+        boxes = np.asarray(bbox_xywh, dtype=np.float64).reshape(-1, 4)
+        if boxes.shape[0] == 0:
+            return np.array([])
+        height, width = ori_img.shape[:2]
+        xyxy = np.empty((boxes.shape[0], 4), np.int32)
+        for i, (x, y, w, h) in enumerate(boxes):
+            xyxy[i] = (max(int(x - w / 2), 0), max(int(y - h / 2), 0), min(int(x + w / 2), width - 1), min(int(y + h / 2), height - 1))
+        self._bind()
+        return self.net.embed_frame_u8(ori_img, xyxy)

@@ -405,3 +405,31 @@ def test_nn_matching_edge_cases(eng):
     np.testing.assert_allclose(m.distance(e[5:6], [3, 2]), [[0.0], [1.0]], atol=1e-6)
     with pytest.raises(ValueError):
         NearestNeighborDistanceMetric("manhattan", 0.1)
+
+
+# ----------------------------------------------------------------------------- crops cut from a frame on the device (§8f-3)
+def test_embed_from_frame_equals_host_sliced_crops(eng_w0):
+    """Extractor.from_frame(bbox_xywh, frame) == Extractor([frame[y1:y2, x1:x2] ...]) bit for bit (same taps, the frame is
+    only indexed with a pitch), incl. boxes touching the frame border and a 3-pixel-wide window.  The host-sliced path is
+    itself checked against the oracle's resize in test_ragged_crops_resize_on_device."""
+    from reid_amd.extractor import Extractor
+    eng, sd = eng_w0
+    ext = Extractor(sd)
+    rng = np.random.default_rng(9)
+    frame = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    xywh = np.asarray([[100.4, 200.2, 60.0, 150.9], [5.0, 10.0, 40.0, 60.0], [630.0, 470.0, 50.0, 80.0], [320.0, 240.0, 2.2, 300.0],
+                       [320.5, 240.5, 128.0, 256.0]])
+    got = ext.from_frame(xywh, frame)
+    crops = []
+    for x, y, w, h in xywh:
+        x1, y1 = max(int(x - w / 2), 0), max(int(y - h / 2), 0)
+        x2, y2 = min(int(x + w / 2), 639), min(int(y + h / 2), 479)
+        crops.append(frame[y1:y2, x1:x2])
+    assert [c.shape[1] for c in crops][3] == 3
+    want = ext(crops)
+    assert np.array_equal(got, want)
+    assert ext.from_frame(np.zeros((0, 4)), frame).size == 0
+    with pytest.raises(_ffi.ReidHipError):
+        eng.embed_frame_u8(frame, [[10, 10, 10, 50]])        # empty window
+    with pytest.raises(_ffi.ReidHipError):
+        eng.embed_frame_u8(frame, [[0, 0, 641, 50]])         # outside the frame
