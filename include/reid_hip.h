@@ -114,7 +114,9 @@ int reid_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, float* d_emb
 /* intermediate activation of the last embed call, for stage-level parity tests:
  * stage 0 = stem conv+BN [n][128][64][64], 1 = maxpool [n][64][32][64], 2..9 = SE blocks 11..42 (NHWC), 10 = GeM [n][512].
  * Only valid when n <= chunk and after reid_ctx_set_debug_keep(ctx, 1).  Copies up to max_floats and returns the stage's element count in *count. */
-int reid_ctx_set_debug_keep(reid_ctx* ctx, int on);   /* give every stage its own buffer (tests only) */
+int reid_ctx_set_debug_keep(reid_ctx* ctx, int on);   /* tests only: give every stage its own buffer; 1 also splits the
+                                                        * fp16 stem into conv + pool kernels so that stage 0 exists,
+                                                        * 2 keeps the production (fused) kernels: stage 0 is not written */
 int reid_debug_stage(reid_ctx* ctx, int stage, float* out_host, size_t max_floats, size_t* count);
 
 /* ---- Swin-T backbone (reference "v1": reid/backbones/swin_transformer.py:339-427, swin_t :508-513) -------------------

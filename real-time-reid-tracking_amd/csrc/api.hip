@@ -39,6 +39,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
+    if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e) != 0;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipEventCreate(&c->t0));
@@ -56,6 +57,7 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     if (ctx->se18.blob) hipFree(ctx->se18.blob);
     if (ctx->se18.blob16) hipFree(ctx->se18.blob16);
     if (ctx->se18.stem_w16) hipFree(ctx->se18.stem_w16);
+    if (ctx->se18.stem_w16s) hipFree(ctx->se18.stem_w16s);
     if (ctx->se18.zero_page) hipFree(ctx->se18.zero_page);
     for (auto& e : ctx->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& p : ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -96,7 +98,7 @@ extern "C" int reid_ctx_set_precision(reid_ctx* ctx, int mode) {
 
 extern "C" int reid_ctx_set_debug_keep(reid_ctx* ctx, int on) {
     ARG_CHECK(ctx);
-    ctx->debug_keep = on != 0;
+    ctx->debug_keep = on < 0 ? 0 : (on > 2 ? 2 : on);   // 1: every kernel unfused, 2: production kernels, stage 0 not produced
     return REID_OK;
 }
 
@@ -255,6 +257,7 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         HIP_TRY(hipFree(w.blob));
         if (w.blob16) HIP_TRY(hipFree(w.blob16));
         if (w.stem_w16) HIP_TRY(hipFree(w.stem_w16));
+        if (w.stem_w16s) HIP_TRY(hipFree(w.stem_w16s));
         if (w.zero_page) HIP_TRY(hipFree(w.zero_page));
         w = Se18Weights();
     }
@@ -315,10 +318,12 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
     // fp16 copies for the fp16 path: whole blob at the same element offsets + the padded-NHWC4 stem weights
     HIP_TRY(hipMalloc((void**)&w.blob16, n_floats * sizeof(_Float16)));
     HIP_TRY(hipMalloc((void**)&w.stem_w16, 64 * 256 * sizeof(_Float16)));
+    HIP_TRY(hipMalloc((void**)&w.stem_w16s, 64 * 256 * sizeof(_Float16)));
     HIP_TRY(hipMalloc((void**)&w.zero_page, 256));
     HIP_TRY(hipMemsetAsync(w.zero_page, 0, 256, ctx->stream));
     REID_TRY(launch_f32_to_f16(ctx, w.blob, n_floats, w.blob16));
     REID_TRY(launch_stem_w16(ctx, w.stem_w, w.stem_w16));
+    REID_TRY(launch_stem_w16_scaled(ctx, w.stem_w, w.stem_scale, w.stem_w16s));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     w.loaded = true;
     return REID_OK;
@@ -374,7 +379,7 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
     }
     Se18Bufs b;
     const size_t per = 131072;  // largest block tensor per crop (64 x 32 x 64)
-    const bool keep = ctx->debug_keep;
+    const bool keep = ctx->debug_keep != 0;
     REID_TRY(ctx_ws(ctx, "se18.stem", (size_t)n * 524288 * 4, (void**)&b.stem));
     REID_TRY(ctx_ws(ctx, "se18.pool", (size_t)n * per * 4, (void**)&b.pool));
     const int nt = keep ? 1 : 4;
@@ -498,7 +503,7 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
     }
     typedef _Float16 f16;
     const size_t per = 131072;
-    const bool keep = ctx->debug_keep;
+    const bool keep = ctx->debug_keep != 0;
     f16 *pad_in, *stem, *pool, *tbase;
     float *stats, *a_scale, *a_shift, *se, *gem;
     REID_TRY(ctx_ws(ctx, "se18h.pad", (size_t)n * PAD_H * PAD_W * 4 * 2, (void**)&pad_in));
@@ -513,9 +518,14 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
 
     if (is_u8) REID_TRY(launch_prep_u8_pad_f16(ctx, (const uint8_t*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
     else REID_TRY(launch_prep_f32_pad_f16(ctx, (const float*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
-    REID_TRY(conv_gemm16(ctx, A16_STEM, pad_in, n, IMG_H, IMG_W, 4, w.stem_w16, 64, 7, 7, 2, 3, 224, w.stem_scale, w.stem_shift,
-                         nullptr, 0, nullptr, stem, PAD_H, PAD_W));
-    REID_TRY(launch_maxpool3s2_f16(ctx, stem, n, 128, 64, 64, pool));
+    if (ctx->f16_stem_fused && ctx->debug_keep != 1) {   // debug_keep 1 keeps the unfused kernels (stage 0 = conv map)
+        // conv 7x7 s2 + BN + MaxPool(3,2,1) in one kernel: the 1 MiB/crop conv map never reaches HBM (stem_pool_f16.hip)
+        REID_TRY(launch_stem_pool_f16(ctx, pad_in, n, w.stem_w16s, w.stem_shift, pool));
+    } else {
+        REID_TRY(conv_gemm16(ctx, A16_STEM, pad_in, n, IMG_H, IMG_W, 4, w.stem_w16, 64, 7, 7, 2, 3, 224, w.stem_scale,
+                             w.stem_shift, nullptr, 0, nullptr, stem, PAD_H, PAD_W));
+        REID_TRY(launch_maxpool3s2_f16(ctx, stem, n, 128, 64, 64, pool));
+    }
     float* stage[11];
     stage[0] = (float*)stem;
     stage[1] = (float*)pool;

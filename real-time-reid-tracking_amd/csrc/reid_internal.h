@@ -114,6 +114,8 @@ int launch_gem_neck_f16(reid_ctx*, const _Float16* x, int n_img, int hw, int c, 
                         const float* shift, float* gem_out, float* emb);
 int launch_f32_to_f16(reid_ctx*, const float* x, size_t n, _Float16* out);
 int launch_stem_w16(reid_ctx*, const float* stem_w_f32, _Float16* out);
+int launch_stem_w16_scaled(reid_ctx*, const float* stem_w_f32, const float* scale, _Float16* out);
+int launch_stem_pool_f16(reid_ctx*, const _Float16* pad_in, int n, const _Float16* w16s, const float* shift, _Float16* pooled);
 int launch_conv_w16_chunked(reid_ctx*, const float* w_f32, int cout, int rs, int cin, _Float16* out);  // -> [Cout][Cin/64][RS][64]   // [64][8][24] -> [64][8][8][4]
 int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int kind, double flops, double bytes);
 
@@ -161,6 +163,7 @@ struct Se18Weights {
     const float *gem_p, *neck_scale, *neck_shift, *cls_w;
     _Float16* blob16 = nullptr;   // fp16 copy of the whole blob (same element offsets) for the fp16 path
     _Float16* stem_w16 = nullptr; // [64][256] stem weights of the padded-NHWC4 formulation
+    _Float16* stem_w16s = nullptr; // same with the folded BN scale multiplied in (fused stem + maxpool kernel)
     _Float16* zero_page = nullptr;
     const _Float16* h(const float* p) const { return blob16 + (p - blob); }
 };
@@ -181,10 +184,11 @@ struct reid_ctx {
     std::map<std::string, std::pair<void*, size_t>> ws;
     Se18Weights se18;
     int last_n = 0;  // crops in the last embed chunk (for reid_debug_stage)
-    bool debug_keep = false;
+    int debug_keep = 0;      // 0 off, 1 stage buffers + unfused kernels, 2 stage buffers + production kernels
     bool last_f16 = false;
     int f16_loader_waves = 1; // LDS-halo kernel: 8 compute + 4 dedicated loader waves (REID_F16_LOADERS)
     int f16_halo = 1;        // 3x3 stride-1 convs of the fp16 path use the LDS-halo kernel (REID_F16_HALO=0: implicit GEMM)
+    int f16_stem_fused = 1;  // fp16 path: stem conv + BN + maxpool as one kernel (REID_F16_STEMPOOL=0: GEMM + pool kernels)
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
     float* stage_ptr[11] = {nullptr};
 };

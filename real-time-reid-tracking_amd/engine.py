@@ -183,7 +183,7 @@ class Engine:
                                          C.c_void_p(d_logits or 0)))
 
     def debug_keep(self, on):
-        check(self.lib.reid_ctx_set_debug_keep(self.h, int(bool(on))))
+        check(self.lib.reid_ctx_set_debug_keep(self.h, int(on)))
 
     def debug_stage(self, stage, n):
         sizes = [524288, 131072, 131072, 131072, 65536, 65536, 32768, 32768, 65536, 65536, 512]

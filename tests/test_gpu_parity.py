@@ -433,3 +433,44 @@ def test_embed_from_frame_equals_host_sliced_crops(eng_w0):
         eng.embed_frame_u8(frame, [[10, 10, 10, 50]])        # empty window
     with pytest.raises(_ffi.ReidHipError):
         eng.embed_frame_u8(frame, [[0, 0, 641, 50]])         # outside the frame
+
+
+# ----------------------------------------------------------------------------- fused stem + maxpool kernel (fp16 path)
+def test_f16_fused_stem_pool_matches_unfused_and_oracle(eng_w0):
+    """stem_pool_f16.hip (conv 7x7 s2 + BN + MaxPool in one kernel, BN scale folded into the f16 weights) against the
+    unfused GEMM + pool kernels (debug_keep 1) and the oracle's pooled map; every later stage and the embedding too."""
+    eng, sd = eng_w0
+    n = 6
+    crops = synth.smooth_crops_u8(n, 3)
+    crops[0] = 255          # saturated crop: all-equal windows
+    crops[1, :, :3] = 0     # a dark left border exercises the -1 column clipping
+    eng.set_precision(1)
+    try:
+        eng.debug_keep(1)
+        emb_u = eng.embed_u8(crops)
+        pool_u = eng.debug_stage(1, n)
+        eng.debug_keep(2)
+        emb_f = eng.embed_u8(crops)
+        pool_f = eng.debug_stage(1, n)
+        last_f = eng.debug_stage(9, n)
+    finally:
+        eng.debug_keep(0)
+        eng.set_precision(0)
+    taps = {}
+    seres18.forward(sd, seres18.preprocess_u8(crops), taps)
+    want = taps["pool0"].permute(0, 2, 3, 1).contiguous().numpy().reshape(-1)
+    scale = np.abs(want).max()
+    assert np.abs(pool_f - want).max() / scale < 4e-3        # f16 weights/activations, fp32 accumulate
+    assert np.abs(pool_u - want).max() / scale < 4e-3
+    assert np.abs(pool_f - pool_u).max() / scale < 4e-3      # scale folded before vs after the f16 rounding
+    want9 = taps[synth.SERES18_BLOCKS[-1][0]].permute(0, 2, 3, 1).contiguous().numpy().reshape(-1)
+    assert np.abs(last_f - want9).max() / np.abs(want9).max() < 1e-2
+    cos = (emb_f * emb_u).sum(1) / np.linalg.norm(emb_f, axis=1) / np.linalg.norm(emb_u, axis=1)
+    assert (1 - cos).max() < 2e-5
+    emb_nk = None
+    eng.set_precision(1)
+    try:
+        emb_nk = eng.embed_u8(crops)                         # production call (no debug buffers): same kernels as keep 2
+    finally:
+        eng.set_precision(0)
+    assert np.array_equal(emb_nk, emb_f)
