@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--crops", type=int, default=4096, help="crops per GPU per step (BASELINE config 2: 4096)")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "512")))
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "1024")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--single", action="store_true", help="measure only --precision (skip the other arithmetic)")
     ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f16"),

@@ -40,6 +40,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
     if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e) != 0;
+    if (const char* e = getenv("REID_F16_C64")) c->f16_c64 = atoi(e) != 0;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipEventCreate(&c->t0));
@@ -58,6 +59,8 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     if (ctx->se18.blob16) hipFree(ctx->se18.blob16);
     if (ctx->se18.stem_w16) hipFree(ctx->se18.stem_w16);
     if (ctx->se18.stem_w16s) hipFree(ctx->se18.stem_w16s);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->se18.l1_conv2_w16s[i]) hipFree(ctx->se18.l1_conv2_w16s[i]);
     if (ctx->se18.zero_page) hipFree(ctx->se18.zero_page);
     for (auto& e : ctx->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& p : ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -258,6 +261,8 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         if (w.blob16) HIP_TRY(hipFree(w.blob16));
         if (w.stem_w16) HIP_TRY(hipFree(w.stem_w16));
         if (w.stem_w16s) HIP_TRY(hipFree(w.stem_w16s));
+        for (int i = 0; i < 2; ++i)
+            if (w.l1_conv2_w16s[i]) HIP_TRY(hipFree(w.l1_conv2_w16s[i]));
         if (w.zero_page) HIP_TRY(hipFree(w.zero_page));
         w = Se18Weights();
     }
@@ -324,6 +329,10 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
     REID_TRY(launch_f32_to_f16(ctx, w.blob, n_floats, w.blob16));
     REID_TRY(launch_stem_w16(ctx, w.stem_w, w.stem_w16));
     REID_TRY(launch_stem_w16_scaled(ctx, w.stem_w, w.stem_scale, w.stem_w16s));
+    for (int i = 0; i < 2; ++i) {   // layer-1 conv2 weights with the BN scale folded in (conv3x3_c64_f16.hip)
+        HIP_TRY(hipMalloc((void**)&w.l1_conv2_w16s[i], 64 * 576 * sizeof(_Float16)));
+        REID_TRY(launch_scale_rows_f16(ctx, w.blk[i].conv2_w, w.blk[i].bn2_scale, 64, 576, w.l1_conv2_w16s[i]));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     w.loaded = true;
     return REID_OK;
@@ -544,7 +553,14 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
         const int Ho = (H + 2 - 3) / k.stride + 1, Wo = (W + 2 - 3) / k.stride + 1;
         const int hw = Ho * Wo, tiles = hw / 128;
         const int half = k.ibn ? k.c / 2 : 0;
-        if (k.ibn) {
+        // layer 1 (64 -> 64 on 64 x 32): register-resident-weight kernel, statistics per image (tiles = 1)
+        const bool c64 = ctx->f16_c64 && i < 2 && conv3x3_c64_f16_supported(H, W, k.cin, k.c, 3, 3, k.stride, 1) && !k.ds;
+        if (c64) {
+            REID_TRY(launch_conv3x3_c64_f16(ctx, cur, n, w.h(k.conv1_w), nullptr, nullptr, 0, stats, c1, w.zero_page));
+            REID_TRY(launch_norm_finalize(ctx, stats, n, 1, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift,
+                                          a_scale, a_shift));
+            REID_TRY(launch_affine_relu_f16(ctx, c1, a_scale, a_shift, n, hw, k.c));
+        } else if (k.ibn) {
             // conv1 raw + per-(image, channel) statistics, then InstanceNorm/BN + ReLU in place
             REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.conv1_w), k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr,
                                  nullptr, nullptr, 0, stats, c1));
@@ -556,15 +572,19 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
             REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.conv1_w), k.c, 3, 3, k.stride, 1, 9 * k.cin,
                                  k.bn1_scale, k.bn1_shift, nullptr, 1, nullptr, c1));
         }
-        REID_TRY(conv_gemm16(ctx, A16_IM2COL, c1, n, Ho, Wo, k.c, w.h(k.conv2_w), k.c, 3, 3, 1, 1, 9 * k.c, k.bn2_scale,
-                             k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, stats, y));
+        if (c64) {
+            REID_TRY(launch_conv3x3_c64_f16(ctx, c1, n, w.l1_conv2_w16s[i], k.bn2_shift, cur, 1, stats, y, w.zero_page));   // residual + ReLU: Q5
+        } else {
+            REID_TRY(conv_gemm16(ctx, A16_IM2COL, c1, n, Ho, Wo, k.c, w.h(k.conv2_w), k.c, 3, 3, 1, 1, 9 * k.c, k.bn2_scale,
+                                 k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, stats, y));
+        }
         const f16* shortcut = cur;
         if (k.ds) {
             REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.ds_w), k.c, 1, 1, k.stride, 0, k.cin, k.ds_scale,
                                  k.ds_shift, nullptr, 0, nullptr, sc));
             shortcut = sc;
         }
-        REID_TRY(launch_se_finalize(ctx, stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, se));
+        REID_TRY(launch_se_finalize(ctx, stats, n, c64 ? 1 : tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, se));
         f16* out = c1;
         REID_TRY(launch_se_combine_f16(ctx, y, shortcut, se, n, hw, k.c, out));
         stage[2 + i] = (float*)out;
@@ -1053,6 +1073,49 @@ extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, 
     return st;
 }
 
+
+// Correctness harness for conv3x3_c64_f16.hip (tests only, not part of the C ABI): fp32 host operands are rounded to f16,
+// the kernel runs once, the f16 result and the fp32 per-image statistics come back as fp32.
+extern "C" int reid_debug_conv_c64(reid_ctx* ctx, int n, const float* x, const float* w_krsc, const float* scale,
+                                   const float* shift, const float* residual, int relu, float* out, float* stats) {
+    ARG_CHECK(ctx && x && w_krsc && out && n >= 1);
+    typedef _Float16 f16;
+    const size_t nact = (size_t)n * 64 * 32 * 64, nw = 64 * 576;
+    float *xf, *wf, *rf = nullptr, *sc = nullptr, *sh = nullptr, *st = nullptr, *of;
+    f16 *xh, *wh, *rh = nullptr, *oh, *zp;
+    REID_TRY(ctx_ws(ctx, "dbg64.xf", nact * 4, (void**)&xf));
+    REID_TRY(ctx_ws(ctx, "dbg64.wf", nw * 4, (void**)&wf));
+    REID_TRY(ctx_ws(ctx, "dbg64.xh", nact * 2, (void**)&xh));
+    REID_TRY(ctx_ws(ctx, "dbg64.wh", nw * 2, (void**)&wh));
+    REID_TRY(ctx_ws(ctx, "dbg64.oh", nact * 2, (void**)&oh));
+    REID_TRY(ctx_ws(ctx, "dbg64.of", nact * 4, (void**)&of));
+    REID_TRY(ctx_ws(ctx, "dbg64.zp", 256, (void**)&zp));
+    REID_TRY(ctx_ws(ctx, "dbg64.sc", 64 * 4, (void**)&sc));
+    REID_TRY(ctx_ws(ctx, "dbg64.sh", 64 * 4, (void**)&sh));
+    REID_TRY(ctx_ws(ctx, "dbg64.st", (size_t)n * 128 * 4, (void**)&st));
+    HIP_TRY(hipMemsetAsync(zp, 0, 256, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(xf, x, nact * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(wf, w_krsc, nw * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<float> ones(64, 1.f);
+    HIP_TRY(hipMemcpyAsync(sc, scale ? scale : ones.data(), 64 * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (shift) HIP_TRY(hipMemcpyAsync(sh, shift, 64 * 4, hipMemcpyHostToDevice, ctx->stream));
+    REID_TRY(launch_f32_to_f16(ctx, xf, nact, xh));
+    REID_TRY(launch_scale_rows_f16(ctx, wf, sc, 64, 576, wh));
+    if (residual) {
+        REID_TRY(ctx_ws(ctx, "dbg64.rf", nact * 4, (void**)&rf));
+        REID_TRY(ctx_ws(ctx, "dbg64.rh", nact * 2, (void**)&rh));
+        HIP_TRY(hipMemcpyAsync(rf, residual, nact * 4, hipMemcpyHostToDevice, ctx->stream));
+        REID_TRY(launch_f32_to_f16(ctx, rf, nact, rh));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // `ones` is a local
+    REID_TRY(launch_conv3x3_c64_f16(ctx, xh, n, wh, shift ? sh : nullptr, rh, relu, stats ? st : nullptr, oh, zp));
+    std::vector<f16> tmp(nact);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), oh, nact * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (stats) HIP_TRY(hipMemcpyAsync(stats, st, (size_t)n * 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < nact; ++i) out[i] = (float)tmp[i];
+    return REID_OK;
+}
 
 // Times one dense fp16 GEMM C[m][n] = A[m][k] . B[n][k]^T (experiments: separates the im2col gather from the tile loop).
 extern "C" int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, int iters, float* ms_per_launch,

@@ -114,6 +114,10 @@ int launch_gem_neck_f16(reid_ctx*, const _Float16* x, int n_img, int hw, int c, 
                         const float* shift, float* gem_out, float* emb);
 int launch_f32_to_f16(reid_ctx*, const float* x, size_t n, _Float16* out);
 int launch_stem_w16(reid_ctx*, const float* stem_w_f32, _Float16* out);
+bool conv3x3_c64_f16_supported(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
+int launch_scale_rows_f16(reid_ctx*, const float* w, const float* scale, int rows, int k, _Float16* out);
+int launch_conv3x3_c64_f16(reid_ctx*, const _Float16* in, int n, const _Float16* w_scaled, const float* shift,
+                           const _Float16* residual, int relu, float* stats, _Float16* out, const _Float16* zero_page);
 int launch_stem_w16_scaled(reid_ctx*, const float* stem_w_f32, const float* scale, _Float16* out);
 int launch_stem_pool_f16(reid_ctx*, const _Float16* pad_in, int n, const _Float16* w16s, const float* shift, _Float16* pooled);
 int launch_conv_w16_chunked(reid_ctx*, const float* w_f32, int cout, int rs, int cin, _Float16* out);  // -> [Cout][Cin/64][RS][64]   // [64][8][24] -> [64][8][8][4]
@@ -163,6 +167,7 @@ struct Se18Weights {
     const float *gem_p, *neck_scale, *neck_shift, *cls_w;
     _Float16* blob16 = nullptr;   // fp16 copy of the whole blob (same element offsets) for the fp16 path
     _Float16* stem_w16 = nullptr; // [64][256] stem weights of the padded-NHWC4 formulation
+    _Float16* l1_conv2_w16s[2] = {nullptr, nullptr};   // layer-1 conv2 weights x BN scale (conv3x3_c64_f16.hip)
     _Float16* stem_w16s = nullptr; // same with the folded BN scale multiplied in (fused stem + maxpool kernel)
     _Float16* zero_page = nullptr;
     const _Float16* h(const float* p) const { return blob16 + (p - blob); }
@@ -188,6 +193,7 @@ struct reid_ctx {
     bool last_f16 = false;
     int f16_loader_waves = 1; // LDS-halo kernel: 8 compute + 4 dedicated loader waves (REID_F16_LOADERS)
     int f16_halo = 1;        // 3x3 stride-1 convs of the fp16 path use the LDS-halo kernel (REID_F16_HALO=0: implicit GEMM)
+    int f16_c64 = 1;         // fp16 path: layer-1 convs on the register-resident-weight kernel (REID_F16_C64=0: implicit GEMM)
     int f16_stem_fused = 1;  // fp16 path: stem conv + BN + maxpool as one kernel (REID_F16_STEMPOOL=0: GEMM + pool kernels)
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
     float* stage_ptr[11] = {nullptr};

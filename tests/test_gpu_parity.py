@@ -474,3 +474,52 @@ def test_f16_fused_stem_pool_matches_unfused_and_oracle(eng_w0):
     finally:
         eng.set_precision(0)
     assert np.array_equal(emb_nk, emb_f)
+
+
+# ----------------------------------------------------------------------------- layer-1 kernel (register-resident weights)
+def _conv_c64(eng, x, w, scale=None, shift=None, residual=None, relu=0, want_stats=True):
+    import ctypes as C
+    fn = eng.lib.reid_debug_conv_c64
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
+    n = x.shape[0]
+    out = np.empty((n, 64, 32, 64), np.float32)
+    stats = np.empty((n, 64, 2), np.float32)
+    p = lambda a: None if a is None else np.ascontiguousarray(a, np.float32).ctypes.data_as(C.c_void_p)
+    keep = [np.ascontiguousarray(a, np.float32) if a is not None else None for a in (x, w, scale, shift, residual)]
+    _ffi.check(fn(eng.h, n, *[None if a is None else a.ctypes.data_as(C.c_void_p) for a in keep], int(relu),
+                  out.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p) if want_stats else None))
+    return out, stats
+
+
+@pytest.mark.parametrize("n,mode", [(1, "raw"), (3, "raw"), (5, "bn_res"), (2, "bn_res_relu"), (300, "bn_res")])
+def test_conv3x3_c64_f16_kernel_against_torch(eng, n, mode):
+    """conv3x3_c64_f16.hip in isolation (more images than CUs exercises the persistent loop): f16-rounded operands, fp32
+    reference convolution in torch; output within f16 rounding, per-image statistics within fp32 summation error."""
+    rng = np.random.default_rng(n)
+    x = rng.normal(0, 1, (n, 64, 32, 64)).astype(np.float32)
+    x[0, 0, :, :] = 3.0          # a bright top row / left column: border handling
+    x[0, :, 0, :] = -2.0
+    w = (rng.normal(0, 1, (64, 3, 3, 64)) / 24).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 64).astype(np.float32) * np.where(rng.random(64) < 0.2, -1, 1).astype(np.float32)
+    shift = rng.normal(0, 0.5, 64).astype(np.float32)
+    res = rng.normal(0, 1, (n, 64, 32, 64)).astype(np.float32)
+    if mode == "raw":
+        got, stats = _conv_c64(eng, x, w.reshape(64, 576))
+    else:
+        got, stats = _conv_c64(eng, x, w.reshape(64, 576), scale, shift, res, relu=int(mode.endswith("relu")))
+    h = lambda a: torch.from_numpy(a).half().float()
+    wq = h(w * (scale[:, None, None, None] if mode != "raw" else 1.0))
+    ref = F.conv2d(h(x).permute(0, 3, 1, 2), wq.permute(0, 3, 1, 2), padding=1)
+    if mode != "raw":
+        ref = ref.half().float() + torch.from_numpy(shift)[None, :, None, None] + h(res).permute(0, 3, 1, 2)
+        if mode.endswith("relu"):
+            ref = ref.clamp_min(0)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    sel = slice(None) if n <= 8 else slice(n - 3, n)
+    err = np.abs(got[sel] - ref[sel])
+    assert err.max() < 2e-2 and err.mean() < 2e-3, (err.max(), err.mean())
+    s1 = ref.sum((1, 2))
+    s2 = (ref.astype(np.float64) ** 2).sum((1, 2))
+    np.testing.assert_allclose(stats[:, :, 0], s1, rtol=0, atol=1.5)          # 2048 values of O(1), f16-rounded outputs
+    np.testing.assert_allclose(stats[:, :, 1], s2, rtol=5e-3, atol=1.0)
