@@ -190,7 +190,7 @@ def main():
             "whole_net_fraction_of_mfma_peak": round(FLOP_PER_CROP * n / (embed_ms * 1e-3) / 1e12 / peak, 4),
             "whole_net_fraction_of_hbm_roofline": round(FUSED_BYTES_PER_CROP * (0.5 if f16 else 1.0) * n / (embed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": {
-                "kernel": ("gemm_f16_kernel<im2col> (implicit-GEMM convolutions, v_mfma_f32_32x32x16_f16, LDS-DMA ring)" if f16 else
+                "kernel": ("convolution kernels of the fp16 path, v_mfma_f32_32x32x16_f16: conv3x3_f16 (LDS halo, layers 2-4), conv3x3_c64_f16 (layer 1, weights in registers), stem_pool_f16 (7x7 + BN + maxpool), gemm_f16 (strided / 1x1)" if f16 else
                            "gemm_f32_kernel<im2col> (implicit-GEMM convolutions, v_mfma_f32_32x32x2_f32)"),
                 "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile(f16),

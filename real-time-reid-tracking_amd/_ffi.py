@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreid_hip.so")
+LIB_PATH = os.environ.get("REID_HIP_LIB", LIB_PATH)   # A/B experiments: an alternative build of the same library
 
 METRIC_L2, METRIC_L2SQR, METRIC_COS_HALF, METRIC_COS, METRIC_DOT = range(5)
 K_CONV_GEMM, K_DIST_GEMM, K_ELEMENTWISE, K_SELECT = range(4)

@@ -1,0 +1,55 @@
+"""HBM-side traffic per launch of the convolution kernel class from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+cannot share a pass: MI355X_MICROARCH.md, rocprofv3 PMC slots).  On the GPU box:
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --single
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --single
+    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch/p_results.db gpurun_out/pmc_write/p_results.db > profiles/r01_traffic_conv_f16.json
+
+gfx950 correction (same guide, HBM section): FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads -> doubled;
+WRITE_SIZE is exact for 16-byte-per-lane stores.  Both counters are in KiB."""
+import json
+import re
+import sqlite3
+import sys
+
+CONV = re.compile(r"conv3x3_f16_kernel|conv3x3_c64_f16_kernel|stem_pool_f16_kernel|gemm_f16_kernel")
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    t = lambda pre: [x for x in tabs if x.startswith(pre)][0]
+    q = (f"select s.kernel_name, p.value from {t('rocpd_pmc_event')} p "
+         f"join {t('rocpd_info_pmc')} i on p.pmc_id = i.id "
+         f"join {t('rocpd_kernel_dispatch')} d on p.event_id = d.event_id "
+         f"join {t('rocpd_info_kernel_symbol')} s on d.kernel_id = s.id where i.name = ?")
+    out = {}
+    for name, val in c.execute(q, (counter,)):
+        m = CONV.search(name)
+        if not m:
+            continue
+        k = m.group(0)
+        a = out.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += float(val)
+    return out
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+launches = sum(v[0] for v in fetch.values())
+fetch_kb = sum(v[1] for v in fetch.values())
+write_kb = sum(v[1] for v in write.values())
+res = {
+    "kernel_class": "convolution kernels of the fp16 path (conv3x3_f16, conv3x3_c64_f16, stem_pool_f16, gemm_f16)",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu --single (4096 crops, chunk 1024)",
+    "launches": launches,
+    "fetch_size_kb_raw_per_launch": fetch_kb / max(1, launches),
+    "write_size_kb_per_launch": write_kb / max(1, sum(v[0] for v in write.values())),
+    "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
+    "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0 / max(1, launches),
+    "per_kernel": {k: {"launches": fetch[k][0], "hbm_bytes_per_launch": (2.0 * fetch[k][1] + write.get(k, [0, 0.0])[1]) * 1024.0 / fetch[k][0]}
+                   for k in fetch},
+}
+print(json.dumps(res, indent=1))
