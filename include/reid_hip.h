@@ -151,6 +151,17 @@ int reid_rerank_jaccard_dev(reid_ctx* ctx, const float* d_x, int n, int d, int k
 int reid_diou(reid_ctx* ctx, const double* box4, const double* cand_m4, int m, double* out_m);
 /* cost[t][m] = 1 - DIoU(tracks[t], dets[m])   ([external] deep_sort iou_cost loop over iou()) */
 int reid_diou_cost(reid_ctx* ctx, const double* tracks_t4, int t, const double* dets_m4, int m, double* out_tm);
+/* ---- evaluation-script post-processing --------------------------------------------------- */
+/* retrieval descriptor of reid/image_reid_inference.py:112-123,252-253: cat(normalize(emb), normalize(logits)) per image,
+ * with flip_tta != 0 averaged with the horizontally mirrored image and renormalised.  x: fp32 [n][3][256][128] already
+ * normalised by the caller's transform; out: fp32 [n][512 + num_class] (reid_seres18_dims). */
+int reid_descriptor_f32_nchw(reid_ctx* ctx, const float* x, int n, int flip_tta, float* out);
+int reid_descriptor_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int flip_tta, float* d_out);
+/* diminish_camera_bias, reid/inference_utils.py:5-15, in place on x fp32 [n][d]: per camera id c (cams is a host int32[n],
+ * ids >= 0) rows X_c <- normalize_rows((X_c - mean X_c) inverse(X_c^T X_c + n_c*la*I)^T).  The inverse is a Newton-Schulz
+ * iteration of fp32 GEMMs that stops when the residual reaches the fp32 noise floor (iters = upper bound, <= 0: 40). */
+int reid_cam_debias(reid_ctx* ctx, float* x, const int32_t* cams, int n, int d, float la, int iters);
+int reid_cam_debias_dev(reid_ctx* ctx, float* d_x, const int32_t* cams, int n, int d, float la, int iters);
 /* ---- DeepSORT appearance metric with the feature bank on the device ---------------------------
  * [external] deep_sort/sort/nn_matching.py NearestNeighborDistanceMetric (the per-frame consumer of Extractor.__call__;
  * MAX_DIST / NN_BUDGET from modification_deepsort/deep_sort.yaml:3,9).  A bank holds, per track slot, the last `budget`

@@ -292,6 +292,18 @@ def gen_rerank():
     np.savez_compressed(os.path.join(OUT, "rerank.npz"), **out)
 
 
+def gen_postproc():
+    """Camera de-biasing from the reference's own function (reid/inference_utils.py:5-15, imports as-is)."""
+    from reid.inference_utils import diminish_camera_bias
+    from reid_amd import synth
+    _, _, _, gf, _, gc = synth.clustered_embeddings(1, 700, d=93, n_ids=20, n_cams=4, seed=41, sigma=0.7)
+    gf = gf + 0.15 * np.random.default_rng(42).normal(0, 1, (4, 93)).astype(np.float32)[gc]   # a per-camera offset to remove
+    gf = (gf / np.linalg.norm(gf, axis=1, keepdims=True)).astype(np.float32)
+    out = diminish_camera_bias(torch.from_numpy(gf.copy()), torch.from_numpy(gc), la=0.05).numpy()
+    np.savez_compressed(os.path.join(OUT, "postproc.npz"), x=gf, cams=gc.astype(np.int32), debiased=out)
+    print("postproc: debias", gf.shape, "mean |delta|", float(np.abs(out - gf).mean()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -302,3 +314,4 @@ if __name__ == "__main__":
     gen_seres18()
     gen_swin()
     gen_rerank()
+    gen_postproc()

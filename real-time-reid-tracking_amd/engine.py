@@ -229,6 +229,25 @@ class Engine:
         check(self.lib.reid_knn_dev(self.h, C.c_void_p(d_xq), int(nq), C.c_void_p(d_xb), int(nb), int(d), int(k),
                                     C.c_void_p(d_D), C.c_void_p(d_I)))
 
+    def descriptor_f32_nchw(self, x, flip_tta=True):
+        """float32 [n,3,256,128] (normalised by the caller) -> float32 [n, 512 + num_class] retrieval descriptor."""
+        x = _f32(x)
+        if x.ndim != 4 or x.shape[1:] != (3, IMG_H, IMG_W):
+            raise ValueError("descriptor_f32_nchw expects [n,3,%d,%d], got %s" % (IMG_H, IMG_W, x.shape))
+        de, nc = self.embed_dim, self.num_class
+        out = np.empty((x.shape[0], de + nc), np.float32)
+        check(self.lib.reid_descriptor_f32_nchw(self.h, _ptr(x), x.shape[0], int(bool(flip_tta)), _ptr(out)))
+        return out
+
+    def cam_debias(self, x, cams, la=0.05, iters=0):
+        """diminish_camera_bias (reid/inference_utils.py:5-15) on the device; returns a new float32 [n, d] array."""
+        x = np.array(_f32(x), copy=True)
+        cams = np.ascontiguousarray(cams, dtype=np.int32).reshape(-1)
+        if x.ndim != 2 or cams.shape[0] != x.shape[0]:
+            raise ValueError("cam_debias expects x[n,d] and cams[n]")
+        check(self.lib.reid_cam_debias(self.h, _ptr(x), _ptr(cams), x.shape[0], x.shape[1], C.c_float(la), int(iters)))
+        return x
+
     def rerank_jaccard(self, x, k1=20, k2=6, rank=None):
         """float32 [n, n] k-reciprocal Jaccard distance (reid/faiss_utils.py:147-244); rank: optional int32 [n, k1]."""
         x = _f32(x)

@@ -523,3 +523,39 @@ def test_conv3x3_c64_f16_kernel_against_torch(eng, n, mode):
     s2 = (ref.astype(np.float64) ** 2).sum((1, 2))
     np.testing.assert_allclose(stats[:, :, 0], s1, rtol=0, atol=1.5)          # 2048 values of O(1), f16-rounded outputs
     np.testing.assert_allclose(stats[:, :, 1], s2, rtol=5e-3, atol=1.0)
+
+
+# ----------------------------------------------------------------------------- evaluation post-processing
+def test_cam_debias_matches_reference_fixture(eng, golden_dir):
+    """reid_cam_debias (Gram + Newton-Schulz inverse + projection as fp32 GEMMs) against the reference's own
+    diminish_camera_bias output; also D = 1263 (the reference's descriptor width, padded to 1264 inside) against the oracle."""
+    from oracle import postproc
+    from reid_amd import inference_utils
+    z = np.load(os.path.join(golden_dir, "postproc.npz"))
+    got = eng.cam_debias(z["x"], z["cams"])
+    np.testing.assert_allclose(got, z["debiased"], rtol=0, atol=5e-5)
+    t = torch.from_numpy(z["x"].copy())
+    assert inference_utils.diminish_camera_bias(t, torch.from_numpy(z["cams"])) is t      # in place, like the reference
+    np.testing.assert_allclose(t.numpy(), z["debiased"], rtol=0, atol=5e-5)
+    _, _, _, x, _, cams = synth.clustered_embeddings(1, 1500, d=1263, n_ids=60, n_cams=3, seed=43, sigma=0.9)
+    cams[cams == 1] = 4                     # ids 1 and 3 have no rows: skipped
+    got = eng.cam_debias(x, cams)
+    want = postproc.diminish_camera_bias(x, cams)
+    np.testing.assert_allclose(got, want, rtol=0, atol=5e-5)
+
+
+def test_tta_descriptor_matches_oracle(eng_w0):
+    """reid_descriptor_f32_nchw: device flip + two forwards + cat/average/normalise against the oracle forward on the plain
+    and mirrored images (image_reid_inference.py:112-123,252-253)."""
+    from oracle import postproc
+    eng, sd = eng_w0
+    x = seres18.preprocess_u8(synth.smooth_crops_u8(5, 7))
+    got = eng.descriptor_f32_nchw(x.numpy(), flip_tta=True)
+    e1, l1 = seres18.forward(sd, x)
+    e2, l2 = seres18.forward(sd, torch.flip(x, dims=[3]))
+    want = postproc.tta_descriptor(e1.numpy(), l1.numpy(), e2.numpy(), l2.numpy())
+    assert got.shape == (5, 512 + 751)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    single = eng.descriptor_f32_nchw(x.numpy(), flip_tta=False)
+    np.testing.assert_allclose(single, postproc.descriptor(e1.numpy(), l1.numpy()), rtol=0, atol=2e-5)

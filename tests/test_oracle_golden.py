@@ -145,3 +145,24 @@ def test_rerank_reciprocal_sets_hand_case():
     assert rerank.k_reciprocal_neigh(rank, 0, 2).tolist() == [0, 1]
     assert rerank.k_reciprocal_neigh(rank, 2, 2).tolist() == [2]      # 1 does not list 2
     assert rerank.k_reciprocal_neigh(rank, 3, 2).tolist() == [3]
+
+
+def test_cam_debias_oracle_matches_reference(golden_dir):
+    """oracle/postproc.py:diminish_camera_bias against the reference's own function (reid/inference_utils.py:5-15)."""
+    from oracle import postproc
+    z = np.load(os.path.join(golden_dir, "postproc.npz"))
+    got = postproc.diminish_camera_bias(z["x"], z["cams"])
+    np.testing.assert_allclose(got, z["debiased"], rtol=0, atol=2e-5)     # fp32 LAPACK inverse in the reference, fp64 here
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+
+
+def test_descriptor_oracle_hand_vectors():
+    """image_reid_inference.py:123,252-253: cat of unit vectors, mean of two views, renormalise."""
+    from oracle import postproc
+    e = np.asarray([[3.0, 4.0]], np.float32)
+    l = np.asarray([[0.0, 2.0, 0.0]], np.float32)
+    np.testing.assert_allclose(postproc.descriptor(e, l), [[0.6, 0.8, 0.0, 1.0, 0.0]], atol=1e-7)
+    d = postproc.tta_descriptor(e, l, np.asarray([[4.0, 3.0]], np.float32), np.asarray([[2.0, 0.0, 0.0]], np.float32))
+    want = np.asarray([[0.7, 0.7, 0.5, 0.5, 0.0]]) / np.sqrt(0.49 * 2 + 0.25 * 2)
+    np.testing.assert_allclose(d, want, atol=1e-6)
+    assert np.isfinite(postproc.descriptor(np.zeros((1, 2), np.float32), l)).all()      # eps clamp of F.normalize
