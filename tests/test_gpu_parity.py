@@ -559,3 +559,49 @@ def test_tta_descriptor_matches_oracle(eng_w0):
     np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
     single = eng.descriptor_f32_nchw(x.numpy(), flip_tta=False)
     np.testing.assert_allclose(single, postproc.descriptor(e1.numpy(), l1.numpy()), rtol=0, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[1] at full size
+@pytest.mark.parametrize("precision", [0, 1])
+def test_full_size_config1_properties(eng_w0, precision):
+    """4096 crops + 4096 x 4096 L2 matrix (BASELINE configs[1]) through size-independent properties: the batch holds 256
+    distinct crops, each 16 times, in shuffled order.  Crops are independent in eval mode (per-sample InstanceNorm / SE), so
+    (a) copies of a crop get bit-identical embeddings wherever they sit in the batch; a different pass size may pick another
+        tile shape for some layer (per-column partial sums of the InstanceNorm statistics then add up in another order), so
+        across pass sizes they agree to rounding, not bit for bit,
+    (b) the distance matrix is symmetric with a ~0 diagonal, duplicates are at distance ~0 and the 16 nearest neighbours of
+        every row are exactly its 16 copies (k-NN selection at full size),
+    (c) a sample of rows equals the oracle within the mode's tolerance."""
+    eng, sd = eng_w0
+    rng = np.random.default_rng(11)
+    base = synth.smooth_crops_u8(256, 5)
+    ids = np.repeat(np.arange(256), 16)
+    rng.shuffle(ids)
+    crops = base[ids]
+    eng.set_precision(precision)
+    try:
+        eng.set_chunk(1024)
+        emb = eng.embed_u8(crops)
+        eng.set_chunk(96)                     # ragged passes: 96 does not divide 4096
+        emb_small = eng.embed_u8(crops[:1000])
+        first = np.asarray([np.flatnonzero(ids == c)[0] for c in range(256)])
+        assert np.array_equal(emb, emb[first][ids])                     # (a) position invariance, bit-exact
+        rel = np.abs(emb_small - emb[:1000]).max() / np.abs(emb).max()
+        assert rel < (2e-3 if precision else 1e-4)                      # (a) pass-size invariance, to rounding
+        dist = eng.distmat(emb, emb, _ffi.METRIC_L2)
+        scale = float(np.median(dist))
+        assert np.abs(dist - dist.T).max() <= 1e-4 * scale
+        # |x|^2 + |y|^2 - 2x.y cancels ~1e-7 * |x|^2 in fp32 (the reference's addmm_ does too); the sqrt makes that 1e-3..1e-2 of a distance
+        assert np.abs(np.diag(dist)).max() <= 1e-2 * scale
+        same = ids[:, None] == ids[None, :]
+        assert dist[same].max() <= 1e-2 * scale
+        assert dist[~same].min() > 20 * dist[same].max()
+        _, knn = eng.knn(emb, emb, 16)
+        assert np.array_equal(np.sort(ids[knn], axis=1), np.repeat(ids[:, None], 16, 1))   # (b)
+        sample = first[:6]
+        want = seres18.embed_u8(sd, crops[sample])                      # (c)
+        cos = (emb[sample] * want).sum(1) / np.linalg.norm(emb[sample], axis=1) / np.linalg.norm(want, axis=1)
+        assert (1 - cos).max() < (1e-4 if precision else 1e-5)
+    finally:
+        eng.set_chunk(128)
+        eng.set_precision(0)
