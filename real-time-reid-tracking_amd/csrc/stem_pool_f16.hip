@@ -122,9 +122,9 @@ __global__ __launch_bounds__(512) void stem_pool_f16_kernel(const f16* __restric
         // pooled row oy = 2k + p_oy: conv rows 2oy-1 .. 2oy+1 (row -1 holds -inf), columns 2ox-1 .. 2ox+1
         {
             const int oy = 2 * k + p_oy;
-            float m[8];
+            half8 m;   // the maximum of f16 values is exact in f16: packed v_pk_max_f16, no conversions inside the window
 #pragma unroll
-            for (int e = 0; e < 8; ++e) m[e] = -65504.f;
+            for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const char* trow = tile + ((2 * oy - 1 + dy) & 7) * TILE_ROW_B;
@@ -133,13 +133,12 @@ __global__ __launch_bounds__(512) void stem_pool_f16_kernel(const f16* __restric
                     const int cx = 2 * p_ox - 1 + dx;
                     if (cx < 0) continue;
                     const half8 v = *(const half8*)(trow + cx * 128 + ((p_cg ^ ((cx >> 1) & 7)) * 16));
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+                    m = __builtin_elementwise_max(m, v);
                 }
             }
             half8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)(m[e] + sh[e]);
+            for (int e = 0; e < 8; ++e) o[e] = (f16)((float)m[e] + sh[e]);
             *(half8*)(o_img + ((long long)oy * OW + p_ox) * 64 + p_cg * 8) = o;
         }
     }
