@@ -87,8 +87,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
             const int hw = p.Ho * p.Wo;
             const int img = m / hw, rem = m - img * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_iy0[j] = oy * p.stride - p.pad;
-            a_ix0[j] = ox * p.stride - p.pad;
+            a_iy0[j] = oy * p.stride - (p.asym ? p.pad_y : p.pad);
+            a_ix0[j] = ox * p.stride - (p.asym ? p.pad_x : p.pad);
             a_img[j] = img;
         }
     }
@@ -279,6 +279,56 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
     const int row0 = wm * WTM + 4 * lh;
     const int m_valid = p.M - m_blk;  // rows of this tile that exist (>= 256 except for a ragged last tile)
 
+    if (p.lin) {   // linear layers (Swin): bias, erf-GELU, fp32 residual stream, fp32 or f16 output, ragged M and N
+        const int n_real = p.n_real ? p.n_real : p.N;
+        constexpr bool LIN_LDS = BM * BN * 2 <= NST * STAGE;
+        // f16 outputs that are plain row-major (no residual, no scatter) are staged through LDS and leave as whole 16-byte
+        // pieces of a row; everything else (fp32 stream, ConvTranspose scatter) stores from the MFMA layout, 128 B per row
+        const bool staged = LIN_LDS && !p.C32 && !p.res32 && p.scat_h == 0 && (n_real & 7) == 0;
+        f16* tile = (f16*)lds;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * WTN + b * 32 + li;
+            const int col = n_blk + lcol;
+            const bool col_ok = col < n_real;
+            const float bias = (p.col_shift && col_ok) ? p.col_shift[col] : 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
+                    float v = acc[a][b][e] + bias;
+                    if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU() (erf form)
+                    if (staged) {
+                        tile[rl * BN + lcol] = (f16)v;
+                    } else if (rl < m_valid && col_ok) {
+                        long long orow = m_blk + rl;
+                        if (p.scat_h > 0) {   // ConvTranspose2d(4,2,1) output parity: (img, j, i) -> (img, 2j+py, 2i+px)
+                            const int hw = p.scat_h * p.scat_w;
+                            const int row = m_blk + rl;
+                            const int img = row / hw, rem = row - img * hw;
+                            const int jj = rem / p.scat_w, ii = rem - jj * p.scat_w;
+                            orow = ((long long)img * 2 * p.scat_h + 2 * jj + p.scat_py) * (2 * p.scat_w) + 2 * ii + p.scat_px;
+                        }
+                        const long long o = orow * ldc + col;
+                        if (p.res32) v += p.res32[o];
+                        if (p.C32) p.C32[o] = v;
+                        else p.C[o] = (f16)v;
+                    }
+                }
+        }
+        if (staged) {
+            __syncthreads();
+            constexpr int C8 = BN / 8;
+            for (int idx = tid; idx < BM * C8; idx += 512) {
+                const int row = idx / C8, c8 = idx - row * C8;
+                if (row < m_valid && n_blk + c8 * 8 < n_real)
+                    *(half8*)(p.C + (long long)(m_blk + row) * ldc + n_blk + c8 * 8) = *(const half8*)(tile + row * BN + c8 * 8);
+            }
+        }
+        return;
+    }
+
     // The residual tile [256][BN] f16 is brought into the (now free) LDS ring by DMA and read from there: per-lane
     // 2-byte global loads would be 128 latency-serialised round trips per lane (measured +40 us per launch).
     constexpr bool RES_LDS = BM * BN * 2 <= NST * STAGE;
@@ -459,7 +509,7 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
 }  // namespace
 
 int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, double flops, double bytes) {
-    ARG_CHECK(p.M > 0 && p.M % 128 == 0 && p.N % 64 == 0 && p.K % 32 == 0 && p.ldb % 8 == 0);
+    ARG_CHECK(p.M > 0 && (p.lin || p.M % 128 == 0) && p.N % 64 == 0 && p.K % 32 == 0 && p.ldb % 8 == 0);
     if (amode == A16_IM2COL) ARG_CHECK(p.Cin % 32 == 0 && p.K == p.R * p.S * p.Cin && p.zero_page);
     if (amode == A16_STEM) ARG_CHECK((p.K == 256 || p.K == 224) && p.Hp >= p.H + 6 && p.Wp >= p.W + 8);
     if (amode == A16_DENSE) ARG_CHECK(p.lda % 8 == 0);

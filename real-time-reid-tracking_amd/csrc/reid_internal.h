@@ -97,6 +97,12 @@ struct Gemm16Params {
     float* stats;
     const _Float16* zero_page;
     unsigned long long* diag;   // diagnostic builds only: per-wave cycle sums [block<64][wave][4]
+    // linear-layer epilogue (Swin): out = act(acc + col_shift) + res32, stored as fp32 (C32) or f16 (C); ragged M, N
+    int lin, act, n_real;       // lin != 0 selects it; act 1 = erf-GELU; n_real = columns that exist (0: N)
+    int asym, pad_y, pad_x;     // asym != 0: separate top / left padding of the im2col gather (ConvTranspose parities)
+    int scat_h, scat_w, scat_py, scat_px;   // > 0: output row (img, j, i) -> (img, 2j+py, 2i+px) of a 2x upsampled map
+    float* C32;
+    const float* res32;
 };
 
 struct reid_ctx;

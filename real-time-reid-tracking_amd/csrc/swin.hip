@@ -12,6 +12,8 @@
 #include <sstream>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16;
+typedef f16 half4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -145,9 +147,10 @@ __global__ __launch_bounds__(256) void sfe_conv2_fc_kernel(const float* __restri
 }
 
 // ---- LayerNorm over the channel dimension, one wave per token (C <= 768)
+template <typename OUT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long ntok, int c, float eps,
                                                         const float* __restrict__ g, const float* __restrict__ b,
-                                                        float* __restrict__ out) {
+                                                        OUT* __restrict__ out) {
     const long long tok = blockIdx.x * 4LL + (threadIdx.x >> 6);
     if (tok >= ntok) return;
     const int lane = threadIdx.x & 63;
@@ -169,19 +172,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         q += d * d;
     }
     const float rstd = 1.0f / sqrtf(wsum(q) / c + eps);
-    float* oi = out + tok * c;
+    OUT* oi = out + tok * c;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         const int ch = lane + 64 * j;
-        if (ch < c) oi[ch] = (v[j] - mean) * rstd * g[ch] + b[ch];
+        if (ch < c) oi[ch] = (OUT)((v[j] - mean) * rstd * g[ch] + b[ch]);
     }
 }
 
 // ---- WindowAttention v1 (swin_transformer.py:191-232): one wave per (image, window, head); lane = query token (49 of
 // 64 lanes active), K and V of the window/head in LDS (read as broadcasts), softmax in registers.
 // qkv: [tokens][3C] (q | k | v, head-major inside each), out: [tokens][C].
-__global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ qkv, int n_img, int H, int W, int heads,
-                                                          int shifted, const float* __restrict__ pos, float* __restrict__ out) {
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 ld4(const f16* p) {
+    const half4 h = *(const half4*)p;
+    f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return r;
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void st4(f16* p, f32x4 v) {
+    half4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+    *(half4*)p = h;
+}
+// T = float (exact mode) or f16 (fp16-storage mode: qkv comes from / the result goes to the f16 GEMMs); ldq = row stride of qkv
+template <typename T>
+__global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ qkv, int ldq, int n_img, int H, int W, int heads,
+                                                          int shifted, const float* __restrict__ pos, T* __restrict__ out) {
     __shared__ float kv[4][2][49 * 32];
     __shared__ float spos[169];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -210,12 +226,12 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
     }
     float q[32];
     if (act) {
-        const float* base = qkv + tok * 3 * C + head * 32;
+        const T* base = qkv + tok * ldq + head * 32;
 #pragma unroll
         for (int d = 0; d < 32; d += 4) {
-            const f32x4 a = *(const f32x4*)(base + d);
-            const f32x4 b = *(const f32x4*)(base + C + d);
-            const f32x4 c = *(const f32x4*)(base + 2 * C + d);
+            const f32x4 a = ld4(base + d);
+            const f32x4 b = ld4(base + C + d);
+            const f32x4 c = ld4(base + 2 * C + d);
             q[d] = a.x; q[d + 1] = a.y; q[d + 2] = a.z; q[d + 3] = a.w;
             *(f32x4*)&kv[wave][0][lane * 32 + d] = b;
             *(f32x4*)&kv[wave][1][lane * 32 + d] = c;
@@ -257,26 +273,30 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 #pragma unroll
         for (int d = 0; d < 32; ++d) o[d] += pj * vj[d];
     }
-    float* dst = out + tok * C + head * 32;
+    T* dst = out + tok * C + head * 32;
 #pragma unroll
     for (int d = 0; d < 32; d += 4) {
         f32x4 v = {o[d], o[d + 1], o[d + 2], o[d + 3]};
-        *(f32x4*)(dst + d) = v;
+        st4(dst + d, v);
     }
 }
 
-// ---- tail (:414-420): LayerNorm(96, eps 1e-6) per token -> GeM_1D over the tokens -> BatchNorm1d.  One block per image.
-__global__ __launch_bounds__(256) void swin_tail_kernel(const float* __restrict__ x, int ntok, const float* __restrict__ g,
-                                                        const float* __restrict__ b, const float* __restrict__ p_ptr,
-                                                        const float* __restrict__ bn_s, const float* __restrict__ bn_t,
-                                                        float* __restrict__ gem_out, float* __restrict__ emb) {
+// ---- tail (:414-420): LayerNorm(96, eps 1e-6) per token -> GeM_1D over the tokens -> BatchNorm1d.
+// Stage 1: grid (image, slice): the sum over a slice of the tokens of clamp(LN(x), 1e-6)^p per channel -> part[img][slice][96]
+// (one block per image left 3136 tokens to four waves and 7 % of the forward in this kernel).
+constexpr int TAIL_SLICES = 16;
+__global__ __launch_bounds__(256) void swin_tail_partial_kernel(const float* __restrict__ x, int ntok, const float* __restrict__ g,
+                                                                const float* __restrict__ b, const float* __restrict__ p_ptr,
+                                                                float* __restrict__ partial) {
     __shared__ float part[4][96];
-    const int img = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.x, slice = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float p = p_ptr[0];
     const float g0 = g[lane], b0 = b[lane];
     const float g1 = lane < 32 ? g[64 + lane] : 0.f, b1 = lane < 32 ? b[64 + lane] : 0.f;
+    const int per = (ntok + TAIL_SLICES - 1) / TAIL_SLICES;
+    const int t0 = slice * per, t1 = t0 + per < ntok ? t0 + per : ntok;
     float a0 = 0.f, a1 = 0.f;
-    for (int t = wave; t < ntok; t += 4) {
+    for (int t = t0 + wave; t < t1; t += 4) {
         const float* xi = x + ((long long)img * ntok + t) * 96;
         const float v0 = xi[lane], v1 = lane < 32 ? xi[64 + lane] : 0.f;
         const float mean = wsum(v0 + v1) / 96.f;
@@ -290,11 +310,21 @@ __global__ __launch_bounds__(256) void swin_tail_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x < 96) {
         const int c = threadIdx.x;
-        const float m = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / (float)ntok;
-        const float gm = powf(m, 1.0f / p);
-        if (gem_out) gem_out[img * 96 + c] = gm;
-        emb[img * 96 + c] = gm * bn_s[c] + bn_t[c];
+        partial[((long long)img * TAIL_SLICES + slice) * 96 + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
     }
+}
+// Stage 2: mean over the tokens, ^(1/p), BatchNorm1d
+__global__ void swin_tail_final_kernel(const float* __restrict__ partial, int n, int ntok, const float* __restrict__ p_ptr,
+                                       const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                       float* __restrict__ gem_out, float* __restrict__ emb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 96) return;
+    const int img = i / 96, c = i - img * 96;
+    float s = 0.f;
+    for (int k = 0; k < TAIL_SLICES; ++k) s += partial[((long long)img * TAIL_SLICES + k) * 96 + c];
+    const float gm = powf(s / (float)ntok, 1.0f / p_ptr[0]);
+    if (gem_out) gem_out[i] = gm;
+    emb[i] = gm * bn_s[c] + bn_t[c];
 }
 
 inline int grid_for(long long work, int block) {
@@ -313,6 +343,40 @@ int linear(reid_ctx* ctx, const float* x, long long m, int k, const float* w, co
     p.C = out; p.ldc = n;
     p.col_shift = bias; p.act = act; p.residual = residual;
     return launch_gemm_f32(ctx, A_DENSE, E_BIAS, p, REID_K_CONV_GEMM, 2.0 * m * n * k, 4.0 * ((double)m * k + (double)n * k + (double)m * n));
+}
+
+// fp16-storage linear on the f16 MFMA GEMM: x f16 [m][lda], w f16 [n padded to 64][k]; out = act(x.w^T + bias) (+ res32),
+// written as f16 (out16, row stride ldc) or into the fp32 residual stream (out32)
+int linear16(reid_ctx* ctx, const f16* x, long long m, int lda, int k, const f16* w, const float* bias, int n, int act,
+             const float* res32, f16* out16, float* out32, int ldc) {
+    Gemm16Params p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.lda = lda;
+    p.B = w; p.ldb = k;
+    p.M = (int)m; p.N = (n + 63) / 64 * 64; p.K = k;
+    p.C = out16; p.C32 = out32; p.ldc = ldc;
+    p.col_shift = bias; p.lin = 1; p.act = act; p.n_real = n; p.res32 = res32;
+    return launch_gemm_f16(ctx, A16_DENSE, p, REID_K_CONV_GEMM, 2.0 * m * n * k, 2.0 * ((double)m * k + (double)n * k) + (out32 ? 4.0 : 2.0) * m * n);
+}
+
+// fp16-storage convolution (patch merging, alignment conv, ConvTranspose parity) on the f16 MFMA GEMM: im2col gather of an
+// NHWC f16 map, weights [Cout padded to 64][R*S*Cin]; out = conv + bias (+ res32 at the output index), f16 or fp32
+int conv16(reid_ctx* ctx, const f16* zero_page, const f16* x, int n, int H, int W, int Cin, const f16* w, const float* bias,
+           int Cout, int R, int S, int stride, int pad_y, int pad_x, int Ho, int Wo, const float* res32, f16* out16, float* out32,
+           int scat_h = 0, int scat_w = 0, int py = 0, int px = 0) {
+    Gemm16Params p;
+    memset(&p, 0, sizeof(p));
+    p.A = x;
+    p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.S = S; p.stride = stride; p.asym = 1; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.Ho = Ho; p.Wo = Wo;
+    p.B = w; p.ldb = (long long)R * S * Cin;
+    p.M = n * Ho * Wo; p.N = (Cout + 63) / 64 * 64; p.K = R * S * Cin;
+    p.C = out16; p.C32 = out32; p.ldc = Cout;
+    p.col_shift = bias; p.lin = 1; p.n_real = Cout; p.res32 = res32;
+    p.scat_h = scat_h; p.scat_w = scat_w; p.scat_py = py; p.scat_px = px;
+    p.zero_page = zero_page;
+    return launch_gemm_f16(ctx, A16_IM2COL, p, REID_K_CONV_GEMM, 2.0 * p.M * Cout * p.K,
+                           2.0 * ((double)n * H * W * Cin + (double)Cout * p.K) + (out32 ? 4.0 : 2.0) * p.M * Cout);
 }
 
 // generic NHWC conv as implicit GEMM with bias (+residual); scatter for ConvTranspose parities
@@ -342,9 +406,16 @@ const int kDims[4] = {96, 192, 384, 768}, kLayers[4] = {2, 2, 6, 2}, kHeads[4] =
 struct SwinBlockW {
     const float *ln1_g, *ln1_b, *qkv_w, *pos, *out_w, *out_b, *post_w, *post_b, *ln2_g, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 };
+struct SwinBlockW16 {
+    const f16 *qkv, *out, *post, *fc1, *fc2;   // [N padded to a multiple of 64][K], zero rows past N
+};
 struct SwinWeights {
     bool loaded = false;
     float* blob = nullptr;
+    f16* blob16 = nullptr;        // fp16-storage mode: the block linears
+    SwinBlockW16 blk16[12];
+    const f16 *merge16[4], *img16, *t16[3];   // patch merging, 8x8 alignment conv, ConvTranspose parities (rows padded to 64)
+    f16* zero_page = nullptr;
     int num_class = 0;
     const float *c1_w, *c1_b, *in_g, *in_b, *bn_s, *bn_t, *c2_w, *c2_b, *fc_w, *fc_b;
     SwinBlockW blk[12];
@@ -363,6 +434,8 @@ void swin_release(reid_ctx* ctx) {
     auto it = r.find(ctx);
     if (it != r.end()) {
         if (it->second.blob) (void)hipFree(it->second.blob);
+        if (it->second.blob16) (void)hipFree(it->second.blob16);
+        if (it->second.zero_page) (void)hipFree(it->second.zero_page);
         r.erase(it);
     }
 }
@@ -444,6 +517,51 @@ extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats,
         (void)hipFree(w.blob);
         return REID_ERR_ARG;
     }
+    // fp16 copies of the block linears for reid_ctx_set_precision(ctx, 1): rows padded to a multiple of 64 (the f16 GEMM's
+    // narrowest N tile); the padding rows are zero and their output columns are never stored
+    {
+        auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
+        size_t total = 0;
+        for (int s = 0; s < 4; ++s) {
+            const size_t c = kDims[s];
+            total += (size_t)kLayers[s] * (pad64(3 * c) * c + 2 * pad64(c) * c + pad64(4 * c) * c + pad64(c) * 4 * c);
+            if (s > 0) total += pad64(c) * 4 * kDims[s - 1];
+        }
+        total += (size_t)768 * 64 * 96;
+        for (int t = 0; t < 3; ++t) total += 4 * pad64(kDims[2 - t]) * 4 * kDims[3 - t];
+        HIP_TRY(hipMalloc((void**)&w.zero_page, 256));
+        HIP_TRY(hipMemsetAsync(w.zero_page, 0, 256, ctx->stream));
+        HIP_TRY(hipMalloc((void**)&w.blob16, total * sizeof(f16)));
+        HIP_TRY(hipMemsetAsync(w.blob16, 0, total * sizeof(f16), ctx->stream));
+        f16* cur = w.blob16;
+        auto conv = [&](const float* src, size_t n, size_t k) -> const f16* {
+            f16* dst = cur;
+            (void)launch_f32_to_f16(ctx, src, n * k, dst);
+            cur += pad64(n) * k;
+            return dst;
+        };
+        int b2 = 0;
+        for (int s = 0; s < 4; ++s) {
+            const size_t c = kDims[s];
+            for (int j = 0; j < kLayers[s]; ++j, ++b2) {
+                const SwinBlockW& k = w.blk[b2];
+                SwinBlockW16& h = w.blk16[b2];
+                h.qkv = conv(k.qkv_w, 3 * c, c);
+                h.out = conv(k.out_w, c, c);
+                h.post = conv(k.post_w, c, c);
+                h.fc1 = conv(k.fc1_w, 4 * c, c);
+                h.fc2 = conv(k.fc2_w, c, 4 * c);
+            }
+        }
+        for (int s = 1; s < 4; ++s) w.merge16[s] = conv(w.merge_w[s], kDims[s], 4 * (size_t)kDims[s - 1]);
+        w.img16 = conv(w.img_w, 768, 64 * 96);
+        for (int t = 0; t < 3; ++t) {   // four parity matrices [co][4*ci] each, every one padded on its own
+            const size_t ci = kDims[3 - t], co = kDims[2 - t];
+            w.t16[t] = cur;
+            for (int q = 0; q < 4; ++q) (void)conv(w.t_w[t] + (size_t)q * co * 4 * ci, co, 4 * ci);
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     w.loaded = true;
     swin_registry()[ctx] = w;
     return REID_OK;
@@ -503,7 +621,14 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
             HIP_TRY(hipMemcpyAsync(xcur, sfe, (size_t)T1 * 96 * 4, hipMemcpyDeviceToDevice, ctx->stream));
         } else {
             // PatchMerging = conv2x2 s2 with weights repacked to (kh, kw, c) order + bias (swin_transformer.py:263-275)
-            REID_TRY(conv_bias(ctx, prev, n, Hs, Ws, kDims[s - 1], w.merge_w[s], w.merge_b[s], C, 2, 2, 2, 0, 0, Hs / 2, Ws / 2, nullptr, xcur));
+            if (ctx->precision == 1) {
+                f16* x16 = (f16*)lnb;   // f16 copy of the previous stage's output (the residual stream itself stays fp32)
+                REID_TRY(launch_f32_to_f16(ctx, prev, (size_t)n * Hs * Ws * kDims[s - 1], x16));
+                REID_TRY(conv16(ctx, w.zero_page, x16, n, Hs, Ws, kDims[s - 1], w.merge16[s], w.merge_b[s], C, 2, 2, 2, 0, 0, Hs / 2, Ws / 2,
+                                nullptr, nullptr, xcur));
+            } else {
+                REID_TRY(conv_bias(ctx, prev, n, Hs, Ws, kDims[s - 1], w.merge_w[s], w.merge_b[s], C, 2, 2, 2, 0, 0, Hs / 2, Ws / 2, nullptr, xcur));
+            }
             Hs /= 2;
             Ws /= 2;
         }
@@ -511,22 +636,51 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
         for (int j = 0; j < kLayers[s]; ++j, ++bi) {
             const SwinBlockW& k = w.blk[bi];
             const int shifted = j & 1;
+            const long long ntask = (long long)n * (Hs / 7) * (Ws / 7) * heads;
+            if (ctx->precision == 1) {
+                // fp16-storage mode: the five linears of the block (95 % of its MACs) on the f16 MFMA GEMM with fp32
+                // accumulation; LayerNorm, softmax, GELU and the residual stream x stay fp32
+                const SwinBlockW16& h = w.blk16[bi];
+                f16* ln16 = (f16*)lnb;                 // [T][C]
+                f16* big16 = (f16*)big;                // qkv [T][ldq] / MLP hidden [T][4C]
+                f16* att16 = (f16*)att;                // [T][C]
+                f16* tmp16 = (f16*)tmp;                // [T][C]
+                const int ldq = (3 * C + 63) / 64 * 64;
+                prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 6);
+                hipLaunchKernelGGL(layernorm_kernel<f16>, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f,
+                                   k.ln1_g, k.ln1_b, ln16);
+                prof_end(ctx);
+                REID_TRY(linear16(ctx, ln16, T, C, C, h.qkv, nullptr, 3 * C, 0, nullptr, big16, nullptr, ldq));
+                prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
+                hipLaunchKernelGGL(window_attn_kernel<f16>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big16, ldq, n,
+                                   Hs, Ws, heads, shifted, k.pos, att16);
+                prof_end(ctx);
+                LAUNCH_CHECK();
+                REID_TRY(linear16(ctx, att16, T, C, C, h.out, k.out_b, C, 0, nullptr, tmp16, nullptr, C));
+                REID_TRY(linear16(ctx, tmp16, T, C, C, h.post, k.post_b, C, 0, xcur, nullptr, xcur, C));
+                prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 6);
+                hipLaunchKernelGGL(layernorm_kernel<f16>, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f,
+                                   k.ln2_g, k.ln2_b, ln16);
+                prof_end(ctx);
+                REID_TRY(linear16(ctx, ln16, T, C, C, h.fc1, k.fc1_b, 4 * C, 1, nullptr, big16, nullptr, 4 * C));
+                REID_TRY(linear16(ctx, big16, T, 4 * C, 4 * C, h.fc2, k.fc2_b, C, 0, xcur, nullptr, xcur, C));
+                continue;
+            }
             // x = x + post_proj(to_out(attn(LN(x))))
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
-            hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f, k.ln1_g, k.ln1_b, lnb);
+            hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f, k.ln1_g, k.ln1_b, lnb);
             prof_end(ctx);
             REID_TRY(linear(ctx, lnb, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big));
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 16);
-            const long long ntask = (long long)n * (Hs / 7) * (Ws / 7) * heads;
-            hipLaunchKernelGGL(window_attn_kernel, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, n, Hs, Ws, heads,
-                               shifted, k.pos, att);
+            hipLaunchKernelGGL(window_attn_kernel<float>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, 3 * C, n,
+                               Hs, Ws, heads, shifted, k.pos, att);
             prof_end(ctx);
             LAUNCH_CHECK();
             REID_TRY(linear(ctx, att, T, C, k.out_w, k.out_b, C, 0, nullptr, tmp));
             REID_TRY(linear(ctx, tmp, T, C, k.post_w, k.post_b, C, 0, xcur, xcur));
             // x = x + fc2(gelu(fc1(LN(x))))
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
-            hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f, k.ln2_g, k.ln2_b, lnb);
+            hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f, k.ln2_g, k.ln2_b, lnb);
             prof_end(ctx);
             REID_TRY(linear(ctx, lnb, T, C, k.fc1_w, k.fc1_b, 4 * C, 1, nullptr, big));
             REID_TRY(linear(ctx, big, T, 4 * C, k.fc2_w, k.fc2_b, C, 0, xcur, xcur));
@@ -535,8 +689,29 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
     }
     // top-down fusion (:405-412): f = stage4 + Conv8x8s8(sfe); then three ConvTranspose2d(4, 2, 1) + stage outputs
     const int H4 = H1 / 8, W4 = W1 / 8;
+    const float* fin;
+    if (ctx->precision == 1) {
+        // same fusion with f16 feature maps between the steps; every step adds its fp32 stage output in the epilogue
+        f16* sfe16 = (f16*)att;
+        f16* maps16[3] = {(f16*)tmp, (f16*)f3, (f16*)f2};   // [n,7,7,768] -> [n,14,14,384] -> [n,28,28,192]
+        REID_TRY(launch_f32_to_f16(ctx, sfe, (size_t)T1 * 96, sfe16));
+        REID_TRY(conv16(ctx, w.zero_page, sfe16, n, H1, W1, 96, w.img16, w.img_b, 768, 8, 8, 8, 0, 0, H4, W4, xs[3], maps16[0], nullptr));
+        int Hi = H4, Wi = W4;
+        for (int t = 0; t < 3; ++t) {
+            const int ci = kDims[3 - t], co = kDims[2 - t];
+            const size_t wstride = (size_t)((co + 63) / 64 * 64) * 4 * ci;
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px)
+                    REID_TRY(conv16(ctx, w.zero_page, maps16[t], n, Hi, Wi, ci, w.t16[t] + (size_t)(py * 2 + px) * wstride, w.t_b[t], co, 2, 2, 1,
+                                    1 - py, 1 - px, Hi, Wi, xs[2 - t], t < 2 ? maps16[t + 1] : nullptr, t < 2 ? nullptr : f1, Hi, Wi,
+                                    py, px));
+            Hi *= 2;
+            Wi *= 2;
+        }
+        fin = f1;
+    } else {
     REID_TRY(conv_bias(ctx, sfe, n, H1, W1, 96, w.img_w, w.img_b, 768, 8, 8, 8, 0, 0, H4, W4, xs[3], tmp));
-    const float* fin = tmp;
+    fin = tmp;
     float* fouts[3] = {f3, f2, f1};
     int Hi = H4, Wi = W4;
     for (int t = 0; t < 3; ++t) {
@@ -549,9 +724,14 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
         Hi *= 2;
         Wi *= 2;
     }
+    }
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T1 * 96 * 4);
-    hipLaunchKernelGGL(swin_tail_kernel, dim3(n), dim3(256), 0, ctx->stream, fin, H1 * W1, w.tail_g, w.tail_b, w.tail_p, w.neck_s,
-                       w.neck_t, gem, d_emb);
+    float* tail_part;
+    REID_TRY(ctx_ws(ctx, "swin.tailp", (size_t)n * TAIL_SLICES * 96 * 4, (void**)&tail_part));
+    hipLaunchKernelGGL(swin_tail_partial_kernel, dim3(n, TAIL_SLICES), dim3(256), 0, ctx->stream, fin, H1 * W1, w.tail_g, w.tail_b,
+                       w.tail_p, tail_part);
+    hipLaunchKernelGGL(swin_tail_final_kernel, dim3((n * 96 + 255) / 256), dim3(256), 0, ctx->stream, tail_part, n, H1 * W1, w.tail_p,
+                       w.neck_s, w.neck_t, gem, d_emb);
     prof_end(ctx);
     LAUNCH_CHECK();
     if (d_logits) {
@@ -572,7 +752,7 @@ extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int
         return REID_ERR_STATE;
     }
     const SwinWeights& sw = it->second;
-    const int chunk = ctx->chunk < 64 ? ctx->chunk : 64;
+    const int chunk = ctx->chunk < 256 ? ctx->chunk : 256;   // ~13 MB of fp32 activations per 224x224 image
     const size_t img = (size_t)3 * h * w;
     for (int i = 0; i < n; i += chunk) {
         const int m = n - i < chunk ? n - i : chunk;

@@ -14,6 +14,7 @@ from reid_amd.engine import get_engine
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+prec = sys.argv[3] if len(sys.argv) > 3 else "f32"
 eng = get_engine(0)
 stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)
@@ -21,6 +22,7 @@ eng.set_stream(stream.cuda_stream)
 eng.set_chunk(chunk)
 sd = synth.swin_state_dict(0)
 eng.load_swin(*weights.pack_swin(sd)[:2])
+eng.set_precision(1 if prec == "f16" else 0)
 x = torch.from_numpy(synth.images_f32(64, 1)).cuda().repeat((n + 63) // 64, 1, 1, 1)[:n].contiguous()
 emb = torch.empty((n, 96), dtype=torch.float32, device="cuda")
 for _ in range(2):
