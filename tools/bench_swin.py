@@ -40,10 +40,10 @@ eng.swin_embed_dev(x.data_ptr(), n, 224, 224, emb.data_ptr())
 torch.cuda.synchronize()
 g, e = eng.profile_get(_ffi.K_CONV_GEMM), eng.profile_get(_ffi.K_ELEMENTWISE)
 eng.profile(False)
-out = {"workload": "BASELINE configs[2]: Swin-T v1, %d images 224x224, fp32 MFMA GEMMs" % n, "crops_per_s": round(n / el, 1),
+out = {"workload": "BASELINE configs[2]: Swin-T v1, %d images 224x224, %s" % (n, "fp16-storage GEMMs / fp32 residual stream" if prec == "f16" else "fp32 MFMA GEMMs"), "crops_per_s": round(n / el, 1),
        "ms": round(el * 1e3, 2), "gemm_tflops": round(g["flops"] / g["ms"] / 1e9, 2), "gemm_ms": round(g["ms"], 2),
        "gemm_launches": g["launches"], "other_ms": round(e["ms"], 2), "chunk": chunk,
-       "flop_fraction_of_f32_mfma_peak": round(11.54e9 * n / el / 157.3e12, 4)}
+       "precision": prec, "whole_net_tflops": round(11.54e9 * n / el / 1e12, 1)}
 if "--cpu" in sys.argv:
     from oracle import swin
     torch.set_num_threads(16)
