@@ -40,7 +40,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
     if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e) != 0;
-    if (const char* e = getenv("REID_F16_C64")) c->f16_c64 = atoi(e) != 0;
+    if (const char* e = getenv("REID_F16_C64")) c->f16_c64 = atoi(e);   // 0 implicit GEMM, 1 layer-1 kernel, 2 + fused SE tail
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipEventCreate(&c->t0));
@@ -572,7 +572,17 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
             REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.conv1_w), k.c, 3, 3, k.stride, 1, 9 * k.cin,
                                  k.bn1_scale, k.bn1_shift, nullptr, 1, nullptr, c1));
         }
-        if (c64) {
+        if (c64 && ctx->f16_c64 == 2) {
+            // conv2 + residual + ReLU (Q5) + SE gate + combine in one kernel: `out` is the block output, y never reaches HBM
+            f16* outb = y;   // c1 is this launch's input, cur its shortcut: the block output goes to the third buffer
+            REID_TRY(launch_conv3x3_c64_f16(ctx, c1, n, w.l1_conv2_w16s[i], k.bn2_shift, cur, 1, nullptr, outb, w.zero_page, k.se_w1,
+                                            k.se_w2));
+            stage[2 + i] = (float*)outb;
+            cur = outb;
+            H = Ho;
+            W = Wo;
+            continue;
+        } else if (c64) {
             REID_TRY(launch_conv3x3_c64_f16(ctx, c1, n, w.l1_conv2_w16s[i], k.bn2_shift, cur, 1, stats, y, w.zero_page));   // residual + ReLU: Q5
         } else {
             REID_TRY(conv_gemm16(ctx, A16_IM2COL, c1, n, Ho, Wo, k.c, w.h(k.conv2_w), k.c, 3, 3, 1, 1, 9 * k.c, k.bn2_scale,

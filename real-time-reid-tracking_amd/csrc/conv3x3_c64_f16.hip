@@ -44,6 +44,12 @@ struct C64Params {
     f16* out;
     const f16* zero_page;
     int n, relu;
+    // fused SE tail (SEBasicBlock.forward, SERes18_IBN.py:120-128): when se_w1 is set, `out` receives the BLOCK output
+    // relu(gate * y + shortcut) with gate = sigmoid(W2 relu(W1 avgpool(y))), y = this convolution's result (kept in the
+    // per-block scratch image `y_scratch`, 2048 x 64 f16, which stays in L2) and shortcut = `residual`
+    const float* se_w1;    // [8][64]
+    const float* se_w2t;   // [8][64] (fc2 transposed)
+    f16* y_scratch;        // [gridDim.x][2048][64]
 };
 
 // 512 threads = 8 waves = two per SIMD, 256 VGPRs each.  Wave (chh, pg) owns output channels chh*32 .. +32 (its 36 weight
@@ -185,11 +191,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_f16_kernel(const C64Params p)
                     s2[e] += f * f;
                     o[e] = (f16)f;
                 }
-                *(half8*)(p.out + step_off + (long long)idx * 8) = (HAS_SHIFT || HAS_RES) ? o : v;
+                if (p.se_w1) *(half8*)(p.y_scratch + ((long long)blockIdx.x * MH + 8 * s) * MW * MC + (long long)idx * 8) = o;
+                else *(half8*)(p.out + step_off + (long long)idx * 8) = (HAS_SHIFT || HAS_RES) ? o : v;
             }
             __syncthreads();   // staging tiles are free again (the next step's residual DMA may start)
         }
-        if (p.stats) {   // 64 threads share a channel octet: fixed-order reduction through the staging tiles
+        if (p.stats || p.se_w1) {   // 64 threads share a channel octet: fixed-order reduction through the staging tiles
             float* red = (float*)tile;   // [512][16] floats = both staging tiles
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -197,13 +204,58 @@ __global__ __launch_bounds__(512) void conv3x3_c64_f16_kernel(const C64Params p)
                 red[tid * 16 + 8 + e] = s2[e];
             }
             __syncthreads();
+            float tot = 0.f;
             if (tid < 128) {
                 const int oc = tid >> 4, j = tid & 15;
-                float t = 0.f;
-                for (int m = 0; m < 64; ++m) t += red[(oc + 8 * m) * 16 + j];
-                p.stats[((long long)img * MC + oc * 8 + (j & 7)) * 2 + (j >> 3)] = t;
+                for (int m = 0; m < 64; ++m) tot += red[(oc + 8 * m) * 16 + j];
+                if (p.stats) p.stats[((long long)img * MC + oc * 8 + (j & 7)) * 2 + (j >> 3)] = tot;
             }
             __syncthreads();
+            if (p.se_w1) {
+                // SE gate of this image: pooled mean -> 64 -> 8 (ReLU) -> 64 (sigmoid); then the block output over the
+                // eight steps again: y from the scratch image this block just wrote (L2), shortcut from the residual input
+                float* pooled = (float*)tile;            // [64]
+                float* hid = pooled + 64;                // [8]
+                float* gate = pooled + 128;              // [64]
+                if (tid < 128 && (tid & 15) < 8) pooled[(tid >> 4) * 8 + (tid & 7)] = tot / (float)(MH * MW);
+                __syncthreads();
+                if (tid < 8 * 64) {   // wave m: hidden unit m
+                    const int m = tid >> 6;
+                    float a = p.se_w1[m * 64 + lane] * pooled[lane];
+                    for (int o = 32; o; o >>= 1) a += __shfl_xor(a, o);
+                    if (lane == 0) hid[m] = fmaxf(a, 0.f);
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) a += p.se_w2t[m * 64 + tid] * hid[m];
+                    gate[tid] = 1.0f / (1.0f + expf(-a));
+                }
+                __syncthreads();
+                float g[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = gate[c8 * 8 + e];
+                const f16* ys = p.y_scratch + (long long)blockIdx.x * MH * MW * MC;
+                const long long img_off = (long long)img * MH * MW * MC;
+                for (int s = 0; s < STEPS; ++s) {
+                    half8 yv[4], rv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const long long o = (long long)s * 8 * MW * MC + (long long)(tid + 512 * i) * 8;
+                        yv[i] = *(const half8*)(ys + o);
+                        rv[i] = *(const half8*)(p.residual + img_off + o);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        half8 o8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o8[e] = (f16)fmaxf(g[e] * (float)yv[i][e] + (float)rv[i][e], 0.f);
+                        *(half8*)(p.out + img_off + (long long)s * 8 * MW * MC + (long long)(tid + 512 * i) * 8) = o8;
+                    }
+                }
+                __syncthreads();   // the gate lives in the staging tile the next image will overwrite
+            }
         }
     }
 }
@@ -231,13 +283,18 @@ int launch_scale_rows_f16(reid_ctx* ctx, const float* w, const float* scale, int
 
 // stats (if given) are per IMAGE: [n][64][2] - the finalize kernels take tiles = 1 for this producer
 int launch_conv3x3_c64_f16(reid_ctx* ctx, const f16* in, int n, const f16* w_scaled, const float* shift, const f16* residual,
-                           int relu, float* stats, f16* out, const f16* zero_page) {
+                           int relu, float* stats, f16* out, const f16* zero_page, const float* se_w1, const float* se_w2t) {
     C64Params p;
     p.in = in; p.w = w_scaled; p.shift = shift; p.residual = residual; p.stats = stats; p.out = out;
     p.zero_page = zero_page; p.n = n; p.relu = relu;
+    p.se_w1 = se_w1; p.se_w2t = se_w2t; p.y_scratch = nullptr;
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const int grid = n < cus ? n : cus;
+    if (se_w1) {
+        ARG_CHECK(se_w2t && residual && shift);
+        REID_TRY(ctx_ws(ctx, "c64.y", (size_t)grid * MH * MW * MC * 2, (void**)&p.y_scratch));
+    }
     const double flops = 2.0 * n * MH * MW * MC * 9.0 * MC;
     const double bytes = (double)n * MH * MW * MC * 2.0 * (residual ? 3.0 : 2.0);
     prof_begin(ctx, REID_K_CONV_GEMM, flops, bytes);
