@@ -34,7 +34,9 @@ namespace {
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int AMODE, int BN, int BK, int NST, int STAG>
+// LIN: the linear-layer epilogue (Swin) instead of the convolution epilogue - a template parameter, not a run-time branch:
+// carrying both epilogues cost the 256-wide conv instantiations 66 more spilled VGPRs (72 -> 214 us per launch)
+template <int AMODE, int BN, int BK, int NST, int STAG, bool LIN = false>
 __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) {
     constexpr int BM = 256;
     constexpr int WM = BN == 256 ? 2 : 4;         // waves along M
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
             const int hw = p.Ho * p.Wo;
             const int img = m / hw, rem = m - img * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_iy0[j] = oy * p.stride - (p.asym ? p.pad_y : p.pad);
-            a_ix0[j] = ox * p.stride - (p.asym ? p.pad_x : p.pad);
+            a_iy0[j] = oy * p.stride - ((LIN && p.asym) ? p.pad_y : p.pad);
+            a_ix0[j] = ox * p.stride - ((LIN && p.asym) ? p.pad_x : p.pad);
             a_img[j] = img;
         }
     }
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
     const int row0 = wm * WTM + 4 * lh;
     const int m_valid = p.M - m_blk;  // rows of this tile that exist (>= 256 except for a ragged last tile)
 
-    if (p.lin) {   // linear layers (Swin): bias, erf-GELU, fp32 residual stream, fp32 or f16 output, ragged M and N
+    if constexpr (LIN) {   // linear layers (Swin): bias, erf-GELU, fp32 residual stream, fp32 or f16 output, ragged M and N
         const int n_real = p.n_real ? p.n_real : p.N;
         constexpr bool LIN_LDS = BM * BN * 2 <= NST * STAGE;
         // f16 outputs that are plain row-major (no residual, no scatter) are staged through LDS and leave as whole 16-byte
@@ -449,13 +451,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
     }
 }
 
-template <int AMODE, int BN, int BK, int NST, int STAG = 0>
+template <int AMODE, int BN, int BK, int NST, int STAG = 0, bool LIN = false>
 int launch_cfg(reid_ctx* ctx, const Gemm16Params& p) {
     if (p.K % BK != 0 || (AMODE == A16_IM2COL && p.Cin % BK != 0)) {
         reid_set_error("gemm_f16: K=%d / Cin=%d not a multiple of BK=%d", p.K, p.Cin, BK);
         return REID_ERR_ARG;
     }
-    hipLaunchKernelGGL((gemm_f16_kernel<AMODE, BN, BK, NST, STAG>), dim3(((p.M + 255) / 256) * (p.N / BN)), dim3(512), 0, ctx->stream, p);
+    hipLaunchKernelGGL((gemm_f16_kernel<AMODE, BN, BK, NST, STAG, LIN>), dim3(((p.M + 255) / 256) * (p.N / BN)), dim3(512), 0, ctx->stream, p);
     LAUNCH_CHECK();
     return REID_OK;
 }
@@ -469,10 +471,26 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
         // (624 TF), 256 -> 128642 (679 TF), 512 -> 256642 (953 TF) when that still gives >= 192 blocks
         const long long mt = (p.M + 255) / 256;
         const bool k64 = p.K % 64 == 0 && (AMODE != A16_IM2COL || p.Cin % 64 == 0);
-        const int bn = p.N % 256 == 0 && mt * (p.N / 256) >= 192 ? 256 : (p.N % 128 == 0 ? 128 : 64);
+        // (the linear-epilogue build of the 256-wide tile spills 98 VGPRs: those launches take the 128-wide one)
+        const int bn = !p.lin && p.N % 256 == 0 && mt * (p.N / 256) >= 192 ? 256 : (p.N % 128 == 0 ? 128 : 64);
         if (!k64) cfg = bn * 1000 + 320 + (bn == 256 ? 4 : 3);
         else if (bn == 128 && p.N == 128) cfg = 128323;
         else cfg = bn * 1000 + 642;
+    }
+    if (p.lin) {   // linear-epilogue builds exist for the tile shapes the heuristic above picks (no STEM mode)
+        if constexpr (AMODE != A16_STEM) {
+            switch (cfg) {
+                case 256324: return launch_cfg<AMODE, 256, 32, 4, 0, true>(ctx, p);
+                case 256642: return launch_cfg<AMODE, 256, 64, 2, 0, true>(ctx, p);
+                case 128323: return launch_cfg<AMODE, 128, 32, 3, 0, true>(ctx, p);
+                case 128642: return launch_cfg<AMODE, 128, 64, 2, 0, true>(ctx, p);
+                case 64323: return launch_cfg<AMODE, 64, 32, 3, 0, true>(ctx, p);
+                case 64642: return launch_cfg<AMODE, 64, 64, 2, 0, true>(ctx, p);
+                default: break;
+            }
+        }
+        reid_set_error("gemm_f16: no linear-epilogue build of tile configuration %d", cfg);
+        return REID_ERR_ARG;
     }
     switch (cfg) {
         case 256324: return launch_cfg<AMODE, 256, 32, 4>(ctx, p);
