@@ -633,3 +633,22 @@ def test_full_size_config1_properties(eng_w0, precision):
     finally:
         eng.set_chunk(128)
         eng.set_precision(0)
+
+
+@pytest.mark.parametrize("n", [1, 3, 7, 33])
+def test_f16_path_small_and_odd_batches(eng_w0, n):
+    """Batches that leave tiles ragged everywhere in the fp16 path: a single crop, odd counts (the 16x8 layers pair images per
+    block), fewer images than CUs (persistent layer-1 / stem kernels with idle blocks) - against the exact fp32 path."""
+    eng, sd = eng_w0
+    crops = synth.smooth_crops_u8(n, 40 + n)
+    ref = eng.embed_u8(crops)
+    eng.set_precision(1)
+    try:
+        got = eng.embed_u8(crops)
+        again = eng.embed_u8(np.concatenate([crops, crops[::-1]]))      # same crops inside a larger, different batch
+    finally:
+        eng.set_precision(0)
+    cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (1 - cos).max() < 1e-4
+    scale = np.abs(ref).max()
+    assert np.abs(again[:n] - got).max() <= 2e-3 * scale and np.abs(again[n:][::-1] - got).max() <= 2e-3 * scale
