@@ -45,7 +45,101 @@ __global__ __launch_bounds__(512) void feed_kernel(const char* __restrict__ src,
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
 }
 
+// MFMA-shape experiment (MI355X_MICROARCH.md, DVFS give-back item 7): the inner loop of the halo convolution - per wave and
+// per 32 k: A and B fragments re-read from LDS with ds_read_b128, then the MFMAs of a 64 x 64 wave tile - built once with
+// v_mfma_f32_32x32x16_f16 (2 x (2A + 2B reads, 4 MFMAs)) and once with v_mfma_f32_16x16x32_f16 (4A + 4B reads, 16 MFMAs):
+// same FLOPs, same LDS bytes, same accumulator registers.  LDS holds pseudo-random f16 values (the chip is clock-limited under
+// MFMA load on random data); results are summed into a sink so that nothing is optimised away.
+typedef _Float16 f16mb;
+typedef f16mb half8mb __attribute__((ext_vector_type(8)));
+typedef float f32x16mb __attribute__((ext_vector_type(16)));
+
+template <int SHAPE>
+__global__ __launch_bounds__(512) void mfma_shape_kernel(int iters, float* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) char lds[64 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned r = tid * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int i = tid; i < 64 * 1024 / 2; i += 512) {
+        r = r * 1664525u + 1013904223u;
+        ((f16mb*)lds)[i] = (f16mb)(((int)(r >> 9) & 0xffff) / 32768.0f - 1.0f);
+    }
+    __syncthreads();
+    const char* base = lds + (wave & 3) * 8192;
+    float total = 0.f;
+    if constexpr (SHAPE == 32) {
+        f32x16mb acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int off = ((it * 2 + kk) & 7) * 1024 + (lane >> 5) * 16;
+                half8mb af[2], bf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[a] = *(const half8mb*)(base + (a * 32 + (lane & 31)) * 32 % 8192 + off % 4096);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bf[b] = *(const half8mb*)(base + 32768 + (b * 32 + (lane & 31)) * 32 % 8192 + off % 4096);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) total += acc[a][b][e];
+    } else {
+        typedef float f32x4mb __attribute__((ext_vector_type(4)));
+        f32x4mb acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4mb{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+            const int off = (it & 7) * 1024 + (lane >> 4) * 16;
+            half8mb af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = *(const half8mb*)(base + (a * 16 + (lane & 15)) * 64 % 8192 + off % 4096);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[b] = *(const half8mb*)(base + 32768 + (b * 16 + (lane & 15)) * 64 % 8192 + off % 4096);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) total += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    }
+    if (total == 12345.678f) sink[0] = total;
+}
+
 }  // namespace
+
+// shape 32 or 16; returns TFLOP/s of the chip over a launch of `iters` 32-k steps per wave (64 x 64 wave tile, 8 waves, 256+ blocks)
+extern "C" int reid_debug_mfma_shape(reid_ctx* ctx, int shape, int iters, int blocks, float* tflops) {
+    ARG_CHECK(ctx && tflops && (shape == 32 || shape == 16) && iters > 0 && blocks > 0);
+    float* sink;
+    REID_TRY(ctx_ws(ctx, "dbg.sink", 64, (void**)&sink));
+    for (int rep = 0; rep < 2; ++rep) {
+        if (rep == 1) REID_TRY(reid_timer_start(ctx));
+        if (shape == 32) hipLaunchKernelGGL(mfma_shape_kernel<32>, dim3(blocks), dim3(512), 0, ctx->stream, iters, sink);
+        else hipLaunchKernelGGL(mfma_shape_kernel<16>, dim3(blocks), dim3(512), 0, ctx->stream, iters, sink);
+    }
+    float ms = 0.f;
+    REID_TRY(reid_timer_stop(ctx, &ms));
+    LAUNCH_CHECK();
+    *tflops = (float)((double)blocks * 8 * iters * 2.0 * 64 * 64 * 32 / (ms * 1e-3) / 1e12);
+    return REID_OK;
+}
 
 extern "C" int reid_debug_feed(reid_ctx* ctx, int mode, size_t footprint, int rowb, size_t stride, int iters, int inflight,
                                float* gbs_per_cu, float* tbs_chip) {
