@@ -39,7 +39,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
-    if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e) != 0;
+    if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e);   // 0 GEMM + pool, 1 fused, 2 fused reading uint8 crops
     if (const char* e = getenv("REID_F16_C64")) c->f16_c64 = atoi(e);   // 0 implicit GEMM, 1 layer-1 kernel, 2 + fused SE tail
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -525,12 +525,18 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
     REID_TRY(ctx_ws(ctx, "se18.se", (size_t)n * 512 * 4, (void**)&se));
     REID_TRY(ctx_ws(ctx, "se18.gem", (size_t)n * 512 * 4, (void**)&gem));
 
-    if (is_u8) REID_TRY(launch_prep_u8_pad_f16(ctx, (const uint8_t*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
-    else REID_TRY(launch_prep_f32_pad_f16(ctx, (const float*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
-    if (ctx->f16_stem_fused && ctx->debug_keep != 1) {   // debug_keep 1 keeps the unfused kernels (stage 0 = conv map)
+    const bool fused = ctx->f16_stem_fused && ctx->debug_keep != 1;   // debug_keep 1 keeps the unfused kernels (stage 0 = conv map)
+    if (is_u8 && fused && ctx->f16_stem_fused == 2) {
+        // uint8 crops straight into the fused stem: normalisation and zero padding happen while its LDS ring is filled
+        REID_TRY(launch_stem_pool_f16(ctx, nullptr, (const uint8_t*)x, n, w.stem_w16s, w.stem_shift, pool));
+    } else if (fused) {
+        if (is_u8) REID_TRY(launch_prep_u8_pad_f16(ctx, (const uint8_t*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
+        else REID_TRY(launch_prep_f32_pad_f16(ctx, (const float*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
         // conv 7x7 s2 + BN + MaxPool(3,2,1) in one kernel: the 1 MiB/crop conv map never reaches HBM (stem_pool_f16.hip)
-        REID_TRY(launch_stem_pool_f16(ctx, pad_in, n, w.stem_w16s, w.stem_shift, pool));
+        REID_TRY(launch_stem_pool_f16(ctx, pad_in, nullptr, n, w.stem_w16s, w.stem_shift, pool));
     } else {
+        if (is_u8) REID_TRY(launch_prep_u8_pad_f16(ctx, (const uint8_t*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
+        else REID_TRY(launch_prep_f32_pad_f16(ctx, (const float*)x, n, IMG_H, IMG_W, PAD_H, PAD_W, pad_in));
         REID_TRY(conv_gemm16(ctx, A16_STEM, pad_in, n, IMG_H, IMG_W, 4, w.stem_w16, 64, 7, 7, 2, 3, 224, w.stem_scale,
                              w.stem_shift, nullptr, 0, nullptr, stem, PAD_H, PAD_W));
         REID_TRY(launch_maxpool3s2_f16(ctx, stem, n, 128, 64, 64, pool));

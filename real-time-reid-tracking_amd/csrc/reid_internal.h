@@ -126,7 +126,8 @@ int launch_conv3x3_c64_f16(reid_ctx*, const _Float16* in, int n, const _Float16*
                            const _Float16* residual, int relu, float* stats, _Float16* out, const _Float16* zero_page,
                            const float* se_w1 = nullptr, const float* se_w2t = nullptr);
 int launch_stem_w16_scaled(reid_ctx*, const float* stem_w_f32, const float* scale, _Float16* out);
-int launch_stem_pool_f16(reid_ctx*, const _Float16* pad_in, int n, const _Float16* w16s, const float* shift, _Float16* pooled);
+int launch_stem_pool_f16(reid_ctx*, const _Float16* pad_in, const uint8_t* crops_u8, int n, const _Float16* w16s, const float* shift,
+                         _Float16* pooled);
 int launch_conv_w16_chunked(reid_ctx*, const float* w_f32, int cout, int rs, int cin, _Float16* out);  // -> [Cout][Cin/64][RS][64]   // [64][8][24] -> [64][8][8][4]
 int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int kind, double flops, double bytes);
 
@@ -202,7 +203,8 @@ struct reid_ctx {
     int f16_halo = 1;        // 3x3 stride-1 convs of the fp16 path use the LDS-halo kernel (REID_F16_HALO=0: implicit GEMM)
     int f16_c64 = 2;         // fp16 path: layer-1 convs on the register-resident-weight kernel, 2 = with the SE tail fused
                              // into conv2 (REID_F16_C64=1: separate se_finalize / se_combine kernels, 0: implicit GEMM)
-    int f16_stem_fused = 1;  // fp16 path: stem conv + BN + maxpool as one kernel (REID_F16_STEMPOOL=0: GEMM + pool kernels)
+    int f16_stem_fused = 2;  // fp16 path: stem conv + BN + maxpool as one kernel, 2 = fed with the uint8 crops directly
+                             // (REID_F16_STEMPOOL=1: from the padded f16 image, 0: GEMM + pool kernels)
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
     float* stage_ptr[11] = {nullptr};
 };

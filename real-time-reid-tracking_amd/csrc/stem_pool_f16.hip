@@ -40,14 +40,35 @@ constexpr int TILE_BYTES = 8 * TILE_ROW_B;     // 65 536
 
 __device__ __forceinline__ int ring_slot(int padded_row) { return (padded_row + 3) % RING_ROWS; }
 
-__global__ __launch_bounds__(512) void stem_pool_f16_kernel(const f16* __restrict__ pad_in, const f16* __restrict__ w16s,
-                                                            const float* __restrict__ shift, f16* __restrict__ out) {
+// U8: the input is the raw uint8 NHWC crop [256][128][3]; (v/255 - 0.5)/0.5 (feature_extractor.py:41-46), the channel
+// padding to 4 and the zero border are produced while the ring is filled - the padded f16 image (285 KB/crop written and
+// read back by a separate kernel) never exists.  Otherwise pad_in is that padded NHWC4 f16 image [262][136][4].
+template <bool U8>
+__global__ __launch_bounds__(512) void stem_pool_f16_kernel(const f16* __restrict__ pad_in, const uint8_t* __restrict__ crops,
+                                                            const f16* __restrict__ w16s, const float* __restrict__ shift,
+                                                            f16* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char lds[RING_BYTES + TILE_BYTES];
     char* ring = lds;
     char* tile = lds + RING_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const char* img = (const char*)(pad_in + (long long)blockIdx.x * PH * PW * 4);
+    const char* img = U8 ? nullptr : (const char*)(pad_in + (long long)blockIdx.x * PH * PW * 4);
+    const uint8_t* cimg = U8 ? crops + (long long)blockIdx.x * IN_H * IN_W * 3 : nullptr;
+    // padded pixel idx (row-major over [rows][136]) of padded row r0 + idx/136 -> the three bytes of the source pixel, or -1
+    auto src_of = [&](int r0, int idx) -> int {
+        const int r = r0 + idx / PW, pp = idx % PW;
+        const int y = r - 3, x = pp - 3;
+        return ((unsigned)y < (unsigned)IN_H && (unsigned)x < (unsigned)IN_W) ? (y * IN_W + x) * 3 : -1;
+    };
+    auto to_px = [&](int b0, int b1, int b2, bool ok) -> half4 {
+        half4 v = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        if (ok) {
+            v[0] = (f16)(((float)b0 / 255.0f - 0.5f) / 0.5f);
+            v[1] = (f16)(((float)b1 / 255.0f - 0.5f) / 0.5f);
+            v[2] = (f16)(((float)b2 / 255.0f - 0.5f) / 0.5f);
+        }
+        return v;
+    };
     f16* o_img = out + (long long)blockIdx.x * OH * OW * 64;
 
     // weights -> registers: fragment (ct, ks) = channels ct*32 + li, k = (ks>>1)*32 + (ks&1)*16 + lh*8 .. +8
@@ -59,8 +80,17 @@ __global__ __launch_bounds__(512) void stem_pool_f16_kernel(const f16* __restric
             wf[ct][ks] = *(const half8*)(w16s + (ct * 32 + li) * 256 + (ks >> 1) * 32 + (ks & 1) * 16 + lh * 8);
 
     // ring: padded rows 0..12 (slots 3..15, contiguous); conv-tile slot of row -1: -inf for the first pooling window
-    for (int idx = tid; idx < 13 * ROW_B / 16; idx += 512)
-        *(half8*)(ring + 3 * ROW_B + idx * 16) = *(const half8*)(img + idx * 16);
+    if constexpr (U8) {
+        for (int idx = tid; idx < 13 * PW; idx += 512) {
+            const int so = src_of(0, idx);
+            const bool ok = so >= 0;
+            const int o = ok ? so : 0;
+            *(half4*)(ring + 3 * ROW_B + idx * 8) = to_px(cimg[o], cimg[o + 1], cimg[o + 2], ok);
+        }
+    } else {
+        for (int idx = tid; idx < 13 * ROW_B / 16; idx += 512)
+            *(half8*)(ring + 3 * ROW_B + idx * 16) = *(const half8*)(img + idx * 16);
+    }
     {
         half8 ninf;
 #pragma unroll
@@ -80,11 +110,24 @@ __global__ __launch_bounds__(512) void stem_pool_f16_kernel(const f16* __restric
     for (int k = 0; k < CH / 4; ++k) {
         // next step's eight input rows (padded rows 8k+13 .. 8k+20, contiguous in global memory and in the ring)
         half8 pre0, pre1;
+        int pb[3][3];           // U8: the bytes of this thread's (up to) three pixels of the next eight rows
+        bool pok[3];
         const bool more = k + 1 < CH / 4;
         if (more) {
-            const char* src = img + (long long)(8 * k + 13) * ROW_B;
-            pre0 = *(const half8*)(src + tid * 16);
-            if (tid < 8 * ROW_B / 16 - 512) pre1 = *(const half8*)(src + (512 + tid) * 16);
+            if constexpr (U8) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int idx = tid + 512 * i;
+                    const int so = idx < 8 * PW ? src_of(8 * k + 13, idx) : -1;
+                    pok[i] = so >= 0;
+                    const int o = pok[i] ? so : 0;
+                    pb[i][0] = cimg[o]; pb[i][1] = cimg[o + 1]; pb[i][2] = cimg[o + 2];
+                }
+            } else {
+                const char* src = img + (long long)(8 * k + 13) * ROW_B;
+                pre0 = *(const half8*)(src + tid * 16);
+                if (tid < 8 * ROW_B / 16 - 512) pre1 = *(const half8*)(src + (512 + tid) * 16);
+            }
         }
         f32x16 acc[2];
 #pragma unroll
@@ -115,8 +158,16 @@ __global__ __launch_bounds__(512) void stem_pool_f16_kernel(const f16* __restric
         }
         if (more) {
             char* dst = ring + ring_slot(8 * k + 13) * ROW_B;
-            *(half8*)(dst + tid * 16) = pre0;
-            if (tid < 8 * ROW_B / 16 - 512) *(half8*)(dst + (512 + tid) * 16) = pre1;
+            if constexpr (U8) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int idx = tid + 512 * i;
+                    if (idx < 8 * PW) *(half4*)(dst + idx * 8) = to_px(pb[i][0], pb[i][1], pb[i][2], pok[i]);
+                }
+            } else {
+                *(half8*)(dst + tid * 16) = pre0;
+                if (tid < 8 * ROW_B / 16 - 512) *(half8*)(dst + (512 + tid) * 16) = pre1;
+            }
         }
         __syncthreads();
         // pooled row oy = 2k + p_oy: conv rows 2oy-1 .. 2oy+1 (row -1 holds -inf), columns 2ox-1 .. 2ox+1
@@ -163,12 +214,14 @@ int launch_stem_w16_scaled(reid_ctx* ctx, const float* w, const float* scale, f1
     return REID_OK;
 }
 
-// pad_in [n][262][136][4] f16 -> pooled [n][64][32][64] f16
-int launch_stem_pool_f16(reid_ctx* ctx, const f16* pad_in, int n, const f16* w16s, const float* shift, f16* out) {
+// pad_in [n][262][136][4] f16, or crops_u8 [n][256][128][3] (then pad_in is not read) -> pooled [n][64][32][64] f16
+int launch_stem_pool_f16(reid_ctx* ctx, const f16* pad_in, const uint8_t* crops_u8, int n, const f16* w16s, const float* shift,
+                         f16* out) {
     const double flops = 2.0 * n * CH * CW * 64 * 147;
-    const double bytes = (double)n * (PH * PW * 8.0 + OH * OW * 128.0);
+    const double bytes = (double)n * ((crops_u8 ? IN_H * IN_W * 3.0 : PH * PW * 8.0) + OH * OW * 128.0);
     prof_begin(ctx, REID_K_CONV_GEMM, flops, bytes);
-    hipLaunchKernelGGL(stem_pool_f16_kernel, dim3(n), dim3(512), 0, ctx->stream, pad_in, w16s, shift, out);
+    if (crops_u8) hipLaunchKernelGGL(stem_pool_f16_kernel<true>, dim3(n), dim3(512), 0, ctx->stream, pad_in, crops_u8, w16s, shift, out);
+    else hipLaunchKernelGGL(stem_pool_f16_kernel<false>, dim3(n), dim3(512), 0, ctx->stream, pad_in, crops_u8, w16s, shift, out);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
