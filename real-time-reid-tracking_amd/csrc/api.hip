@@ -40,6 +40,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
     if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e);   // 0 GEMM + pool, 1 fused, 2 fused reading uint8 crops
+    if (const char* e = getenv("REID_F16_SETAIL")) c->f16_se_tail = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_C64")) c->f16_c64 = atoi(e);   // 0 implicit GEMM, 1 layer-1 kernel, 2 + fused SE tail
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -600,9 +601,13 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
                                  k.ds_shift, nullptr, 0, nullptr, sc));
             shortcut = sc;
         }
-        REID_TRY(launch_se_finalize(ctx, stats, n, c64 ? 1 : tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, se));
         f16* out = c1;
-        REID_TRY(launch_se_combine_f16(ctx, y, shortcut, se, n, hw, k.c, out));
+        if (ctx->f16_se_tail) {
+            REID_TRY(launch_se_tail_f16(ctx, stats, n, c64 ? 1 : tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, y, shortcut, out));
+        } else {
+            REID_TRY(launch_se_finalize(ctx, stats, n, c64 ? 1 : tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, se));
+            REID_TRY(launch_se_combine_f16(ctx, y, shortcut, se, n, hw, k.c, out));
+        }
         stage[2 + i] = (float*)out;
         cur = out;
         H = Ho;

@@ -205,6 +205,60 @@ int launch_affine_relu_f16(reid_ctx* ctx, f16* x, const float* a, const float* b
     LAUNCH_CHECK();
     return REID_OK;
 }
+// SE gate + combine of one SE block in one launch (SERes18_IBN.py:32-41 + :120-128): block = image.  Phase 1 is se_finalize
+// (pooled mean from the conv2 epilogue's partial sums -> 8..32 hidden units -> sigmoid gate, kept in LDS), phase 2 streams the
+// image: out = relu(gate * y + shortcut).  Several blocks per CU overlap one image's gate with another's streaming.
+__global__ __launch_bounds__(256) void se_tail_f16_kernel(const float* __restrict__ stats, int tiles, int c, int mid, int hw,
+                                                          const float* __restrict__ w1, const float* __restrict__ w2t,
+                                                          const f16* __restrict__ y, const f16* __restrict__ sc,
+                                                          f16* __restrict__ out) {
+    __shared__ float pooled[512];
+    __shared__ float hid[64];
+    __shared__ float gate[512];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int ch = tid; ch < c; ch += 256) {
+        double acc = 0.0;
+        for (int t = 0; t < tiles; ++t) acc += (double)stats[(((long long)img * tiles + t) * c + ch) * 2];
+        pooled[ch] = (float)(acc / hw);
+    }
+    __syncthreads();
+    for (int m = wave; m < mid; m += 4) {
+        float acc = 0.f;
+        for (int ch = lane; ch < c; ch += 64) acc += w1[m * c + ch] * pooled[ch];
+        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) hid[m] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 256) {
+        float acc = 0.f;
+        for (int m = 0; m < mid; ++m) acc += w2t[m * c + ch] * hid[m];
+        gate[ch] = 1.0f / (1.0f + expf(-acc));
+    }
+    __syncthreads();
+    const int c8n = c >> 3;
+    const long long base = (long long)img * hw * c;
+    const int total8 = hw * c8n;
+    for (int i = tid; i < total8; i += 256) {
+        const int cc = i % c8n;
+        const half8 yy = *(const half8*)(y + base + (long long)i * 8);
+        const half8 rr = *(const half8*)(sc + base + (long long)i * 8);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf(gate[cc * 8 + e] * (float)yy[e] + (float)rr[e], 0.f);
+        *(half8*)(out + base + (long long)i * 8) = o;
+    }
+}
+
+int launch_se_tail_f16(reid_ctx* ctx, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1,
+                       const float* w2t, const f16* y, const f16* sc, f16* out) {
+    ARG_CHECK(c % 8 == 0 && c <= 512 && mid <= 64);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 6.0);
+    hipLaunchKernelGGL(se_tail_f16_kernel, dim3(n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2t, y, sc, out);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
 int launch_se_combine_f16(reid_ctx* ctx, const f16* y, const f16* sc, const float* s, int n_img, int hw, int c, f16* out) {
     ARG_CHECK(c % 8 == 0);
     const long long total8 = (long long)n_img * hw * (c / 8);

@@ -114,6 +114,8 @@ int launch_prep_u8_pad_f16(reid_ctx*, const uint8_t* crops, int n, int h, int w,
 int launch_prep_f32_pad_f16(reid_ctx*, const float* nhwc3, int n, int h, int w, int hp, int wp, _Float16* out);
 int launch_maxpool3s2_f16(reid_ctx*, const _Float16* x, int n, int h, int w, int c, _Float16* out);
 int launch_affine_relu_f16(reid_ctx*, _Float16* x, const float* a_scale, const float* a_shift, int n_img, int hw, int c);
+int launch_se_tail_f16(reid_ctx*, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1, const float* w2t,
+                       const _Float16* y, const _Float16* sc, _Float16* out);
 int launch_se_combine_f16(reid_ctx*, const _Float16* y, const _Float16* sc, const float* s, int n_img, int hw, int c,
                           _Float16* out);
 int launch_gem_neck_f16(reid_ctx*, const _Float16* x, int n_img, int hw, int c, const float* p, const float* scale,
@@ -201,6 +203,7 @@ struct reid_ctx {
     bool last_f16 = false;
     int f16_loader_waves = 1; // LDS-halo kernel: 8 compute + 4 dedicated loader waves (REID_F16_LOADERS)
     int f16_halo = 1;        // 3x3 stride-1 convs of the fp16 path use the LDS-halo kernel (REID_F16_HALO=0: implicit GEMM)
+    int f16_se_tail = 1;     // fp16 path: SE gate + combine in one launch per block (REID_F16_SETAIL=0: se_finalize + se_combine)
     int f16_c64 = 2;         // fp16 path: layer-1 convs on the register-resident-weight kernel, 2 = with the SE tail fused
                              // into conv2 (REID_F16_C64=1: separate se_finalize / se_combine kernels, 0: implicit GEMM)
     int f16_stem_fused = 2;  // fp16 path: stem conv + BN + maxpool as one kernel, 2 = fed with the uint8 crops directly
