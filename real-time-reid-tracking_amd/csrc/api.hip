@@ -1073,6 +1073,10 @@ extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, 
     const size_t src_n = ctx->se18.n_floats;
     for (size_t o = 0; o < nin; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nin - o < src_n ? nin - o : src_n, x + o));
     for (size_t o = 0; o < nw; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nw - o < src_n ? nw - o : src_n, wt + o));
+    if (getenv("REID_DEBUG_ZERO")) {   // clock experiment: all-zero operands draw less power (DVFS give-back)
+        HIP_TRY(hipMemsetAsync(x, 0, nin * 2, ctx->stream));
+        HIP_TRY(hipMemsetAsync(wt, 0, nw * 2, ctx->stream));
+    }
     const int c0 = ctx->f16_cfg;
     const int h0 = ctx->f16_halo;
     ctx->f16_halo = cfg >= 2000000 ? 2 : 0;   // 2xxxxxx: force the LDS-halo kernel, 2000001: with loader waves
