@@ -526,7 +526,10 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
     REID_TRY(ctx_ws(ctx, "se18.se", (size_t)n * 512 * 4, (void**)&se));
     REID_TRY(ctx_ws(ctx, "se18.gem", (size_t)n * 512 * 4, (void**)&gem));
 
-    const bool fused = ctx->f16_stem_fused && ctx->debug_keep != 1;   // debug_keep 1 keeps the unfused kernels (stage 0 = conv map)
+    // The stem and layer-1 kernels give one whole image to a block: with fewer images than half the CUs (a tracking frame)
+    // the tile-parallel GEMM kernels finish sooner (tools/bench_tracking.py: 758 vs 719 frames/s)
+    const bool per_image_ok = n >= 128 || ctx->debug_keep == 2;
+    const bool fused = ctx->f16_stem_fused && ctx->debug_keep != 1 && per_image_ok;   // debug_keep 1 keeps the unfused kernels (stage 0 = conv map)
     if (is_u8 && fused && ctx->f16_stem_fused == 2) {
         // uint8 crops straight into the fused stem: normalisation and zero padding happen while its LDS ring is filled
         REID_TRY(launch_stem_pool_f16(ctx, nullptr, (const uint8_t*)x, n, w.stem_w16s, w.stem_shift, pool));
@@ -561,7 +564,7 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
         const int hw = Ho * Wo, tiles = hw / 128;
         const int half = k.ibn ? k.c / 2 : 0;
         // layer 1 (64 -> 64 on 64 x 32): register-resident-weight kernel, statistics per image (tiles = 1)
-        const bool c64 = ctx->f16_c64 && i < 2 && conv3x3_c64_f16_supported(H, W, k.cin, k.c, 3, 3, k.stride, 1) && !k.ds;
+        const bool c64 = ctx->f16_c64 && per_image_ok && i < 2 && conv3x3_c64_f16_supported(H, W, k.cin, k.c, 3, 3, k.stride, 1) && !k.ds;
         if (c64) {
             REID_TRY(launch_conv3x3_c64_f16(ctx, cur, n, w.h(k.conv1_w), nullptr, nullptr, 0, stats, c1, w.zero_page));
             REID_TRY(launch_norm_finalize(ctx, stats, n, 1, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift,
