@@ -605,7 +605,7 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
             shortcut = sc;
         }
         f16* out = c1;
-        if (ctx->f16_se_tail) {
+        if (ctx->f16_se_tail && per_image_ok) {   // one block per image: only with enough images to fill the chip
             REID_TRY(launch_se_tail_f16(ctx, stats, n, c64 ? 1 : tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, y, shortcut, out));
         } else {
             REID_TRY(launch_se_finalize(ctx, stats, n, c64 ? 1 : tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, se));

@@ -396,7 +396,8 @@ template <int TW, int IMGS, int LW>
 int launch_geom(reid_ctx* ctx, const Gemm16Params& p) {
     const int nmt = (p.M + 255) / 256;
     const int threads = LW ? 768 : 512;
-    if (p.N % 128 == 0) {
+    // few M tiles (a tracking frame): 64-wide N tiles put twice as many blocks on the chip
+    if (p.N % 128 == 0 && (long long)nmt * (p.N / 128) >= 128) {
         hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW>), dim3(nmt * (p.N / 128)), dim3(threads), 0, ctx->stream, p);
     } else {
         hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64, LW>), dim3(nmt * (p.N / 64)), dim3(threads), 0, ctx->stream, p);
