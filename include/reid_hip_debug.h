@@ -1,0 +1,36 @@
+/* Experiment and correctness-harness entry points of libreid_hip_debug.so (built from csrc/debug.hip + csrc/microbench.hip,
+ * linked on top of libreid_hip.so).  NOT part of the drop-in C ABI of include/reid_hip.h: nothing the reference's callers
+ * would bind lives here.  Used by tools/*.py (kernel A/B timing, feed / MFMA-shape microbenchmarks) and by one parity test
+ * of the layer-1 fp16 convolution kernel.  All functions return a reid_hip.h status code. */
+#pragma once
+#include "reid_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Times `iters` launches of one fp16-storage implicit-GEMM convolution (SERes18_IBN.py:120-128 shapes) on random device
+ * data; cfg = BN*1000 + BK*10 + NST, 2000000 / 2000001 = LDS-halo kernel without / with loader waves. */
+int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int cfg, int iters,
+                        float* ms_per_launch);
+/* The same for the exact-fp32 convolutions.  flags: 1 fused input affine + ReLU, 2 BN epilogue, 4 residual + ReLU,
+ * 8 statistics; variant 0 = gemm_f32_kernel<A_IM2COL>, 1 = conv_f32.hip. */
+int reid_debug_conv_f32(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int flags,
+                        int variant, int iters, float* ms_per_launch);
+/* Correctness harness of conv3x3_c64_f16.hip: fp32 host operands are rounded to f16, one launch, fp32 results back. */
+int reid_debug_conv_c64(reid_ctx* ctx, int n, const float* x, const float* w_krsc, const float* scale, const float* shift,
+                        const float* residual, int relu, float* out, float* stats);
+/* Times one dense fp16 GEMM C[m][n] = A[m][k] . B[n][k]^T; diag_host: optional [64*8*4] per-wave cycle sums. */
+int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, int iters, float* ms_per_launch,
+                        unsigned long long* diag_host);
+/* Switches the s_memtime stamps of the loader-wave conv kernel on / off (out_host [64*8*5] when disabling). */
+int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long long* out_host);
+/* Bare MFMA loop with fragments re-read from LDS (shape 32 = 32x32x16 f16, 16 = 16x16x32 f16). */
+int reid_debug_mfma_shape(reid_ctx* ctx, int shape, int iters, int blocks, float* tflops);
+/* Operand-feed microbenchmark: rows of `rowb` bytes at `stride` from a `footprint`-byte buffer, LDS-DMA or register loads. */
+int reid_debug_feed(reid_ctx* ctx, int mode, size_t footprint, int rowb, size_t stride, int iters, int inflight,
+                    float* gbs_per_cu, float* tbs_chip);
+
+#ifdef __cplusplus
+}
+#endif

@@ -76,7 +76,12 @@ _SIGS = {
 }
 EXPORTS = tuple(sorted(_SIGS))
 
+DEBUG_LIB_PATH = os.path.join(_HERE, "libreid_hip_debug.so")
+DEBUG_EXPORTS = ("reid_debug_conv_c64", "reid_debug_conv_diag", "reid_debug_conv_f16", "reid_debug_conv_f32",
+                 "reid_debug_feed", "reid_debug_gemm_f16", "reid_debug_mfma_shape")   # include/reid_hip_debug.h
+
 _lib = None
+_dbg = None
 
 
 class ReidHipError(RuntimeError):
@@ -91,13 +96,24 @@ def lib():
             raise ReidHipError(
                 "HIP extension missing: %s (build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C real-time-reid-tracking_amd/csrc`); there is no CPU fallback" % LIB_PATH)
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+def debug_lib():
+    """libreid_hip_debug.so (experiments + harnesses, include/reid_hip_debug.h); loads the product library first."""
+    global _dbg
+    if _dbg is None:
+        lib()
+        if not os.path.exists(DEBUG_LIB_PATH):
+            raise ReidHipError("debug library missing: %s (make -C real-time-reid-tracking_amd/csrc)" % DEBUG_LIB_PATH)
+        _dbg = C.CDLL(DEBUG_LIB_PATH)
+    return _dbg
 
 
 def check(status):

@@ -37,6 +37,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     reid_ctx* c = new reid_ctx();
     c->device = device;
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
+    if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
     if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e);   // 0 GEMM + pool, 1 fused, 2 fused reading uint8 crops
@@ -353,7 +354,7 @@ extern "C" int reid_seres18_dims(reid_ctx* ctx, int* embed_dim, int* num_class) 
 // ------------------------------------------------------------------------------------------------ forward
 static const int IMG_H = 256, IMG_W = 128;
 
-static int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
+int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
                      int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
                      const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats,
                      float* out) {
@@ -372,6 +373,7 @@ static int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int 
     const double flops = 2.0 * p.M * Cout * ktrue;
     const double in_bytes = (double)n * H * W * Cin * (amode == A_STEM_U8 ? 1.0 : 4.0);
     const double bytes = in_bytes + ((double)p.M * Cout + (double)Cout * ktrue) * 4.0 + (residual ? (double)p.M * Cout * 4.0 : 0.0);
+    if (amode == A_IM2COL && ctx->f32_conv && conv_f32_supported(p)) return launch_conv_f32(ctx, p, REID_K_CONV_GEMM, flops, bytes);
     return launch_gemm_f32(ctx, amode, E_CONV, p, REID_K_CONV_GEMM, flops, bytes);
 }
 
@@ -473,10 +475,9 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
 }
 
 // ------------------------------------------------------------------------------------------------ fp16 forward
-static unsigned long long* g_conv_diag = nullptr;   // experiments: stamps of the loader-wave conv kernel
-static int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H, int W, int Cin, const _Float16* wgt, int Cout,
+int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H, int W, int Cin, const _Float16* wgt, int Cout,
                        int R, int S, int stride, int pad, int K, const float* col_scale, const float* col_shift,
-                       const _Float16* residual, int relu, float* stats, _Float16* out, int Hp = 0, int Wp = 0) {
+                       const _Float16* residual, int relu, float* stats, _Float16* out, int Hp, int Wp) {
     Gemm16Params p;
     memset(&p, 0, sizeof(p));
     p.A = x;
@@ -488,7 +489,7 @@ static int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H
     p.C = out; p.ldc = Cout;
     p.col_scale = col_scale; p.col_shift = col_shift; p.residual = residual; p.relu = relu; p.stats = stats;
     p.zero_page = ctx->se18.zero_page;
-    p.diag = g_conv_diag;
+    p.diag = ctx->conv_diag;
     const double ktrue = (double)R * S * (amode == A16_STEM ? 3 : Cin);
     const double flops = 2.0 * p.M * Cout * ktrue;
     const double bytes = ((double)n * H * W * (amode == A16_STEM ? 4 : Cin) + (double)p.M * Cout + (double)Cout * ktrue +
@@ -1060,143 +1061,3 @@ extern "C" int reid_gemm_nt(reid_ctx* ctx, const float* a, int m, const float* b
 }
 
 
-// ------------------------------------------------------------------------------------------------ kernel experiments
-// Times `iters` launches of one fp16 implicit-GEMM convolution on random device data (not part of the public header).
-extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int cfg,
-                                   int iters, float* ms_per_launch) {
-    ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded);
-    typedef _Float16 f16;
-    const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - r) / stride + 1;
-    const size_t nin = (size_t)n * h * w * cin, nw = (size_t)cout * r * r * cin, nout = (size_t)n * ho * wo * cout;
-    f16 *x, *wt, *out;
-    REID_TRY(ctx_ws(ctx, "dbg.x", nin * 2, (void**)&x));
-    REID_TRY(ctx_ws(ctx, "dbg.w", nw * 2, (void**)&wt));
-    REID_TRY(ctx_ws(ctx, "dbg.out", nout * 2, (void**)&out));
-    // random-ish operands: the loaded weight blob (f32 -> f16), cycled
-    const size_t src_n = ctx->se18.n_floats;
-    for (size_t o = 0; o < nin; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nin - o < src_n ? nin - o : src_n, x + o));
-    for (size_t o = 0; o < nw; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nw - o < src_n ? nw - o : src_n, wt + o));
-    if (getenv("REID_DEBUG_ZERO")) {   // clock experiment: all-zero operands draw less power (DVFS give-back)
-        HIP_TRY(hipMemsetAsync(x, 0, nin * 2, ctx->stream));
-        HIP_TRY(hipMemsetAsync(wt, 0, nw * 2, ctx->stream));
-    }
-    const int c0 = ctx->f16_cfg;
-    const int h0 = ctx->f16_halo;
-    ctx->f16_halo = cfg >= 2000000 ? 2 : 0;   // 2xxxxxx: force the LDS-halo kernel, 2000001: with loader waves
-    const int l0 = ctx->f16_loader_waves;
-    if (cfg >= 2000000) ctx->f16_loader_waves = cfg & 1;
-    ctx->f16_cfg = cfg >= 2000000 ? 0 : cfg;
-    int st = REID_OK;
-    for (int i = 0; i < 2 && st == REID_OK; ++i)
-        st = conv_gemm16(ctx, A16_IM2COL, x, n, h, w, cin, wt, cout, r, r, stride, pad, r * r * cin, nullptr, nullptr, nullptr, 0, nullptr, out);
-    if (st == REID_OK) st = reid_timer_start(ctx);
-    for (int i = 0; i < iters && st == REID_OK; ++i)
-        st = conv_gemm16(ctx, A16_IM2COL, x, n, h, w, cin, wt, cout, r, r, stride, pad, r * r * cin, nullptr, nullptr, nullptr, 0, nullptr, out);
-    float ms = 0.f;
-    if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
-    ctx->f16_cfg = c0;
-    ctx->f16_halo = h0;
-    ctx->f16_loader_waves = l0;
-    *ms_per_launch = ms / (iters > 0 ? iters : 1);
-    return st;
-}
-
-
-// Correctness harness for conv3x3_c64_f16.hip (tests only, not part of the C ABI): fp32 host operands are rounded to f16,
-// the kernel runs once, the f16 result and the fp32 per-image statistics come back as fp32.
-extern "C" int reid_debug_conv_c64(reid_ctx* ctx, int n, const float* x, const float* w_krsc, const float* scale,
-                                   const float* shift, const float* residual, int relu, float* out, float* stats) {
-    ARG_CHECK(ctx && x && w_krsc && out && n >= 1);
-    typedef _Float16 f16;
-    const size_t nact = (size_t)n * 64 * 32 * 64, nw = 64 * 576;
-    float *xf, *wf, *rf = nullptr, *sc = nullptr, *sh = nullptr, *st = nullptr, *of;
-    f16 *xh, *wh, *rh = nullptr, *oh, *zp;
-    REID_TRY(ctx_ws(ctx, "dbg64.xf", nact * 4, (void**)&xf));
-    REID_TRY(ctx_ws(ctx, "dbg64.wf", nw * 4, (void**)&wf));
-    REID_TRY(ctx_ws(ctx, "dbg64.xh", nact * 2, (void**)&xh));
-    REID_TRY(ctx_ws(ctx, "dbg64.wh", nw * 2, (void**)&wh));
-    REID_TRY(ctx_ws(ctx, "dbg64.oh", nact * 2, (void**)&oh));
-    REID_TRY(ctx_ws(ctx, "dbg64.of", nact * 4, (void**)&of));
-    REID_TRY(ctx_ws(ctx, "dbg64.zp", 256, (void**)&zp));
-    REID_TRY(ctx_ws(ctx, "dbg64.sc", 64 * 4, (void**)&sc));
-    REID_TRY(ctx_ws(ctx, "dbg64.sh", 64 * 4, (void**)&sh));
-    REID_TRY(ctx_ws(ctx, "dbg64.st", (size_t)n * 128 * 4, (void**)&st));
-    HIP_TRY(hipMemsetAsync(zp, 0, 256, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(xf, x, nact * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(wf, w_krsc, nw * 4, hipMemcpyHostToDevice, ctx->stream));
-    std::vector<float> ones(64, 1.f);
-    HIP_TRY(hipMemcpyAsync(sc, scale ? scale : ones.data(), 64 * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (shift) HIP_TRY(hipMemcpyAsync(sh, shift, 64 * 4, hipMemcpyHostToDevice, ctx->stream));
-    REID_TRY(launch_f32_to_f16(ctx, xf, nact, xh));
-    REID_TRY(launch_scale_rows_f16(ctx, wf, sc, 64, 576, wh));
-    if (residual) {
-        REID_TRY(ctx_ws(ctx, "dbg64.rf", nact * 4, (void**)&rf));
-        REID_TRY(ctx_ws(ctx, "dbg64.rh", nact * 2, (void**)&rh));
-        HIP_TRY(hipMemcpyAsync(rf, residual, nact * 4, hipMemcpyHostToDevice, ctx->stream));
-        REID_TRY(launch_f32_to_f16(ctx, rf, nact, rh));
-    }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // `ones` is a local
-    REID_TRY(launch_conv3x3_c64_f16(ctx, xh, n, wh, shift ? sh : nullptr, rh, relu, stats ? st : nullptr, oh, zp));
-    std::vector<f16> tmp(nact);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), oh, nact * 2, hipMemcpyDeviceToHost, ctx->stream));
-    if (stats) HIP_TRY(hipMemcpyAsync(stats, st, (size_t)n * 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i < nact; ++i) out[i] = (float)tmp[i];
-    return REID_OK;
-}
-
-// Times one dense fp16 GEMM C[m][n] = A[m][k] . B[n][k]^T (experiments: separates the im2col gather from the tile loop).
-extern "C" int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, int iters, float* ms_per_launch,
-                                   unsigned long long* diag_host /* [64*8*4] or NULL */) {
-    ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded);
-    unsigned long long* d_diag = nullptr;
-    if (diag_host) {
-        REID_TRY(ctx_ws(ctx, "dbg.diag", 64 * 8 * 4 * 8, (void**)&d_diag));
-        HIP_TRY(hipMemsetAsync(d_diag, 0, 64 * 8 * 4 * 8, ctx->stream));
-    }
-    typedef _Float16 f16;
-    f16 *a, *b, *c;
-    REID_TRY(ctx_ws(ctx, "dbg.x", (size_t)m * k * 2, (void**)&a));
-    REID_TRY(ctx_ws(ctx, "dbg.w", (size_t)n * k * 2, (void**)&b));
-    REID_TRY(ctx_ws(ctx, "dbg.out", (size_t)m * n * 2, (void**)&c));
-    const size_t src_n = ctx->se18.n_floats;
-    for (size_t o = 0; o < (size_t)m * k; o += src_n)
-        REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, (size_t)m * k - o < src_n ? (size_t)m * k - o : src_n, a + o));
-    for (size_t o = 0; o < (size_t)n * k; o += src_n)
-        REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, (size_t)n * k - o < src_n ? (size_t)n * k - o : src_n, b + o));
-    Gemm16Params p;
-    memset(&p, 0, sizeof(p));
-    p.A = a; p.lda = k; p.B = b; p.ldb = k; p.M = m; p.N = n; p.K = k; p.C = c; p.ldc = n;
-    p.zero_page = ctx->se18.zero_page;
-    p.diag = d_diag;
-    const int c0 = ctx->f16_cfg;
-    ctx->f16_cfg = cfg;
-    int st = REID_OK;
-    for (int i = 0; i < 2 && st == REID_OK; ++i) st = launch_gemm_f16(ctx, A16_DENSE, p, REID_K_CONV_GEMM, 0, 0);
-    if (st == REID_OK) st = reid_timer_start(ctx);
-    for (int i = 0; i < iters && st == REID_OK; ++i) st = launch_gemm_f16(ctx, A16_DENSE, p, REID_K_CONV_GEMM, 0, 0);
-    float ms = 0.f;
-    if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
-    ctx->f16_cfg = c0;
-    *ms_per_launch = ms / (iters > 0 ? iters : 1);
-    if (st == REID_OK && diag_host) {
-        HIP_TRY(hipMemcpyAsync(diag_host, d_diag, 64 * 8 * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    return st;
-}
-
-extern "C" int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long long* out_host /* [64*8*4] when disabling */) {
-    ARG_CHECK(ctx);
-    if (enable) {
-        REID_TRY(ctx_ws(ctx, "dbg.cdiag", 64 * 8 * 5 * 8, (void**)&g_conv_diag));
-        HIP_TRY(hipMemsetAsync(g_conv_diag, 0, 64 * 8 * 5 * 8, ctx->stream));
-    } else {
-        if (out_host && g_conv_diag) {
-            HIP_TRY(hipMemcpyAsync(out_host, g_conv_diag, 64 * 8 * 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        }
-        g_conv_diag = nullptr;
-    }
-    return REID_OK;
-}

@@ -1,0 +1,195 @@
+// Kernel experiments and correctness harnesses (include/reid_hip_debug.h).  Built into libreid_hip_debug.so, which links
+// against libreid_hip.so: nothing here is part of the product library or of the drop-in C ABI.
+#include "reid_internal.h"
+#include <string.h>
+#include <stdlib.h>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------ kernel experiments
+// Times `iters` launches of one fp16 implicit-GEMM convolution on random device data (not part of the public header).
+extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int cfg,
+                                   int iters, float* ms_per_launch) {
+    ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded);
+    typedef _Float16 f16;
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - r) / stride + 1;
+    const size_t nin = (size_t)n * h * w * cin, nw = (size_t)cout * r * r * cin, nout = (size_t)n * ho * wo * cout;
+    f16 *x, *wt, *out;
+    REID_TRY(ctx_ws(ctx, "dbg.x", nin * 2, (void**)&x));
+    REID_TRY(ctx_ws(ctx, "dbg.w", nw * 2, (void**)&wt));
+    REID_TRY(ctx_ws(ctx, "dbg.out", nout * 2, (void**)&out));
+    // random-ish operands: the loaded weight blob (f32 -> f16), cycled
+    const size_t src_n = ctx->se18.n_floats;
+    for (size_t o = 0; o < nin; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nin - o < src_n ? nin - o : src_n, x + o));
+    for (size_t o = 0; o < nw; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nw - o < src_n ? nw - o : src_n, wt + o));
+    if (getenv("REID_DEBUG_ZERO")) {   // clock experiment: all-zero operands draw less power (DVFS give-back)
+        HIP_TRY(hipMemsetAsync(x, 0, nin * 2, ctx->stream));
+        HIP_TRY(hipMemsetAsync(wt, 0, nw * 2, ctx->stream));
+    }
+    const int c0 = ctx->f16_cfg;
+    const int h0 = ctx->f16_halo;
+    ctx->f16_halo = cfg >= 2000000 ? 2 : 0;   // 2xxxxxx: force the LDS-halo kernel, 2000001: with loader waves
+    const int l0 = ctx->f16_loader_waves;
+    if (cfg >= 2000000) ctx->f16_loader_waves = cfg & 1;
+    ctx->f16_cfg = cfg >= 2000000 ? 0 : cfg;
+    int st = REID_OK;
+    for (int i = 0; i < 2 && st == REID_OK; ++i)
+        st = conv_gemm16(ctx, A16_IM2COL, x, n, h, w, cin, wt, cout, r, r, stride, pad, r * r * cin, nullptr, nullptr, nullptr, 0, nullptr, out);
+    if (st == REID_OK) st = reid_timer_start(ctx);
+    for (int i = 0; i < iters && st == REID_OK; ++i)
+        st = conv_gemm16(ctx, A16_IM2COL, x, n, h, w, cin, wt, cout, r, r, stride, pad, r * r * cin, nullptr, nullptr, nullptr, 0, nullptr, out);
+    float ms = 0.f;
+    if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
+    ctx->f16_cfg = c0;
+    ctx->f16_halo = h0;
+    ctx->f16_loader_waves = l0;
+    *ms_per_launch = ms / (iters > 0 ? iters : 1);
+    return st;
+}
+
+
+// Correctness harness for conv3x3_c64_f16.hip (tests only, not part of the C ABI): fp32 host operands are rounded to f16,
+// the kernel runs once, the f16 result and the fp32 per-image statistics come back as fp32.
+extern "C" int reid_debug_conv_c64(reid_ctx* ctx, int n, const float* x, const float* w_krsc, const float* scale,
+                                   const float* shift, const float* residual, int relu, float* out, float* stats) {
+    ARG_CHECK(ctx && x && w_krsc && out && n >= 1);
+    typedef _Float16 f16;
+    const size_t nact = (size_t)n * 64 * 32 * 64, nw = 64 * 576;
+    float *xf, *wf, *rf = nullptr, *sc = nullptr, *sh = nullptr, *st = nullptr, *of;
+    f16 *xh, *wh, *rh = nullptr, *oh, *zp;
+    REID_TRY(ctx_ws(ctx, "dbg64.xf", nact * 4, (void**)&xf));
+    REID_TRY(ctx_ws(ctx, "dbg64.wf", nw * 4, (void**)&wf));
+    REID_TRY(ctx_ws(ctx, "dbg64.xh", nact * 2, (void**)&xh));
+    REID_TRY(ctx_ws(ctx, "dbg64.wh", nw * 2, (void**)&wh));
+    REID_TRY(ctx_ws(ctx, "dbg64.oh", nact * 2, (void**)&oh));
+    REID_TRY(ctx_ws(ctx, "dbg64.of", nact * 4, (void**)&of));
+    REID_TRY(ctx_ws(ctx, "dbg64.zp", 256, (void**)&zp));
+    REID_TRY(ctx_ws(ctx, "dbg64.sc", 64 * 4, (void**)&sc));
+    REID_TRY(ctx_ws(ctx, "dbg64.sh", 64 * 4, (void**)&sh));
+    REID_TRY(ctx_ws(ctx, "dbg64.st", (size_t)n * 128 * 4, (void**)&st));
+    HIP_TRY(hipMemsetAsync(zp, 0, 256, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(xf, x, nact * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(wf, w_krsc, nw * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<float> ones(64, 1.f);
+    HIP_TRY(hipMemcpyAsync(sc, scale ? scale : ones.data(), 64 * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (shift) HIP_TRY(hipMemcpyAsync(sh, shift, 64 * 4, hipMemcpyHostToDevice, ctx->stream));
+    REID_TRY(launch_f32_to_f16(ctx, xf, nact, xh));
+    REID_TRY(launch_scale_rows_f16(ctx, wf, sc, 64, 576, wh));
+    if (residual) {
+        REID_TRY(ctx_ws(ctx, "dbg64.rf", nact * 4, (void**)&rf));
+        REID_TRY(ctx_ws(ctx, "dbg64.rh", nact * 2, (void**)&rh));
+        HIP_TRY(hipMemcpyAsync(rf, residual, nact * 4, hipMemcpyHostToDevice, ctx->stream));
+        REID_TRY(launch_f32_to_f16(ctx, rf, nact, rh));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // `ones` is a local
+    REID_TRY(launch_conv3x3_c64_f16(ctx, xh, n, wh, shift ? sh : nullptr, rh, relu, stats ? st : nullptr, oh, zp));
+    std::vector<f16> tmp(nact);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), oh, nact * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (stats) HIP_TRY(hipMemcpyAsync(stats, st, (size_t)n * 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < nact; ++i) out[i] = (float)tmp[i];
+    return REID_OK;
+}
+
+// Times one dense fp16 GEMM C[m][n] = A[m][k] . B[n][k]^T (experiments: separates the im2col gather from the tile loop).
+extern "C" int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, int iters, float* ms_per_launch,
+                                   unsigned long long* diag_host /* [64*8*4] or NULL */) {
+    ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded);
+    unsigned long long* d_diag = nullptr;
+    if (diag_host) {
+        REID_TRY(ctx_ws(ctx, "dbg.diag", 64 * 8 * 4 * 8, (void**)&d_diag));
+        HIP_TRY(hipMemsetAsync(d_diag, 0, 64 * 8 * 4 * 8, ctx->stream));
+    }
+    typedef _Float16 f16;
+    f16 *a, *b, *c;
+    REID_TRY(ctx_ws(ctx, "dbg.x", (size_t)m * k * 2, (void**)&a));
+    REID_TRY(ctx_ws(ctx, "dbg.w", (size_t)n * k * 2, (void**)&b));
+    REID_TRY(ctx_ws(ctx, "dbg.out", (size_t)m * n * 2, (void**)&c));
+    const size_t src_n = ctx->se18.n_floats;
+    for (size_t o = 0; o < (size_t)m * k; o += src_n)
+        REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, (size_t)m * k - o < src_n ? (size_t)m * k - o : src_n, a + o));
+    for (size_t o = 0; o < (size_t)n * k; o += src_n)
+        REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, (size_t)n * k - o < src_n ? (size_t)n * k - o : src_n, b + o));
+    Gemm16Params p;
+    memset(&p, 0, sizeof(p));
+    p.A = a; p.lda = k; p.B = b; p.ldb = k; p.M = m; p.N = n; p.K = k; p.C = c; p.ldc = n;
+    p.zero_page = ctx->se18.zero_page;
+    p.diag = d_diag;
+    const int c0 = ctx->f16_cfg;
+    ctx->f16_cfg = cfg;
+    int st = REID_OK;
+    for (int i = 0; i < 2 && st == REID_OK; ++i) st = launch_gemm_f16(ctx, A16_DENSE, p, REID_K_CONV_GEMM, 0, 0);
+    if (st == REID_OK) st = reid_timer_start(ctx);
+    for (int i = 0; i < iters && st == REID_OK; ++i) st = launch_gemm_f16(ctx, A16_DENSE, p, REID_K_CONV_GEMM, 0, 0);
+    float ms = 0.f;
+    if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
+    ctx->f16_cfg = c0;
+    *ms_per_launch = ms / (iters > 0 ? iters : 1);
+    if (st == REID_OK && diag_host) {
+        HIP_TRY(hipMemcpyAsync(diag_host, d_diag, 64 * 8 * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return st;
+}
+
+extern "C" int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long long* out_host /* [64*8*4] when disabling */) {
+    ARG_CHECK(ctx);
+    if (enable) {
+        REID_TRY(ctx_ws(ctx, "dbg.cdiag", 64 * 8 * 5 * 8, (void**)&ctx->conv_diag));
+        HIP_TRY(hipMemsetAsync(ctx->conv_diag, 0, 64 * 8 * 5 * 8, ctx->stream));
+    } else {
+        if (out_host && ctx->conv_diag) {
+            HIP_TRY(hipMemcpyAsync(out_host, ctx->conv_diag, 64 * 8 * 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        ctx->conv_diag = nullptr;
+    }
+    return REID_OK;
+}
+
+// Times `iters` launches of one exact-fp32 convolution of the ResNet18-SE path on random device data.
+// flags: 1 = fused input affine + ReLU (conv2 of an SE block), 2 = BN scale/shift epilogue, 4 = residual + ReLU, 8 = statistics.
+// variant: 0 = gemm_f32_kernel<A_IM2COL> (round-1 kernel), 1 = conv_f32.hip.
+extern "C" int reid_debug_conv_f32(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int flags,
+                                   int variant, int iters, float* ms_per_launch) {
+    ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded && n >= 1);
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - r) / stride + 1;
+    const size_t nin = (size_t)n * h * w * cin, nw = (size_t)cout * r * r * cin, nout = (size_t)n * ho * wo * cout;
+    float *x, *wt, *out, *res, *asc, *ash, *stats;
+    REID_TRY(ctx_ws(ctx, "dbg32.x", nin * 4, (void**)&x));
+    REID_TRY(ctx_ws(ctx, "dbg32.w", nw * 4, (void**)&wt));
+    REID_TRY(ctx_ws(ctx, "dbg32.out", nout * 4, (void**)&out));
+    REID_TRY(ctx_ws(ctx, "dbg32.res", nout * 4, (void**)&res));
+    REID_TRY(ctx_ws(ctx, "dbg32.asc", (size_t)n * cin * 4, (void**)&asc));
+    REID_TRY(ctx_ws(ctx, "dbg32.ash", (size_t)n * cin * 4, (void**)&ash));
+    REID_TRY(ctx_ws(ctx, "dbg32.stats", (size_t)n * 2048 * 4 * 16, (void**)&stats));
+    // random-ish operands: the loaded weight blob, cycled
+    const size_t src_n = ctx->se18.n_floats;
+    auto fill = [&](float* dst, size_t cnt) -> int {
+        for (size_t o = 0; o < cnt; o += src_n)
+            HIP_TRY(hipMemcpyAsync(dst + o, ctx->se18.blob, (cnt - o < src_n ? cnt - o : src_n) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return REID_OK;
+    };
+    REID_TRY(fill(x, nin));
+    REID_TRY(fill(wt, nw));
+    REID_TRY(fill(res, nout));
+    REID_TRY(fill(asc, (size_t)n * cin));
+    REID_TRY(fill(ash, (size_t)n * cin));
+    const int v0 = ctx->f32_conv;
+    ctx->f32_conv = variant;
+    const float* cs = (flags & 2) ? ctx->se18.neck_scale : nullptr;   // any 512 floats
+    const float* sh = (flags & 2) ? ctx->se18.neck_shift : nullptr;
+    auto run = [&]() {
+        return conv_gemm(ctx, A_IM2COL, x, n, h, w, cin, wt, cout, r, r, stride, pad, r * r * cin, (flags & 1) ? asc : nullptr,
+                         (flags & 1) ? ash : nullptr, (flags & 1), cs, sh, (flags & 4) ? res : nullptr, (flags & 4) ? 1 : 0,
+                         (flags & 8) ? stats : nullptr, out);
+    };
+    int st = REID_OK;
+    for (int i = 0; i < 2 && st == REID_OK; ++i) st = run();
+    if (st == REID_OK) st = reid_timer_start(ctx);
+    for (int i = 0; i < iters && st == REID_OK; ++i) st = run();
+    float ms = 0.f;
+    if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
+    ctx->f32_conv = v0;
+    *ms_per_launch = ms / (iters > 0 ? iters : 1);
+    return st;
+}

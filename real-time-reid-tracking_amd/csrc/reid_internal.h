@@ -132,6 +132,8 @@ int launch_stem_pool_f16(reid_ctx*, const _Float16* pad_in, const uint8_t* crops
                          _Float16* pooled);
 int launch_conv_w16_chunked(reid_ctx*, const float* w_f32, int cout, int rs, int cin, _Float16* out);  // -> [Cout][Cin/64][RS][64]   // [64][8][24] -> [64][8][8][4]
 int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int kind, double flops, double bytes);
+bool conv_f32_supported(const GemmParams& p);   // conv_f32.hip: pipelined implicit-GEMM convolution of the fp32 path (full tiles)
+int launch_conv_f32(reid_ctx* ctx, const GemmParams& p, int kind, double flops, double bytes);
 
 // elementwise / reduction kernels (elementwise.hip)
 int launch_nchw_to_nhwc3(reid_ctx*, const float* x_nchw, int n, int h, int w, float* out_nhwc);
@@ -208,10 +210,19 @@ struct reid_ctx {
                              // into conv2 (REID_F16_C64=1: separate se_finalize / se_combine kernels, 0: implicit GEMM)
     int f16_stem_fused = 2;  // fp16 path: stem conv + BN + maxpool as one kernel, 2 = fed with the uint8 crops directly
                              // (REID_F16_STEMPOOL=1: from the padded f16 image, 0: GEMM + pool kernels)
+    int f32_conv = 1;        // fp32 path: 1 = conv_f32.hip (pipelined, double-buffered LDS), 0 = gemm_f32_kernel<A_IM2COL> (REID_F32_CONV)
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
     float* stage_ptr[11] = {nullptr};
+    unsigned long long* conv_diag = nullptr;   // experiments (debug.hip): stamps of the loader-wave conv kernel
 };
 
+// convolution launchers of the two arithmetic modes (api.hip); also used by the experiment harnesses in debug.hip
+int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
+              int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
+              const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats, float* out);
+int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H, int W, int Cin, const _Float16* wgt, int Cout,
+                int R, int S, int stride, int pad, int K, const float* col_scale, const float* col_shift,
+                const _Float16* residual, int relu, float* stats, _Float16* out, int Hp = 0, int Wp = 0);
 void swin_release(reid_ctx* ctx);   // frees the Swin weights held for this context (swin.hip)
 int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out);  // grow-only named workspace
 void prof_begin(reid_ctx* ctx, int kind, double flops, double bytes);

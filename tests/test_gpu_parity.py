@@ -511,7 +511,7 @@ def test_f16_fused_stem_pool_matches_unfused_and_oracle(eng_w0):
 # ----------------------------------------------------------------------------- layer-1 kernel (register-resident weights)
 def _conv_c64(eng, x, w, scale=None, shift=None, residual=None, relu=0, want_stats=True):
     import ctypes as C
-    fn = eng.lib.reid_debug_conv_c64
+    fn = _ffi.debug_lib().reid_debug_conv_c64
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
     n = x.shape[0]

@@ -7,13 +7,14 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reid_amd import synth, weights
 from reid_amd.engine import get_engine
+from reid_amd import _ffi
 from reid_amd._ffi import check
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 eng = get_engine(0)
 blob, manifest, _ = weights.pack_seres18(synth.seres18_state_dict(0))
 eng.load_seres18(blob, manifest)
-fn = eng.lib.reid_debug_conv_f16
+fn = _ffi.debug_lib().reid_debug_conv_f16
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_float)]
 layers = [("L1 64->64 64x32", 64, 32, 64, 64), ("L2 128->128 32x16", 32, 16, 128, 128),
@@ -32,7 +33,7 @@ for name, h, w, cin, cout in layers:
     print(name, " ".join("%d:%.0fTF" % (k, flops / (v * 1e-3) / 1e12) for k, v in sorted(best.items(), key=lambda kv: kv[1])))
 
 # dense GEMMs of the same sizes (no im2col gather): separates the gather from the tile loop
-gf = eng.lib.reid_debug_gemm_f16
+gf = _ffi.debug_lib().reid_debug_gemm_f16
 gf.restype = C.c_int
 gf.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(C.c_float), C.c_void_p]
 for name, m, nn, k in (("dense L4-size 32768x512x4608", n * 128, 512, 4608), ("dense 8192x8192x4096", 8192, 8192, 4096),

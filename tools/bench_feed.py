@@ -6,10 +6,11 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reid_amd.engine import get_engine
+from reid_amd import _ffi
 from reid_amd._ffi import check
 
 eng = get_engine(0)
-fn = eng.lib.reid_debug_feed
+fn = _ffi.debug_lib().reid_debug_feed
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
 for fp_name, fp in (("2MB(L2)", 2 << 20), ("24MB(L2 agg)", 24 << 20), ("128MB(MALL)", 128 << 20), ("2GB(HBM)", 2 << 30)):

@@ -6,10 +6,11 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reid_amd.engine import get_engine
+from reid_amd import _ffi
 from reid_amd._ffi import check
 
 eng = get_engine(0)
-fn = eng.lib.reid_debug_mfma_shape
+fn = _ffi.debug_lib().reid_debug_mfma_shape
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
 for blocks in (256, 512):

@@ -8,14 +8,15 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reid_amd import synth, weights
 from reid_amd.engine import get_engine
+from reid_amd import _ffi
 from reid_amd._ffi import check
 
 eng = get_engine(0)
 eng.load_seres18(*weights.pack_seres18(synth.seres18_state_dict(0))[:2])
-fn = eng.lib.reid_debug_conv_f16
+fn = _ffi.debug_lib().reid_debug_conv_f16
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_float)]
-dg = eng.lib.reid_debug_conv_diag
+dg = _ffi.debug_lib().reid_debug_conv_diag
 dg.restype = C.c_int
 dg.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 n = 256

@@ -8,11 +8,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reid_amd import synth, weights
 from reid_amd.engine import get_engine
+from reid_amd import _ffi
 from reid_amd._ffi import check
 
 eng = get_engine(0)
 eng.load_seres18(*weights.pack_seres18(synth.seres18_state_dict(0))[:2])
-gf = eng.lib.reid_debug_gemm_f16
+gf = _ffi.debug_lib().reid_debug_gemm_f16
 gf.restype = C.c_int
 gf.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(C.c_float), C.c_void_p]
 for cfg, bk in ((3256642, 64), (3128643, 64), (3128642, 64), (3256324, 32)):
