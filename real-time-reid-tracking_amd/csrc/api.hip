@@ -64,6 +64,7 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     for (int i = 0; i < 2; ++i)
         if (ctx->se18.l1_conv2_w16s[i]) hipFree(ctx->se18.l1_conv2_w16s[i]);
     if (ctx->se18.zero_page) hipFree(ctx->se18.zero_page);
+    if (ctx->se18.ep) hipFree(ctx->se18.ep);
     for (auto& e : ctx->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& p : ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     hipEventDestroy(ctx->t0);
@@ -266,6 +267,7 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         for (int i = 0; i < 2; ++i)
             if (w.l1_conv2_w16s[i]) HIP_TRY(hipFree(w.l1_conv2_w16s[i]));
         if (w.zero_page) HIP_TRY(hipFree(w.zero_page));
+        if (w.ep) HIP_TRY(hipFree(w.ep));
         w = Se18Weights();
     }
     HIP_TRY(hipMalloc((void**)&w.blob, n_floats * sizeof(float)));
@@ -322,6 +324,19 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         w = Se18Weights();
         return REID_ERR_ARG;
     }
+    {   // conv1 epilogue vectors of the IBN blocks: identity on the InstanceNorm half, folded BatchNorm on the rest
+        std::vector<float> ep(8 * 1024, 0.f);
+        for (int i = 0; i < 8; ++i) {
+            const Se18Block& b = w.blk[i];
+            const int half = b.ibn ? b.c / 2 : 0;
+            for (int ch = 0; ch < b.c; ++ch) {
+                ep[i * 1024 + ch] = ch < half ? 1.f : blob[(b.bn1_scale - w.blob) + (ch - half)];
+                ep[i * 1024 + 512 + ch] = ch < half ? 0.f : blob[(b.bn1_shift - w.blob) + (ch - half)];
+            }
+        }
+        HIP_TRY(hipMalloc((void**)&w.ep, ep.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(w.ep, ep.data(), ep.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     // fp16 copies for the fp16 path: whole blob at the same element offsets + the padded-NHWC4 stem weights
     HIP_TRY(hipMalloc((void**)&w.blob16, n_floats * sizeof(_Float16)));
     HIP_TRY(hipMalloc((void**)&w.stem_w16, 64 * 256 * sizeof(_Float16)));
@@ -357,7 +372,7 @@ static const int IMG_H = 256, IMG_W = 128;
 int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
                      int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
                      const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats,
-                     float* out) {
+                     float* out, int relu_from) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x;
@@ -369,6 +384,8 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
     p.M = n * p.Ho * p.Wo; p.N = Cout; p.K = Kpad;
     p.C = out; p.ldc = Cout;
     p.col_scale = col_scale; p.col_shift = col_shift; p.residual = residual; p.relu = relu; p.stats = stats;
+    p.relu_from = relu_from;
+    p.diag = ctx->conv_diag;
     const double ktrue = (double)R * S * Cin;
     const double flops = 2.0 * p.M * Cout * ktrue;
     const double in_bytes = (double)n * H * W * Cin * (amode == A_STEM_U8 ? 1.0 : 4.0);
@@ -429,6 +446,20 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
         const int Ho = (H + 2 - 3) / k.stride + 1, Wo = (W + 2 - 3) / k.stride + 1;
         const int hw = Ho * Wo, tiles = hw / 128;
         const int half = k.ibn ? k.c / 2 : 0;
+        if (ctx->f32_conv == 1) {
+            // LDS-DMA conv kernel (conv_f32.hip): its loader copies, so bn1 is finished by the producer - the BatchNorm channels
+            // (+ ReLU) in conv1's epilogue, the InstanceNorm half (statistics of the whole image) by one in-place pass
+            if (k.ibn) {
+                REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr,
+                                   0, w.ep + (size_t)i * 1024, w.ep + (size_t)i * 1024 + 512, nullptr, 1, b.stats, c1, half));
+                REID_TRY(launch_in_apply(ctx, c1, b.stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta));
+            } else {
+                REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr,
+                                   0, k.bn1_scale, k.bn1_shift, nullptr, 1, nullptr, c1));
+            }
+            REID_TRY(conv_gemm(ctx, A_IM2COL, c1, n, Ho, Wo, k.c, k.conv2_w, k.c, 3, 3, 1, 1, 9 * k.c, nullptr, nullptr, 0,
+                               k.bn2_scale, k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, b.stats, y));
+        } else {
         // conv1 (raw) + per-(image, channel) sum / sumsq partials for the InstanceNorm half
         REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr, 0,
                            nullptr, nullptr, nullptr, 0, b.stats, c1));
@@ -438,6 +469,7 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
         // downsample: block_pre is the whole BasicBlock_IBN) and SE average-pool partials in its epilogue
         REID_TRY(conv_gemm(ctx, A_IM2COL, c1, n, Ho, Wo, k.c, k.conv2_w, k.c, 3, 3, 1, 1, 9 * k.c, b.a_scale, b.a_shift, 1,
                            k.bn2_scale, k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, b.stats, y));
+        }
         const float* shortcut = cur;
         if (k.ds) {
             REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.ds_w, k.c, 1, 1, k.stride, 0, k.cin, nullptr, nullptr, 0,

@@ -27,8 +27,78 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDP = 36;
 
-template <int BN, bool AFF>
+// ------------------------------------------------------------------ epilogue (full tiles, no predicates)
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// v = acc * col_scale + col_shift (+ residual), ReLU on columns >= relu_from, per-(tile, column) sum / sumsq of the result.
+// stat_lds: [2 (wm)][BN][2] floats of LDS that no wave reads as a tile any more (every wave is past the last barrier).
+template <int BN>
+__device__ __forceinline__ void conv_epilogue(const GemmParams& p, f32x16 (&acc)[2][BN / 64], float* stat_lds, int m_blk, int n_blk,
+                                              int mtile, int tid) {
+    constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const bool has_cs = p.col_scale != nullptr;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int lcol = wn * WN + b * 32 + li;
+        const int col = n_blk + lcol;
+        const float cs = has_cs ? p.col_scale[col] : 1.f;
+        const float sh = has_cs ? p.col_shift[col] : 0.f;
+        const float lo = (p.relu && col >= p.relu_from) ? 0.f : -3.402823466e38f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const long long base = (long long)(m_blk + wm * 64 + a * 32 + 4 * lh) * p.ldc + col;
+            float res[16];
+            if (p.residual) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) res[e] = p.residual[base + (long long)((e & 3) + 8 * (e >> 2)) * p.ldc];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[a][b][e];
+                if (has_cs) v = v * cs + sh;
+                if (p.residual) v += res[e];
+                v = fmaxf(v, lo);
+                s1 += v;
+                s2 += v * v;
+                p.C[base + (long long)((e & 3) + 8 * (e >> 2)) * p.ldc] = v;
+            }
+        }
+        if (p.stats) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lh == 0) {
+                stat_lds[(wm * BN + lcol) * 2 + 0] = s1;
+                stat_lds[(wm * BN + lcol) * 2 + 1] = s2;
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const float t1 = stat_lds[tid * 2 + 0] + stat_lds[(BN + tid) * 2 + 0];
+            const float t2 = stat_lds[tid * 2 + 1] + stat_lds[(BN + tid) * 2 + 1];
+            float* o = p.stats + ((long long)mtile * p.N + n_blk + tid) * 2;
+            o[0] = t1;
+            o[1] = t2;
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long stamp() {   // diagnostic builds only (cdna_hip_programming.md section 7, in-kernel stamps)
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <int BN, bool AFF, int FLAGS>
 __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const GemmParams p) {
+    constexpr bool DIAG = (FLAGS & 1) != 0;   // s_memtime stamps (experiments)
+    constexpr bool PRIO = (FLAGS & 2) != 0;   // raise the wave's priority while it stages the next tile
     constexpr int WN = BN / 2;      // wave tile width
     constexpr int TM = 2;
     constexpr int TN = WN / 32;
@@ -55,19 +125,21 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const GemmParams p) {
     const int rem_blk = m_blk - img * hw;
 
     const int c4 = tid & 7, lrow = tid >> 3;
-    int iy0[4], ix0[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rem = rem_blk + j * 32 + lrow;
+    // rows j*32 + lrow of the tile: Wo divides 32, so the four rows of a thread share ox and sit 32/Wo output rows apart
+    int iy0[4], ix0;
+    {
+        const int rem = rem_blk + lrow;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        iy0[j] = oy * p.stride - p.pad_y;
-        ix0[j] = ox * p.stride - p.pad_x;
+        ix0 = ox * p.stride - p.pad_x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) iy0[j] = (oy + j * (32 / p.Wo)) * p.stride - p.pad_y;
     }
     const float* Aimg = (const float*)p.A + (long long)img * p.H * p.W * p.Cin + c4 * 4;
     const float* Bthr = p.B + (long long)(n_blk + lrow) * p.ldb + c4 * 4;
     const float* sc_ptr = AFF ? p.a_scale + (long long)img * p.Cin + c4 * 4 : nullptr;
     const float* sh_ptr = AFF ? p.a_shift + (long long)img * p.Cin + c4 * 4 : nullptr;
     const int cpt = p.Cin / BK;                     // K-tiles per tap
+    const int wc = p.W * p.Cin;
     const int nk = p.R * p.S * cpt;
 
     // loader state (uniform): the K-tile the next issue_loads() fetches
@@ -77,12 +149,15 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const GemmParams p) {
     auto issue_loads = [&]() {
         const int c0 = l_cc * BK;
         okm = 0;
+        const int ix = ix0 + l_s;
+        const bool okx = (unsigned)ix < (unsigned)p.W;
+        const int xoff = min(max(ix, 0), p.W - 1) * p.Cin + c0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int iy = iy0[j] + l_r, ix = ix0[j] + l_s;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-            ra[j] = *(const f32x4*)(Aimg + (iyc * p.W + ixc) * p.Cin + c0);
+            const int iy = iy0[j] + l_r;
+            const bool ok = okx && (unsigned)iy < (unsigned)p.H;
+            const int iyc = min(max(iy, 0), p.H - 1);
+            ra[j] = *(const f32x4*)(Aimg + iyc * wc + xoff);
             okm |= (ok ? 1u : 0u) << j;
         }
         if constexpr (AFF) {
@@ -148,82 +223,259 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const GemmParams p) {
     store_tile(lds);
     if (nk > 1) issue_loads();
     __syncthreads();
+    unsigned long long dsum[5] = {0, 0, 0, 0, 0};
     for (int kt = 0; kt < nk; ++kt) {
         float* cur = lds + (kt & 1) * TILE;
         float* nxt = lds + ((kt + 1) & 1) * TILE;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+        if constexpr (DIAG) t0 = stamp();
         mfma_half(cur, 0);
+        if constexpr (DIAG) t1 = stamp();
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DIAG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t2 = stamp();
+        }
+        // The staging block is ~100 dependent VALU / LDS / VMEM instructions.  Beside the partner wave's back-to-back MFMAs (two
+        // waves per SIMD, one per resident block) it took 3 000-3 600 cycles per K-tile (tools/diag_conv_f32.py): the partner's
+        // MFMA needs ONE issue slot per 64 cycles, so this wave takes priority while it stages.
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
         if (kt + 1 < nk) {
             store_tile(nxt);                  // tile kt+1: its loads were issued one K-tile ago
             if (kt + 2 < nk) issue_loads();   // tile kt+2: lands behind the next 64 MFMAs
         }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DIAG) t3 = stamp();
         mfma_half(cur, 1);
+        if constexpr (DIAG) t4 = stamp();
         __syncthreads();
+        if constexpr (DIAG) {
+            t5 = stamp();
+            dsum[0] += t1 - t0; dsum[1] += t2 - t1; dsum[2] += t3 - t2; dsum[3] += t4 - t3; dsum[4] += t5 - t4;
+        }
+    }
+    if constexpr (DIAG) {
+        if (p.diag && blockIdx.x < 64 && lane == 0)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p.diag[(blockIdx.x * 8 + wave) * 5 + i] = dsum[i];
     }
 
-    // ------------------------------------------------------------------ epilogue (full tiles, no predicates)
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float* stat_lds = lds;   // [2 (wm)][BN][2]; every wave is past the last barrier, nothing reads the tiles any more
-    const bool has_cs = p.col_scale != nullptr;
+    conv_epilogue<BN>(p, acc, (float*)lds, m_blk, n_blk, mtile, tid);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (no input transform): the kernel every convolution of the fp32 forward runs on.
+//
+// Why: beside the OTHER wave's back-to-back v_mfma_f32_32x32x2_f32 a SIMD issues one VALU instruction per ~19 cycles
+// instead of 3.3 (tools/bench_coissue.py: the fp32 MFMA holds the vector issue port for most of its 64 cycles; s_setprio
+// changes nothing).  The register-staged kernel above spends ~100 VALU per K-tile and wave on addresses, the input
+// affine, padding selects and LDS writes - 3 000-4 300 cycles per K-tile (tools/diag_conv_f32.py) in which the wave issues
+// no MFMA, so the matrix pipe is only busy while its two waves happen to alternate.  Here a K-tile costs a wave ONE VALU
+// instruction per A piece: buffer_load_dwordx4 ... lds with a per-lane byte offset fixed for the whole kernel (centre tap of
+// the lane's output pixel), the tap / channel-chunk offset in the scalar offset, and padding as "offset out of range":
+// g[j] holds the lane's (top, bottom, left, right) border flags in bits 31..28, sel the flags tap (r, s) violates,
+// voffset = (g & sel) | voff  (v_and_or_b32) - any set bit pushes the offset past num_records = 2^28 and the DMA writes zeros.
+// The LDS image is lane-linear (8 rows x 128 B per wave-instruction), conflict-free through an XOR swizzle of the source
+// chunk and of the fragment read (chunk c of row r sits in slot c ^ ((r >> 1) & 7)).  Two stages: tile kt+1 lands while the
+// 64 MFMAs of tile kt run; one s_waitcnt vmcnt(0) + one raw s_barrier per K-tile.
+// The InstanceNorm / BatchNorm + ReLU that the register-staged kernel applied in its loader now happens where it is free:
+// BatchNorm channels in the producing conv's epilogue (col_scale / col_shift, ReLU from column relu_from on), InstanceNorm
+// channels in one in-place pass over half the tensor (in_apply_kernel, elementwise.hip).
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(uintptr_t)(p))
+#define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <int BN, int FLAGS>
+__global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
+    constexpr bool DIAG = (FLAGS & 1) != 0;
+    constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
+    constexpr int ROWB = BK * 4;                    // 128-byte LDS rows
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int AJ = BM / 8 / 4;                  // A pieces (8 rows each) per wave and K-tile
+    constexpr int BJ = BN / 8 / 4;
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nnt = p.N / BN;
+    int mtile, ntile;
+    {
+        const int nwg = gridDim.x;
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        mtile = L / nnt;
+        ntile = L - mtile * nnt;
+    }
+    const int m_blk = mtile * BM, n_blk = ntile * BN;
+    const int hw = p.Ho * p.Wo;
+    const int img = m_blk / hw;
+    const int rem_blk = m_blk - img * hw;
+
+    // ---- DMA descriptors
+    // A: base = first byte the top-left tap of pixel (0, 0) would read (before the image when pad > 0: never dereferenced,
+    // those lanes are flagged); num_records 2^28 > image + tap offsets, flagged offsets are >= 2^28
+    const char* a_base = (const char*)p.A + ((long long)img * p.H * p.W - (p.pad_y * p.W + p.pad_x)) * (long long)p.Cin * 4;
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 1 << 28, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7fffffff, 0x00020000);
+    int a_voff[AJ];
+    unsigned a_flag[AJ];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int lcol = wn * WN + b * 32 + li;
-        const int col = n_blk + lcol;
-        const float cs = has_cs ? p.col_scale[col] : 1.f;
-        const float sh = has_cs ? p.col_shift[col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < AJ; ++j) {
+        const int row = (wave * AJ + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int rem = rem_blk + row;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy = oy * p.stride, ix = ox * p.stride;       // centre tap: always inside the image
+        a_voff[j] = ((iy * p.W + ix) * p.Cin + chunk * 4) * 4;
+        unsigned f = 0;
+        if (iy - p.pad_y < 0) f |= 1u << 31;                    // tap row 0 is above the image
+        if (iy - p.pad_y + p.R - 1 >= p.H) f |= 1u << 30;       // tap row R-1 is below it
+        if (ix - p.pad_x < 0) f |= 1u << 29;
+        if (ix - p.pad_x + p.S - 1 >= p.W) f |= 1u << 28;
+        a_flag[j] = f;
+    }
+    int b_voff[BJ];
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const long long base = (long long)(m_blk + wm * 64 + a * 32 + 4 * lh) * p.ldc + col;
-            float res[16];
-            if (p.residual) {
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (wave * BJ + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        b_voff[j] = (int)(((long long)(n_blk + row) * p.ldb + chunk * 4) * 4);
+    }
+    const int cpt = p.Cin / BK;
+    const int nk = p.R * p.S * cpt;
+    const int wc4 = p.W * p.Cin * 4;
+
+    int l_r = 0, l_s = 0, l_cc = 0, l_k = 0;     // uniform: the K-tile the next stage() fetches
+    auto stage = [&](int slot) {
+        char* As = lds + slot * STAGE;
+        char* Bs = As + A_BYTES;
+        const int soff = l_r * wc4 + (l_s * p.Cin + l_cc * BK) * 4;
+        const unsigned sel = (l_r == 0 ? 1u << 31 : 0u) | (l_r == p.R - 1 ? 1u << 30 : 0u) | (l_s == 0 ? 1u << 29 : 0u) |
+                             (l_s == p.S - 1 ? 1u << 28 : 0u);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) res[e] = p.residual[base + (long long)((e & 3) + 8 * (e >> 2)) * p.ldc];
-            }
+        for (int j = 0; j < AJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(As + (wave * AJ + j) * 1024), 16, (int)((a_flag[j] & sel) | (unsigned)a_voff[j]),
+                                                     soff, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[a][b][e];
-                if (has_cs) v = v * cs + sh;
-                if (p.residual) v += res[e];
-                if (p.relu) v = fmaxf(v, 0.f);
-                s1 += v;
-                s2 += v * v;
-                p.C[base + (long long)((e & 3) + 8 * (e >> 2)) * p.ldc] = v;
-            }
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, LPTR(Bs + (wave * BJ + j) * 1024), 16, b_voff[j], l_k * 4, 0, 0);
+        l_k += BK;
+        if (++l_cc == cpt) {
+            l_cc = 0;
+            if (++l_s == p.S) { l_s = 0; ++l_r; }
         }
-        if (p.stats) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lh == 0) {
-                stat_lds[(wm * BN + lcol) * 2 + 0] = s1;
-                stat_lds[(wm * BN + lcol) * 2 + 1] = s2;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // fragment reads: lane (li, lh) takes chunk kk*2 + lh of row li (k = 8 kk + 4 lh ..+3), slot = chunk ^ ((row >> 1) & 7)
+    const int swz = (li >> 1) & 7;
+    int a_rd[4], b_rd[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int pos = ((kk * 2 + lh) ^ swz) * 16;
+        a_rd[kk] = (wm * 64 + li) * ROWB + pos;
+        b_rd[kk] = A_BYTES + (wn * WN + li) * ROWB + pos;
+    }
+    // fragments of k-step kk+1 are fetched before the 16 MFMAs of k-step kk are issued (two register sets)
+    auto mfma_tile = [&](int slot) {
+        const char* base = lds + slot * STAGE;
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[0][a] = *(const f32x4*)(base + a_rd[0] + a * 32 * ROWB);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[0][b] = *(const f32x4*)(base + b_rd[0] + b * 32 * ROWB);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[(kk + 1) & 1][a] = *(const f32x4*)(base + a_rd[kk + 1] + a * 32 * ROWB);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[(kk + 1) & 1][b] = *(const f32x4*)(base + b_rd[kk + 1] + b * 32 * ROWB);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][a][e], bf[kk & 1][b][e], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    unsigned long long dsum[5] = {0, 0, 0, 0, 0};
+    stage(0);
+    for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {       // unrolled by the two stages: LDS offsets become instruction immediates
+            if (kt + u < nk) {
+                unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+                if constexpr (DIAG) t0 = stamp();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+u have landed
+                if constexpr (DIAG) t1 = stamp();
+                RAW_BARRIER();                                     // ... everyone's have, and everyone is done reading tile kt+u-1
+                if constexpr (DIAG) t2 = stamp();
+                if (kt + u + 1 < nk) stage(u ^ 1);
+                if constexpr (DIAG) t3 = stamp();
+                mfma_tile(u);
+                if constexpr (DIAG) {
+                    t4 = stamp();
+                    dsum[0] += t1 - t0; dsum[1] += t2 - t1; dsum[2] += t3 - t2; dsum[3] += t4 - t3;
+                }
             }
         }
     }
-    if (p.stats) {
-        __syncthreads();
-        if (tid < BN) {
-            const float t1 = stat_lds[tid * 2 + 0] + stat_lds[(BN + tid) * 2 + 0];
-            const float t2 = stat_lds[tid * 2 + 1] + stat_lds[(BN + tid) * 2 + 1];
-            float* o = p.stats + ((long long)mtile * p.N + n_blk + tid) * 2;
-            o[0] = t1;
-            o[1] = t2;
-        }
+    if constexpr (DIAG) {
+        if (p.diag && blockIdx.x < 64 && lane == 0)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p.diag[(blockIdx.x * 8 + wave) * 5 + i] = dsum[i];
     }
+    __syncthreads();   // the epilogue reuses the tiles' LDS for the column statistics
+    conv_epilogue<BN>(p, acc, (float*)lds, m_blk, n_blk, mtile, tid);
+#endif
+}
+
+bool conv_f32_dma_supported(const GemmParams& p) {
+    return (p.R == 1 || p.R == 3) && p.S == p.R && p.pad_y == (p.R - 1) / 2 && p.pad_x == p.pad_y &&
+           ((long long)p.H * p.W + 4ll * p.W + 4) * p.Cin * 4 < (1ll << 28) && (long long)p.N * p.ldb * 4 < 0x7fffffffll;
 }
 
 template <int BN>
 void launch_bn(reid_ctx* ctx, const GemmParams& p) {
     const int grid = (p.M / BM) * (p.N / BN);
-    if (p.a_scale) hipLaunchKernelGGL((conv_f32_kernel<BN, true>), dim3(grid), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((conv_f32_kernel<BN, false>), dim3(grid), dim3(256), 0, ctx->stream, p);
+    if (!p.a_scale && ctx->f32_conv != 2 && conv_f32_dma_supported(p)) {   // REID_F32_CONV=2: register-staged kernel everywhere (A/B)
+        if (p.diag) hipLaunchKernelGGL((conv_f32_dma_kernel<BN, 1>), dim3(grid), dim3(256), 0, ctx->stream, p);
+        else hipLaunchKernelGGL((conv_f32_dma_kernel<BN, 0>), dim3(grid), dim3(256), 0, ctx->stream, p);
+        return;
+    }
+    const bool prio = false;   // s_setprio around the staging block: measured, no gain (the MFMA holds the issue port)
+#define CONV_F32_LAUNCH(AFF, FL) hipLaunchKernelGGL((conv_f32_kernel<BN, AFF, FL>), dim3(grid), dim3(256), 0, ctx->stream, p)
+    if (p.diag) {   // experiments: the same kernel with s_memtime stamps around the segments of a K-tile
+        if (p.a_scale) { if (prio) CONV_F32_LAUNCH(true, 3); else CONV_F32_LAUNCH(true, 1); }
+        else { if (prio) CONV_F32_LAUNCH(false, 3); else CONV_F32_LAUNCH(false, 1); }
+        return;
+    }
+    if (p.a_scale) { if (prio) CONV_F32_LAUNCH(true, 2); else CONV_F32_LAUNCH(true, 0); }
+    else { if (prio) CONV_F32_LAUNCH(false, 2); else CONV_F32_LAUNCH(false, 0); }
+#undef CONV_F32_LAUNCH
 }
 
 }  // namespace
 
 bool conv_f32_supported(const GemmParams& p) {
     return p.Cin % BK == 0 && p.K == p.R * p.S * p.Cin && p.M % BM == 0 && (p.Ho * p.Wo) % BM == 0 && p.N % 64 == 0 &&
+           p.Wo >= 1 && p.Wo <= 32 && 32 % p.Wo == 0 &&
            p.ldb % 4 == 0 && p.ldc == p.N && (p.a_scale == nullptr) == (p.a_shift == nullptr) &&
            (p.col_scale == nullptr) == (p.col_shift == nullptr) && (long long)p.H * p.W * p.Cin < (1ll << 31);
 }

@@ -136,6 +136,43 @@ __global__ void norm_finalize_kernel(const float* __restrict__ stats, int tiles,
     }
 }
 
+// ---- InstanceNorm half of an IBN layer applied in place (SERes18_IBN.py:88-93), for the LDS-DMA convolution kernel
+// (conv_f32.hip) whose loader cannot transform its input: x[img][pix][ch] = relu(x * a + b) for ch < half, with (a, b)
+// from the producing conv's per-tile sum / sumsq partials exactly as norm_finalize_kernel computes them.  The BatchNorm
+// half was finished in that conv's epilogue.  grid = (hw / rows, images): every block recomputes its image's (a, b).
+__global__ __launch_bounds__(256) void in_apply_kernel(float* __restrict__ x, const float* __restrict__ stats, int tiles, int c,
+                                                       int half, int hw, int rows, const float* __restrict__ in_gamma,
+                                                       const float* __restrict__ in_beta) {
+    __shared__ float sa[256], sb[256];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    for (int ch = tid; ch < half; ch += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = 0; t < tiles; ++t) {
+            const float* st = stats + (((long long)img * tiles + t) * c + ch) * 2;
+            s1 += (double)st[0];
+            s2 += (double)st[1];
+        }
+        const double mean = s1 / hw;
+        double var = s2 / hw - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double inv = 1.0 / sqrt(var + 1e-5);
+        sa[ch] = (float)(inv * (double)in_gamma[ch]);
+        sb[ch] = (float)((double)in_beta[ch] - mean * inv * (double)in_gamma[ch]);
+    }
+    __syncthreads();
+    const int q = half >> 2;   // 16-byte chunks of a pixel's InstanceNorm half
+    float* base = x + ((long long)img * hw + (long long)blockIdx.x * rows) * c;
+    for (int i = tid; i < rows * q; i += 256) {
+        const int row = i / q, cc = i - row * q;
+        f32x4* ptr = (f32x4*)(base + (long long)row * c + cc * 4);
+        f32x4 v = *ptr;
+        const f32x4 a = *(const f32x4*)&sa[cc * 4], b = *(const f32x4*)&sb[cc * 4];
+        v = v * a + b;
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *ptr = v;
+    }
+}
+
 // ---- SEBlock (SERes18_IBN.py:32-41): s = sigmoid(W2 . relu(W1 . avgpool(y))), no bias, norm layer disabled (:36).
 // avgpool comes from the conv2 epilogue's per-tile column sums.  One block per image.  w1: [mid][c], w2: [mid][c] (fc2^T).
 __global__ __launch_bounds__(256) void se_finalize_kernel(const float* __restrict__ stats, int tiles, int c, int mid,
@@ -254,6 +291,17 @@ int launch_norm_finalize(reid_ctx* ctx, const float* stats, int n_img, int tiles
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * c * (tiles * 8.0 + 8.0));
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(n_img), dim3(c < 256 ? c : 256), 0, ctx->stream, stats, tiles, c, half, hw,
                        in_gamma, in_beta, bn_scale, bn_shift, a_scale, a_shift);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_in_apply(reid_ctx* ctx, float* x, const float* stats, int n_img, int tiles, int c, int half, int hw,
+                    const float* in_gamma, const float* in_beta) {
+    ARG_CHECK(half >= 4 && half % 4 == 0 && half <= 256 && hw % 128 == 0);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * half * 8.0);
+    hipLaunchKernelGGL(in_apply_kernel, dim3(hw / 128, n_img), dim3(256), 0, ctx->stream, x, stats, tiles, c, half, hw, 128, in_gamma,
+                       in_beta);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

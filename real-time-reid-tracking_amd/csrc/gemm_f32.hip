@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
                 if constexpr (EPI == E_CONV) {
                     if (p.col_scale) v = v * cs + sh;
                     if (p.residual && ok) v += p.residual[idx];
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu && col >= p.relu_from) v = fmaxf(v, 0.f);
                     if (ok) { s1 += v; s2 += v * v; }
                 } else if constexpr (EPI == E_BIAS) {
                     v += sh;

@@ -1,6 +1,7 @@
 // Operand-feed microbenchmarks (experiments, not part of the public header): how many bytes per second can a CU pull
 // into LDS (global_load_lds) or into registers (global_load_dwordx4) from a buffer of a given footprint, 8 waves/block?
 #include "reid_internal.h"
+#include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -160,5 +161,114 @@ extern "C" int reid_debug_feed(reid_ctx* ctx, int mode, size_t footprint, int ro
     const double bytes = (double)blocks * 8 * iters * 8 * 1024.0;
     *tbs_chip = (float)(bytes / (ms * 1e-3) / 1e12);
     *gbs_per_cu = (float)(bytes / (ms * 1e-3) / 1e9 / 256.0);
+    return REID_OK;
+}
+
+// Co-issue experiment for the exact-fp32 path: what does a wave that stages data (VALU / LDS writes / global loads) get to
+// issue while the OTHER wave of its SIMD runs back-to-back v_mfma_f32_32x32x2_f32?  512-thread blocks, one per CU: waves 0-3
+// run `iters` x 16 MFMAs (4 accumulators), waves 4-7 run `iters` x 64 operations of `mode` (0 v_fma_f32, 1 ds_write_b128,
+// 2 global_load_dwordx4 + wait every 8, 3 v_fma with s_setprio 3).  `roles`: bit 0 = MFMA waves active, bit 1 = other waves active.
+// Output: median cycles per wave of each role.
+namespace {
+typedef float f32x16cb __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ __launch_bounds__(512) void coissue_kernel(int iters, int roles, const float* __restrict__ src,
+                                                      unsigned long long* __restrict__ out, float* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) float lds[512 * 4 * 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mf = wave < 4;
+    float keep = 0.f;
+    __syncthreads();
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    if (mf) {
+        if (roles & 1) {
+            f32x16cb acc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+            const float av = src[lane], bv = src[64 + lane];
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j & 3], 0, 0, 0);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) keep += acc[a][0] + acc[a][7];
+        }
+    } else if (roles & 2) {
+        if constexpr (MODE == 3) __builtin_amdgcn_s_setprio(3);
+        if constexpr (MODE == 0 || MODE == 3) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = src[lane + j];
+            const float a = src[200 + lane], b = src[300 + lane];
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) x[j & 7] = __builtin_fmaf(x[j & 7], a, b);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) keep += x[j];
+        } else if constexpr (MODE == 1) {
+            f32x4 v = {src[lane], src[lane + 1], src[lane + 2], src[lane + 3]};
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    *(f32x4*)&lds[(tid * 2 + (j & 1)) * 4] = v;
+                    asm volatile("" ::: "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            keep += lds[tid * 8];
+        } else {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    const f32x4 v = *(const f32x4*)(src + ((size_t)(blockIdx.x * 512 + tid) * 4 + (size_t)((it * 64 + j) & 1023) * 65536));
+                    s += v;
+                }
+            }
+            keep += s.x + s.y + s.z + s.w;
+        }
+        if constexpr (MODE == 3) __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+    if (keep == 12345.678f) sink[0] = keep;
+}
+}  // namespace
+
+extern "C" int reid_debug_coissue(reid_ctx* ctx, int mode, int iters, int roles, double* cyc_mfma_wave, double* cyc_other_wave) {
+    ARG_CHECK(ctx && mode >= 0 && mode <= 3 && iters > 0 && cyc_mfma_wave && cyc_other_wave);
+    float* src;
+    unsigned long long* out;
+    float* sink;
+    const int blocks = 256;
+    const size_t src_bytes = (size_t)1024 * 65536 * 4 + (size_t)blocks * 512 * 16 + 4096;
+    REID_TRY(ctx_ws(ctx, "dbg.co_src", src_bytes, (void**)&src));
+    REID_TRY(ctx_ws(ctx, "dbg.co_out", blocks * 8 * 8, (void**)&out));
+    REID_TRY(ctx_ws(ctx, "dbg.sink", 64, (void**)&sink));
+    HIP_TRY(hipMemsetAsync(src, 0x3c, src_bytes, ctx->stream));   // 0x3c3c3c3c = 0.0115 as fp32
+    for (int rep = 0; rep < 2; ++rep) {
+        switch (mode) {
+            case 0: hipLaunchKernelGGL(coissue_kernel<0>, dim3(blocks), dim3(512), 0, ctx->stream, iters, roles, src, out, sink); break;
+            case 1: hipLaunchKernelGGL(coissue_kernel<1>, dim3(blocks), dim3(512), 0, ctx->stream, iters, roles, src, out, sink); break;
+            case 2: hipLaunchKernelGGL(coissue_kernel<2>, dim3(blocks), dim3(512), 0, ctx->stream, iters, roles, src, out, sink); break;
+            default: hipLaunchKernelGGL(coissue_kernel<3>, dim3(blocks), dim3(512), 0, ctx->stream, iters, roles, src, out, sink); break;
+        }
+    }
+    LAUNCH_CHECK();
+    std::vector<unsigned long long> h(blocks * 8);
+    HIP_TRY(hipMemcpyAsync(h.data(), out, blocks * 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<double> a, b;
+    for (int i = 0; i < blocks; ++i)
+        for (int w = 0; w < 8; ++w) (w < 4 ? a : b).push_back((double)h[i * 8 + w]);
+    std::sort(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    *cyc_mfma_wave = a[a.size() / 2];
+    *cyc_other_wave = b[b.size() / 2];
     return REID_OK;
 }

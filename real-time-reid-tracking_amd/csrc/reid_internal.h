@@ -65,11 +65,13 @@ struct GemmParams {
     const float* col_shift;
     const float* residual;
     int relu;
+    int relu_from;         // conv_f32.hip: ReLU applies to columns >= relu_from (0 = all; IBN: BatchNorm half only)
     float* stats;          // [M/128][N][2] or null
     // E_BIAS extras: act 1 = exact (erf) GELU after the bias; residual is added after the activation.
     // scat_h > 0: row m = (img, j, i) of a scat_h x scat_w grid is written to pixel (2j+scat_py, 2i+scat_px) of the
     // 2x up-sampled grid (one output parity of a ConvTranspose2d(4, 2, 1)); residual uses the same index.
     int act, scat_h, scat_w, scat_py, scat_px;
+    unsigned long long* diag;   // diagnostic builds of conv_f32.hip only: per-wave cycle sums [block<64][8][5]
     const float* row_sq;   // E_DIST
     const float* col_sq;
     int metric;
@@ -143,6 +145,8 @@ int launch_maxpool3s2(reid_ctx*, const float* x, int n, int h, int w, int c, flo
 int launch_norm_finalize(reid_ctx*, const float* stats, int n_img, int tiles, int c, int half, int hw,
                          const float* in_gamma, const float* in_beta, const float* bn_scale, const float* bn_shift,
                          float* a_scale, float* a_shift);
+int launch_in_apply(reid_ctx*, float* x, const float* stats, int n_img, int tiles, int c, int half, int hw, const float* in_gamma,
+                    const float* in_beta);
 int launch_se_finalize(reid_ctx*, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1,
                        const float* w2, float* s);
 int launch_se_combine(reid_ctx*, const float* y, const float* sc, const float* s, int n_img, int hw, int c, float* out);
@@ -182,6 +186,8 @@ struct Se18Weights {
     _Float16* l1_conv2_w16s[2] = {nullptr, nullptr};   // layer-1 conv2 weights x BN scale (conv3x3_c64_f16.hip)
     _Float16* stem_w16s = nullptr; // same with the folded BN scale multiplied in (fused stem + maxpool kernel)
     _Float16* zero_page = nullptr;
+    float* ep = nullptr;          // [8 blocks][2][512]: conv1 epilogue scale / shift of the IBN blocks: (1, 0) on the InstanceNorm
+                                  // half, the folded BatchNorm on the other (conv_f32.hip flow)
     const _Float16* h(const float* p) const { return blob16 + (p - blob); }
 };
 
@@ -210,7 +216,8 @@ struct reid_ctx {
                              // into conv2 (REID_F16_C64=1: separate se_finalize / se_combine kernels, 0: implicit GEMM)
     int f16_stem_fused = 2;  // fp16 path: stem conv + BN + maxpool as one kernel, 2 = fed with the uint8 crops directly
                              // (REID_F16_STEMPOOL=1: from the padded f16 image, 0: GEMM + pool kernels)
-    int f32_conv = 1;        // fp32 path: 1 = conv_f32.hip (pipelined, double-buffered LDS), 0 = gemm_f32_kernel<A_IM2COL> (REID_F32_CONV)
+    int f32_conv = 1;        // fp32 path (REID_F32_CONV): 1 = conv_f32.hip LDS-DMA kernel, norms in the producer's epilogue / in_apply;
+                             // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
     float* stage_ptr[11] = {nullptr};
     unsigned long long* conv_diag = nullptr;   // experiments (debug.hip): stamps of the loader-wave conv kernel
@@ -219,7 +226,8 @@ struct reid_ctx {
 // convolution launchers of the two arithmetic modes (api.hip); also used by the experiment harnesses in debug.hip
 int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
               int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
-              const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats, float* out);
+              const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats, float* out,
+              int relu_from = 0);
 int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H, int W, int Cin, const _Float16* wgt, int Cout,
                 int R, int S, int stride, int pad, int K, const float* col_scale, const float* col_shift,
                 const _Float16* residual, int relu, float* stats, _Float16* out, int Hp = 0, int Wp = 0);

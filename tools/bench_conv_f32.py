@@ -1,6 +1,6 @@
 """Kernel experiments: times the exact-fp32 convolutions of ResNet18-SE (every conv shape of the network, with the fusions
-it runs with) for the round-1 kernel (variant 0, gemm_f32_kernel<A_IM2COL>) and conv_f32.hip (variant 1), interleaved in one
-process.  python tools/bench_conv_f32.py [n_crops]"""
+it runs with) for the round-1 kernel (variant 0, gemm_f32_kernel<A_IM2COL>), the register-staged conv_f32.hip kernel (variant 2) and its
+LDS-DMA kernel (variant 1, what the forward runs), interleaved in one process.  python tools/bench_conv_f32.py [n_crops]"""
 import ctypes as C
 import os
 import sys
@@ -11,7 +11,7 @@ from reid_amd.engine import get_engine
 from reid_amd._ffi import check
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 2, 1]   # 0 round-1 kernel, 2 conv_f32 without the priority switch, 1 conv_f32
 eng = get_engine(0)
 blob, manifest, _ = weights.pack_seres18(synth.seres18_state_dict(0))
 eng.load_seres18(blob, manifest)
@@ -41,7 +41,9 @@ for name, h, w, cin, cout, r, stride, pad, flags, cnt in layers:
     for rep in range(3):
         for v in variants:
             ms = C.c_float()
-            check(fn(eng.h, n, h, w, cin, cout, r, stride, pad, flags, v, 5, C.byref(ms)))
+            # variant 1 = the LDS-DMA flow: no affine in the loader (flag 1 off), the BatchNorm half in conv1's epilogue (flag 2 on)
+            fl = ((flags & ~1) | 2) if v == 1 else flags
+            check(fn(eng.h, n, h, w, cin, cout, r, stride, pad, fl, v, 5, C.byref(ms)))
             best[v] = min(ms.value, best.get(v, 1e9))
     for v in variants:
         tot[v] += best[v] * cnt
