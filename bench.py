@@ -45,13 +45,15 @@ def host_cores():
 
 
 def traffic_from_profile(f16):
-    """HBM-side bytes per launch of the conv-GEMM class from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
-    per the gfx950 correction, WRITE_SIZE as is); cannot be measured from inside the process."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_conv_f16.json")
-    if not f16 or not os.path.exists(path):
+    """HBM-side bytes per launch of the conv-GEMM class from the committed rocprofv3 PMC passes of this same command
+    (tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); PMC counters cannot be read
+    from inside the process.  The newest profiles/rNN_traffic_conv_<mode>.json wins."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_conv_%s.json" % ("f16" if f16 else "f32"))))
+    if not cands:
         return None
     try:
-        return round(json.load(open(path))["hbm_bytes_per_launch"], 1)
+        return round(json.load(open(cands[-1]))["hbm_bytes_per_launch"], 1)
     except (KeyError, ValueError):
         return None
 
@@ -94,8 +96,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "1024")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--single", action="store_true", help="measure only --precision (skip the other arithmetic)")
-    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f16"),
-                    help="f32 = exact fp32 MFMA; f16 = fp16 storage / fp32 accumulate (1e-3 cosine tolerance of north_star)")
+    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f32"),
+                    help="arithmetic of the headline: f32 = the reference's (exact fp32 MFMA, default); f16 = fp16 storage / fp32 "
+                         "accumulate (inside north_star's 1e-3 cosine tolerance, reported as the labelled side run by default)")
     args = ap.parse_args()
 
     import torch
@@ -125,9 +128,8 @@ def main():
     eng.load_seres18(blob, manifest)
 
     n, d = args.crops, 512
-    # synthetic crops, resident in HBM before the timed region (256 distinct crops per rank, repeated)
-    base = synth.crops_u8(256, seed=1 + rank)
-    crops = torch.from_numpy(base).cuda().repeat((n + 255) // 256, 1, 1, 1)[:n].contiguous()
+    # synthetic crops, resident in HBM before the timed region: n DISTINCT crops per rank (BASELINE config 2, seed 1 + rank)
+    crops = torch.from_numpy(synth.crops_u8(n, seed=1 + rank)).cuda()
     emb = torch.empty((n, d), dtype=torch.float32, device="cuda")
     gathered = torch.empty((n * world, d), dtype=torch.float32, device="cuda") if world > 1 else emb
     distmat = torch.empty((n, n * world), dtype=torch.float32, device="cuda")
@@ -191,7 +193,7 @@ def main():
             "whole_net_fraction_of_hbm_roofline": round(FUSED_BYTES_PER_CROP * (0.5 if f16 else 1.0) * n / (embed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": {
                 "kernel": ("convolution kernels of the fp16 path, v_mfma_f32_32x32x16_f16: conv3x3_f16 (LDS halo, layers 2-4), conv3x3_c64_f16 (layer 1, weights in registers), stem_pool_f16 (7x7 + BN + maxpool), gemm_f16 (strided / 1x1)" if f16 else
-                           "gemm_f32_kernel<im2col> (implicit-GEMM convolutions, v_mfma_f32_32x32x2_f32)"),
+                           "convolution kernels of the fp32 path, v_mfma_f32_32x32x2_f32 (exact fp32): conv_f32_dma_kernel (implicit GEMM, LDS-DMA staging, all 3x3 / 1x1 convs) + the 7x7 stem"),
                 "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile(f16),
                 "launches": conv["launches"], "avg_launch_us": round(conv["ms"] * 1e3 / max(1, conv["launches"]), 2),
@@ -210,7 +212,7 @@ def main():
 
     main_res = run(args.precision, args.steps, args.warmup)
     other = "f32" if args.precision == "f16" else "f16"
-    other_res = run(other, max(1, min(2, args.steps)), 1) if not args.single else None
+    other_res = run(other, max(1, min(3, args.steps)), 1) if not args.single else None
 
     # parity inside the bench: the two precisions agree on the embeddings of this rank (cosine) and on row arg-mins
     eng.set_precision(1)
