@@ -5,10 +5,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = BASELINE config 2 on every rank: embed 4096 synthetic uint8 crops (128x256, already resident in HBM)
-with ResNet18-IBN-SE, [N>1: one RCCL all-gather of the 512-d embeddings], then the L2 distance matrix of this
-rank's 4096 embeddings against all gathered ones.  Weak scaling: per-GPU work is fixed, value = crops of ALL
-ranks / max-over-ranks time.  Prints ONE JSON line on rank 0.
+Default workload = BASELINE configs[1] on every rank: embed 4096 synthetic uint8 crops (128x256, already resident in HBM)
+with ResNet18-IBN-SE in the reference's arithmetic (fp32), [N>1: ONE RCCL all-gather of the 512-d embeddings, issued through
+the C ABI - csrc/comm.hip, no torch.distributed on the data path], then the L2 distance matrix of this rank's 4096
+embeddings against all gathered ones.  Weak scaling: per-GPU work is fixed, value = crops of ALL ranks / max-over-ranks
+time.  Prints ONE JSON line on rank 0.  The fp16-storage mode is measured in the same run and reported as `f16_path`.
+
+Other BASELINE configs, same launch line plus --workload:
+    --workload swin      configs[2]: Swin-T v1, 4096 images 224x224 per rank (weak)
+    --workload tracking  configs[3]: 600-frame detection stream, each frame's crops dealt round-robin to the ranks,
+                         all-gather of the frame's embeddings, feature-bank cost + DIoU on every rank (strong)
+    --workload market    configs[4]: query(3368) x gallery(15913) x 512, gallery rows sharded over the ranks (faiss
+                         IndexShards pattern), per-shard top-k, all-gather + device merge, Rank-1 (strong)
 """
 import argparse
 import json
@@ -26,6 +34,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (spec, no sparsity)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_CROP = 3.980e9        # 1 990 145 536 MAC
 FUSED_BYTES_PER_CROP = 13.78e6 # layer-fused fp32 activation traffic model, SURVEY.md section 8(d)
+SWIN_FLOP_PER_IMAGE = 11.54e9  # Swin-T v1 at 224x224
 
 
 def host_cores():
@@ -44,12 +53,12 @@ def host_cores():
     return n
 
 
-def traffic_from_profile(f16):
-    """HBM-side bytes per launch of the conv-GEMM class from the committed rocprofv3 PMC passes of this same command
+def traffic_from_profile(tag):
+    """HBM-side bytes per launch of a kernel class from the committed rocprofv3 PMC passes of this same command
     (tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); PMC counters cannot be read
-    from inside the process.  The newest profiles/rNN_traffic_conv_<mode>.json wins."""
+    from inside the process.  The newest profiles/rNN_traffic_<tag>.json wins."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_conv_%s.json" % ("f16" if f16 else "f32"))))
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % tag)))
     if not cands:
         return None
     try:
@@ -58,7 +67,7 @@ def traffic_from_profile(f16):
         return None
 
 
-def cpu_baseline(sd, budget_s=12.0):
+def cpu_baseline_embed(sd, budget_s=12.0):
     """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload:
     batch 64 (reference default --bs 64), all host cores."""
     import torch
@@ -87,41 +96,59 @@ def cpu_baseline(sd, budget_s=12.0):
             "distmat_1024_ms": round(dist_ms, 2)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--crops", type=int, default=4096, help="crops per GPU per step (BASELINE config 2: 4096)")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "1024")))
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--single", action="store_true", help="measure only --precision (skip the other arithmetic)")
-    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f32"),
-                    help="arithmetic of the headline: f32 = the reference's (exact fp32 MFMA, default); f16 = fp16 storage / fp32 "
-                         "accumulate (inside north_star's 1e-3 cosine tolerance, reported as the labelled side run by default)")
-    args = ap.parse_args()
+class Job:
+    """Engine + stream + communicator of this rank, and the timing protocol of the bench contract."""
 
-    import torch
-    import torch.distributed as dist
-    from reid_amd import _ffi, synth, weights
-    from reid_amd.engine import get_engine
+    def __init__(self, args):
+        import torch
+        from reid_amd import parallel
+        from reid_amd.engine import get_engine
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, self.world, args.gpus))
+        torch.cuda.set_device(self.local_rank)
+        self.eng = get_engine(self.local_rank)
+        # one explicit (non-null) HIP stream shared by torch (synchronize) and the C ABI launches + RCCL calls
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
+        self.eng.set_stream(self.stream.cuda_stream)
+        # RCCL communicator behind the C ABI (reid_comm_init); REID_BENCH_COMM1=1: a real 1-rank communicator on one GPU
+        self.comm = parallel.RcclComm.from_env(self.eng, single_rank_communicator=os.environ.get("REID_BENCH_COMM1") == "1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+    def barrier(self):
+        self.comm.barrier()                  # RCCL all-reduce of one double + stream sync (local sync when world == 1)
+        self.torch.cuda.synchronize()
 
-    eng = get_engine(local_rank)
-    # one explicit (non-null) HIP stream shared by torch (events, RCCL ordering) and the C ABI launches
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    eng.set_stream(stream.cuda_stream)
+    def timed(self, step, steps, warmup):
+        """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        return float(self.comm.all_reduce([elapsed], "max")[0])
+
+    def close(self):
+        self.comm.close()
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]: embed + distmat
+def run_embed(job, args):
+    from reid_amd import _ffi, parallel, synth, weights
+    eng, comm, world, rank = job.eng, job.comm, job.world, job.rank
     eng.set_chunk(args.chunk)
     sd = synth.seres18_state_dict(0, gem_p=3.0)
     blob, manifest, _ = weights.pack_seres18(sd)
@@ -129,48 +156,28 @@ def main():
 
     n, d = args.crops, 512
     # synthetic crops, resident in HBM before the timed region: n DISTINCT crops per rank (BASELINE config 2, seed 1 + rank)
-    crops = torch.from_numpy(synth.crops_u8(n, seed=1 + rank)).cuda()
-    emb = torch.empty((n, d), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((n * world, d), dtype=torch.float32, device="cuda") if world > 1 else emb
-    distmat = torch.empty((n, n * world), dtype=torch.float32, device="cuda")
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    crops = parallel.DevArray.from_numpy(eng, synth.crops_u8(n, seed=1 + rank))
+    emb_all = parallel.DevArray(eng, (n * world, d))
+    emb_local = parallel.DevArray(eng, (n, d))
+    distmat = parallel.DevArray(eng, (n, n * world))
+    lo, hi = parallel.shard_bounds(n * world, world, rank)
 
-    def step(timed=None):
-        if timed:
-            ev[0].record()
-        eng.embed_u8_dev(crops.data_ptr(), n, emb.data_ptr())
-        if timed:
-            ev[1].record()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, emb)
-        eng.distmat_dev(emb.data_ptr(), n, gathered.data_ptr(), n * world, d, _ffi.METRIC_L2, distmat.data_ptr())
-        if timed:
-            ev[2].record()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step():
+        # the multi-GPU path of the library itself (parallel.py): embed the local shard, ONE all-gather, row block
+        parallel.embed_sharded_dev(eng, comm, crops.ptr, n, n * world, emb_all, emb_local.ptr)
+        parallel.distmat_row_block(eng, emb_all, lo, hi, _ffi.METRIC_L2, distmat)
 
     def run(precision, steps, warmup):
         """Timed region per the bench contract + a profiled repeat of the same steps for the roofline object."""
         eng.set_precision(1 if precision == "f16" else 0)
-        for _ in range(warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = job.timed(step, steps, warmup)
         # split of one step (embed / all-gather+distmat), HIP events on the launch stream
-        step(timed=True)
-        torch.cuda.synchronize()
-        embed_ms, match_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+        eng.timer_start()
+        parallel.embed_sharded_dev(eng, comm, crops.ptr, n, n * world, emb_all, emb_local.ptr)
+        embed_ms = eng.timer_stop()
+        eng.timer_start()
+        parallel.distmat_row_block(eng, emb_all, lo, hi, _ffi.METRIC_L2, distmat)
+        match_ms = eng.timer_stop()
         # roofline of the dominant kernel class (implicit-GEMM convolutions): the same steps again with every launch
         # of the class bracketed by HIP events on its stream
         eng.profile_reset()
@@ -178,7 +185,7 @@ def main():
         tp = time.perf_counter()
         for _ in range(steps):
             step()
-        torch.cuda.synchronize()
+        eng.sync()
         prof_ms = (time.perf_counter() - tp) * 1e3 / steps
         conv, dgm, elt = (eng.profile_get(k) for k in (_ffi.K_CONV_GEMM, _ffi.K_DIST_GEMM, _ffi.K_ELEMENTWISE))
         eng.profile(False)
@@ -195,7 +202,7 @@ def main():
                 "kernel": ("convolution kernels of the fp16 path, v_mfma_f32_32x32x16_f16: conv3x3_f16 (LDS halo, layers 2-4), conv3x3_c64_f16 (layer 1, weights in registers), stem_pool_f16 (7x7 + BN + maxpool), gemm_f16 (strided / 1x1)" if f16 else
                            "convolution kernels of the fp32 path, v_mfma_f32_32x32x2_f32 (exact fp32): conv_f32_dma_kernel (implicit GEMM, LDS-DMA staging, all 3x3 / 1x1 convs) + the 7x7 stem"),
                 "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile(f16),
+                "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile("conv_f16" if f16 else "conv_f32"),
                 "launches": conv["launches"], "avg_launch_us": round(conv["ms"] * 1e3 / max(1, conv["launches"]), 2),
                 "algorithmic_gflop_per_launch": round(conv["flops"] / max(1, conv["launches"]) / 1e9, 3),
                 "algorithmic_bytes_per_launch": round(conv["bytes"] / max(1, conv["launches"]), 1),
@@ -214,48 +221,281 @@ def main():
     other = "f32" if args.precision == "f16" else "f16"
     other_res = run(other, max(1, min(3, args.steps)), 1) if not args.single else None
 
-    # parity inside the bench: the two precisions agree on the embeddings of this rank (cosine) and on row arg-mins
-    eng.set_precision(1)
-    eng.embed_u8_dev(crops.data_ptr(), 256, emb.data_ptr())
-    e16 = emb[:256].clone()
-    eng.set_precision(0)
-    eng.embed_u8_dev(crops.data_ptr(), 256, emb.data_ptr())
-    torch.cuda.synchronize()
-    e32 = emb[:256]
-    cos_err = float((1 - torch.nn.functional.cosine_similarity(e16, e32, dim=1)).max().item())
+    # parity inside the bench: the two precisions agree on the embeddings of this rank (cosine)
+    e = {}
+    for mode, name in ((1, "f16"), (0, "f32")):
+        eng.set_precision(mode)
+        eng.embed_u8_dev(crops.ptr, 256, emb_local.ptr)
+        e[name] = emb_local.numpy()[:256]
+    cos = (e["f16"] * e["f32"]).sum(1) / np.linalg.norm(e["f16"], axis=1) / np.linalg.norm(e["f32"], axis=1)
+    cos_err = float((1 - cos).max())
 
-    if rank == 0:
-        f16 = args.precision == "f16"
-        out = {
-            "metric": "crops/sec embedded + NxM distmat ms, ResNet18-SE 128x256",
-            "value": main_res["value"],
-            "unit": "crops/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"],
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f16" if f16 else "f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ResNet18-SE embed %d uint8 crops (128x256) per GPU + %dx%d L2 distmat"
-                                   % (n, n, n * world),
-                       "crops_per_gpu": n, "embed_dim": d, "chunk": args.chunk,
-                       "arithmetic": ("fp16 storage, fp32 accumulate (north_star tolerance 1e-3 cosine; measured below)" if f16
-                                      else "exact fp32 (v_mfma_f32_32x32x2_f32)"),
-                       "sharding": "crops sharded by rank, one RCCL all-gather of [N,512] embeddings" if world > 1 else "single GPU"},
-            "f16_vs_f32_max_cosine_err": cos_err,
-        }
-        out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
-        if other_res is not None:
-            out[other + "_path"] = other_res
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sd)
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    f16 = args.precision == "f16"
+    out = {
+        "metric": "crops/sec embedded + NxM distmat ms, ResNet18-SE 128x256",
+        "value": main_res["value"],
+        "unit": "crops/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": main_res["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16" if f16 else "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: ResNet18-SE embed %d distinct uint8 crops (128x256) per GPU + %dx%d L2 distmat"
+                               % (n, n, n * world),
+                   "crops_per_gpu": n, "embed_dim": d, "chunk": args.chunk,
+                   "arithmetic": ("fp16 storage, fp32 accumulate (north_star tolerance 1e-3 cosine; measured below)" if f16
+                                  else "exact fp32 (v_mfma_f32_32x32x2_f32), the reference's arithmetic"),
+                   "sharding": ("crops sharded by rank, one RCCL all-gather of [N,512] embeddings through the C ABI (reid_allgather_dev)"
+                                if world > 1 else "single GPU")},
+        "f16_vs_f32_max_cosine_err": cos_err,
+    }
+    out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
+    if other_res is not None:
+        out[other + "_path"] = other_res
+    if not args.no_cpu and world == 1:
+        out["cpu_baseline"] = cpu_baseline_embed(sd)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ configs[2]: Swin-T
+def run_swin(job, args):
+    from reid_amd import _ffi, parallel, synth, weights
+    eng, comm, world, rank = job.eng, job.comm, job.world, job.rank
+    n = args.crops
+    eng.set_chunk(min(args.chunk, 256))
+    sd = synth.swin_state_dict(0)
+    eng.load_swin(*weights.pack_swin(sd)[:2])
+    # 256 distinct images per rank repeated (a 4096 x 3 x 224 x 224 fp32 batch is 2.4 GB: generated as 16 x 256)
+    base = synth.images_f32(256, 2 + rank)
+    x = parallel.DevArray(eng, (n, 3, 224, 224))
+    for i in range(0, n, 256):
+        m = min(256, n - i)
+        eng.h2d(x.row_ptr(i), base[:m])
+    emb_local = parallel.DevArray(eng, (n, 96))
+    emb_all = parallel.DevArray(eng, (n * world, 96))
+
+    def step():
+        eng.swin_embed_dev(x.ptr, n, 224, 224, emb_local.ptr)
+        comm.all_gather(emb_local.ptr, emb_all.ptr, n * 96 * 4)
+
+    def run(precision, steps, warmup):
+        eng.set_precision(1 if precision == "f16" else 0)
+        elapsed = job.timed(step, steps, warmup)
+        eng.profile_reset()
+        eng.profile(True)
+        for _ in range(steps):
+            step()
+        eng.sync()
+        g, e = eng.profile_get(_ffi.K_CONV_GEMM), eng.profile_get(_ffi.K_ELEMENTWISE)
+        eng.profile(False)
+        f16 = precision == "f16"
+        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+        tf = g["flops"] / max(g["ms"], 1e-9) / 1e9
+        return {"value": round(n * world * steps / elapsed, 1), "ms_per_step": round(elapsed * 1e3 / steps, 3),
+                "whole_net_tflops": round(SWIN_FLOP_PER_IMAGE * n * steps / elapsed / 1e12, 1),
+                "roofline": {"kernel": "Swin Linear / conv / window-attention contractions (%s)" % ("v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x2_f32"),
+                             "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                             "traffic": traffic_from_profile("swin_f16" if f16 else "swin_f32"), "launches": g["launches"],
+                             "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2)},
+                "other_kernels": {"elementwise_attention_norm": {"ms_per_step": round(e["ms"] / steps, 3)}}}
+
+    main_res = run(args.precision, args.steps, args.warmup)
+    other = "f32" if args.precision == "f16" else "f16"
+    other_res = run(other, max(1, min(2, args.steps)), 1) if not args.single else None
+    if rank != 0:
+        return None
+    out = {"metric": "images/sec embedded, Swin-T v1 224x224", "value": main_res["value"], "unit": "images/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: Swin-T v1 backbone, %d images 224x224 per GPU (+ all-gather of the 96-d embeddings)" % n,
+                      "images_per_gpu": n, "embed_dim": 96, "chunk": min(args.chunk, 256)}}
+    out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
+    if other_res is not None:
+        out[other + "_path"] = other_res
+    if not args.no_cpu and world == 1:
+        import torch
+        from oracle import swin
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        xs = base[:16]
+        swin.embed(sd, xs)
+        t0, m = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 10:
+            swin.embed(sd, xs)
+            m += 16
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(m / el, 2), "unit": "images/s", "cores": cores, "kind": "port",
+                               "sample": "%d images (batches of 16, %.1f s) through oracle/swin.py (torch-CPU restatement)" % (m, el)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ configs[3]: tracking stream
+def run_tracking(job, args):
+    """MOT16-02 is not in the container: synthetic stand-in per SURVEY.md section 8(d) - 600 frames, detections per frame
+    ~ Poisson(30) clipped to [1, 80], ragged crop sizes.  Per frame: this rank's share of the crops (round-robin) is resized
+    and embedded on the device, ONE all-gather of the frame's embeddings, then - on every rank, as DeepSORT would -
+    the feature-bank cost against 40 tracks x 100 samples (gated at MAX_DIST 0.15) and the DIoU cost."""
+    from reid_amd import parallel, synth, weights
+    from reid_amd.iou_matching import iou_cost
+    from reid_amd.nn_matching import NearestNeighborDistanceMetric
+    eng, comm, world, rank = job.eng, job.comm, job.world, job.rank
+    sd = synth.seres18_state_dict(0, gem_p=3.0)
+    eng.load_seres18(*weights.pack_seres18(sd)[:2])
+    eng.set_precision(1 if args.precision == "f16" else 0)
+    frames = args.frames
+    rng = np.random.default_rng(3)
+    counts = np.clip(rng.poisson(30, frames), 1, 80)
+    pool = synth.ragged_crops_u8(256, seed=3)
+    metric = NearestNeighborDistanceMetric("cosine", 0.15, 100)         # MAX_DIST / NN_BUDGET, deep_sort.yaml:3,9
+    tracks = list(range(40))
+    metric.partial_fit(rng.normal(size=(40 * 100, 512)).astype(np.float32), np.repeat(tracks, 100), tracks)
+    boxes = rng.uniform(0, 500, (80, 4))
+    boxes[:, 2:] = rng.uniform(20, 120, (80, 2))
+    per_max = (80 + world - 1) // world
+    d_local = parallel.DevArray(eng, (per_max, 512))
+    d_all = parallel.DevArray(eng, (per_max * world, 512))
+    gather_us = []
+
+    def frame(f, timed=False):
+        n = int(counts[f])
+        mine = parallel.round_robin(n, world, rank)
+        crops = [pool[(f * 7 + int(i)) % 256] for i in mine]
+        local = eng.embed_ragged_u8(crops) if len(crops) else np.empty((0, 512), np.float32)
+        if world > 1:
+            # equal-size slots (ceil(n / world) rows, zero padded): one ncclAllGather, no count exchange
+            per = (n + world - 1) // world
+            buf = np.zeros((per, 512), np.float32)
+            buf[: len(local)] = local
+            eng.h2d(d_local.ptr, buf)
+            t0 = time.perf_counter()
+            comm.all_gather(d_local.ptr, d_all.ptr, per * 512 * 4)
+            eng.sync()
+            if timed:
+                gather_us.append((time.perf_counter() - t0) * 1e6)
+            allb = np.empty((world * per, 512), np.float32)
+            eng.d2h(allb, d_all.ptr)
+            feats = np.empty((n, 512), np.float32)
+            for r in range(world):
+                idx = parallel.round_robin(n, world, r)
+                feats[idx] = allb[r * per: r * per + len(idx)]
+        else:
+            feats = local
+        cost = metric.distance(feats, tracks, max_distance=0.15)
+        icost = iou_cost(boxes[:40], boxes[:n])
+        k = min(n, 40)
+        metric.partial_fit(feats[:k], tracks[:k], tracks)
+        return n, cost, icost
+
+    for f in range(3):
+        frame(f)
+    job.barrier()
+    t0 = time.perf_counter()
+    ncrops = 0
+    lat = []
+    for f in range(frames):
+        t1 = time.perf_counter()
+        ncrops += frame(f, timed=True)[0]
+        lat.append(time.perf_counter() - t1)
+    job.barrier()
+    elapsed = float(comm.all_reduce([time.perf_counter() - t0], "max")[0])
+    if rank != 0:
+        return None
+    lat = np.asarray(lat) * 1e3
+    return {"metric": "frames/sec, per-frame crop batches embedded + gathered + matched (ResNet18-SE 128x256)", "value": round(frames / elapsed, 1),
+            "unit": "frames/s", "n_gpus": world, "steps": frames, "warmup": 3, "ms_per_step": round(elapsed * 1e3 / frames, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3] stand-in: %d frames, %d crops (Poisson(30) per frame, ragged sizes), round-robin over "
+                                   "the ranks, all-gather of [n_f,512], bank cost (40 tracks x 100) + DIoU" % (frames, ncrops)},
+            "crops_per_s": round(ncrops / elapsed, 1), "ms_per_frame_median": round(float(np.median(lat)), 3),
+            "ms_per_frame_p95": round(float(np.percentile(lat, 95)), 3),
+            "allgather_us_median": round(float(np.median(gather_us)), 1) if gather_us else None}
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]: Market-sized retrieval
+def run_market(job, args):
+    from reid_amd import _ffi, parallel, synth
+    eng, comm, world, rank = job.eng, job.comm, job.world, job.rank
+    nq, ng, d, k = 3368, 15913, 512, 20
+    qf, ql, qc, gf, gl, gc = synth.clustered_embeddings(nq, ng, d=d, n_ids=751, n_cams=6, seed=4, sigma=3.0)
+    lo, hi = parallel.shard_bounds(ng, world, rank)
+    dq = parallel.DevArray.from_numpy(eng, qf)
+    dg = parallel.DevArray.from_numpy(eng, gf[lo:hi])                   # this rank's gallery rows only
+    dist = parallel.DevArray(eng, (nq, max(hi - lo, 1)))
+    dD, dI = parallel.DevArray(eng, (nq, k)), parallel.DevArray(eng, (nq, k), np.int32)
+
+    def step():
+        # the shard's block of the distance matrix (the metric's "N x M distmat ms") + sharded k-NN with device merge
+        if hi > lo:
+            eng.distmat_dev(dq.ptr, nq, dg.ptr, hi - lo, d, _ffi.METRIC_L2, dist.ptr)
+        parallel.knn_gallery_sharded_dev(eng, dq.ptr, nq, dg.ptr, hi - lo, lo, d, k, dD.ptr, dI.ptr)
+
+    elapsed = job.timed(step, args.steps, args.warmup)
+    eng.timer_start()
+    if hi > lo:
+        eng.distmat_dev(dq.ptr, nq, dg.ptr, hi - lo, d, _ffi.METRIC_L2, dist.ptr)
+    dist_ms = eng.timer_stop()
+    I = dI.numpy()
+    # Rank-1 over the merged lists, reference rule (reid/evaluate.py:55-105): first item that is not junk (same id AND same camera)
+    junk = (gl[I] == ql[:, None]) & (gc[I] == qc[:, None])
+    first = np.where(junk, I.shape[1], np.arange(I.shape[1])[None, :]).min(1)
+    ok = first < I.shape[1]
+    rank1 = float((gl[I[np.arange(nq), np.minimum(first, I.shape[1] - 1)]] == ql)[ok].sum() / nq)
+    if rank != 0:
+        return None
+    flops = 2.0 * nq * (hi - lo) * d
+    byts = 4.0 * (nq * d + (hi - lo) * d + nq * (hi - lo))
+    out = {"metric": "N x M distmat ms + rank-1, query(3368) x gallery(15913) x 512", "value": round(nq * args.steps / elapsed, 1),
+           "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4]: 3368 x 15913 x 512, gallery rows sharded over %d rank(s): shard distance matrix + "
+                                  "top-%d per shard, all-gather (fp32 distances, int32 indices), device k-way merge" % (world, k)},
+           "distmat_shard_ms": round(dist_ms, 3), "rank1_top%d" % k: rank1,
+           "roofline": {"kernel": "gemm_f32_kernel<dense, distance epilogue> (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                        "achieved": round(flops / (dist_ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(flops / (dist_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": byts, "hbm_gbs": round(byts / (dist_ms * 1e-3) / 1e9, 1)}}
+    if not args.no_cpu and world == 1:
+        from oracle import matching
+        t0 = time.perf_counter()
+        matching.euclidean_dist(qf[:1024], gf)
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(1024 / el, 1), "unit": "queries/s", "cores": host_cores(), "kind": "port",
+                               "sample": "1024 x 15913 x 512 L2 distance matrix through oracle/matching.py (numpy) in %.1f ms" % (el * 1e3)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["embed", "swin", "tracking", "market"], default="embed",
+                    help="embed = BASELINE configs[1] (the metric's configuration, default); the others are configs[2..4]")
+    ap.add_argument("--crops", type=int, default=4096, help="crops (images) per GPU per step (BASELINE config 2 / 3: 4096)")
+    ap.add_argument("--frames", type=int, default=600, help="--workload tracking: frames of the stream")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "1024")))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--single", action="store_true", help="measure only --precision (skip the other arithmetic)")
+    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f32"),
+                    help="arithmetic of the headline: f32 = the reference's (exact fp32 MFMA, default); f16 = fp16 storage / fp32 "
+                         "accumulate (inside north_star's 1e-3 cosine tolerance, reported as the labelled side run by default)")
+    args = ap.parse_args()
+
+    job = Job(args)
+    try:
+        out = {"embed": run_embed, "swin": run_swin, "tracking": run_tracking, "market": run_market}[args.workload](job, args)
+        if out is not None:
+            print(json.dumps(out))
+        job.barrier()
+    finally:
+        job.close()
 
 
 if __name__ == "__main__":

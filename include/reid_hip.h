@@ -190,6 +190,31 @@ int reid_rank_eval(reid_ctx* ctx, const float* qf, const int64_t* ql, const int6
                    const float* gf, const int64_t* gl, const int64_t* gc, int ng, int d,
                    int32_t* cmc_sum, double* ap, int32_t* valid);
 
+/* ---- multi-GPU exchange: one process per GPU, collectives directly on librccl (RCCL over xGMI) -----
+ * The path shards with ONE exchange step: crops are split contiguous-by-index, every rank embeds its shard, one all-gather of
+ * the [n_local][512] fp32 embeddings follows, each rank computes its row block of the distance matrix.  A fixed gallery is
+ * sharded by rows - the reference's own faiss.IndexShards pattern (reid/faiss_utils.py:121-135: shard, search, merge).
+ * Rank 0 creates the id, the host distributes its 128 bytes (any channel: a TCP store, MPI, a file), every rank calls
+ * reid_comm_init.  Without a communicator (or world == 1) every collective below degrades to the local copy. */
+#define REID_COMM_ID_BYTES 128
+int reid_comm_unique_id(void* id128);                                        /* ncclGetUniqueId */
+int reid_comm_init(reid_ctx* ctx, int rank, int world, const void* id128);   /* ncclCommInitRank on the context's device */
+int reid_comm_info(reid_ctx* ctx, int* rank, int* world);
+int reid_comm_destroy(reid_ctx* ctx);
+/* d_recv[r * bytes ..] = rank r's d_send (bytes per rank equal on all ranks); enqueued on the context's stream, no sync */
+int reid_allgather_dev(reid_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* ragged row blocks: rank r contributes n_local rows of row_bytes; d_out = all rows in rank order, counts_host[world] (may be
+ * NULL) the per-rank row counts, *n_total their sum.  Synchronises the stream once (the counts are needed on the host). */
+int reid_allgather_rows_dev(reid_ctx* ctx, const void* d_local, int n_local, size_t row_bytes, void* d_out,
+                            int32_t* counts_host, int* n_total);
+/* small host-side reduction over the ranks, op 0 = sum, 1 = max, count <= 64; also the job's barrier.  Synchronises. */
+int reid_allreduce_f64(reid_ctx* ctx, double* inout_host, int count, int op);
+/* squared-L2 k-NN over a gallery whose ROWS are sharded across the ranks (index_init_gpu's IndexShards, faiss_utils.py:121-135):
+ * d_xq [nq][d] identical on every rank, d_xb_local [nb_local][d] this rank's rows, index_base their first global row.
+ * Same (d_D, d_I) on every rank, equal to a single-process reid_knn_dev over the whole gallery (ties -> lowest global row). */
+int reid_knn_gallery_sharded_dev(reid_ctx* ctx, const float* d_xq, int nq, const float* d_xb_local, int nb_local,
+                                 int index_base, int d, int k, float* d_D, int32_t* d_I);
+
 /* ---- single operators (unit tests and reuse by other backbones) --------------------------- */
 /* NHWC convolution, weights [Cout][R][S][Cin], optional per-channel scale/shift, residual (same shape as out), ReLU */
 int reid_conv2d_nhwc(reid_ctx* ctx, const float* x, int n, int h, int w, int cin, const float* wgt, int cout, int r,

@@ -30,6 +30,11 @@ int reid_debug_mfma_shape(reid_ctx* ctx, int shape, int iters, int blocks, float
 /* Operand-feed microbenchmark: rows of `rowb` bytes at `stride` from a `footprint`-byte buffer, LDS-DMA or register loads. */
 int reid_debug_feed(reid_ctx* ctx, int mode, size_t footprint, int rowb, size_t stride, int iters, int inflight,
                     float* gbs_per_cu, float* tbs_chip);
+/* The device k-way merge of reid_knn_gallery_sharded_dev run on host lists [world][nq][kk] (tests with virtual shards). */
+int reid_debug_knn_merge(reid_ctx* ctx, const float* Dall, const int32_t* Iall, int world, int nq, int kk, int k, float* D,
+                         int32_t* I);
+/* What a wave that stages data can issue beside the other wave's back-to-back v_mfma_f32_32x32x2_f32 (microbench.hip). */
+int reid_debug_coissue(reid_ctx* ctx, int mode, int iters, int roles, double* cyc_mfma_wave, double* cyc_other_wave);
 
 #ifdef __cplusplus
 }

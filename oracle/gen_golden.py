@@ -304,6 +304,72 @@ def gen_postproc():
     print("postproc: debias", gf.shape, "mean |delta|", float(np.abs(out - gf).mean()))
 
 
+def gen_config1():
+    """BASELINE configs[0] / SURVEY 8(c): the reference's own SERse18_IBN on 256 seeded 128x256 crops -> emb[256,512], the
+    cosine distance matrix via the reference's cosine_dist ((1 - cos) / 2, reid/losses/utils.py:12-19) and its row arg-min
+    with the diagonal excluded.  Two crop sets: uniform-random pixels (seed 0, the set SURVEY 8(d) names - embeddings of noise
+    images are nearly parallel, so the top-2 gaps are tiny) and smooth synthetic "persons" (seed 5, realistic gaps).
+    Crops and weights are regenerated in the tests from reid_amd.synth (same seeds)."""
+    from reid_amd import synth
+    from reid.backbones.SERes18_IBN import seres18_ibn
+    from reid.losses.utils import cosine_dist
+
+    sd_np = synth.seres18_state_dict(0)
+    model = seres18_ibn(num_classes=751, loss="triplet")
+    res = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model.eval()
+    out = {}
+    for tag, crops in (("rand0", synth.crops_u8(256, 0)), ("smooth5", synth.smooth_crops_u8(256, 5))):
+        embs = []
+        with torch.no_grad():
+            for i in range(0, 256, 64):      # reference default --bs 64 (image_reid_inference.py:144)
+                x = torch.from_numpy(crops[i:i + 64]).float().div(255.0).sub(0.5).div(0.5).permute(0, 3, 1, 2).contiguous()
+                embs.append(model(x)[0])
+        emb = torch.cat(embs, 0)
+        dist = cosine_dist(emb, emb).numpy()
+        d = dist.copy()
+        np.fill_diagonal(d, np.inf)
+        srt = np.sort(d, axis=1)
+        out.update({tag + "_emb": emb.numpy(), tag + "_cosdist": dist.astype(np.float32),
+                    tag + "_argmin": d.argmin(1).astype(np.int32), tag + "_gap": (srt[:, 1] - srt[:, 0]).astype(np.float32)})
+        print("config1", tag, "emb", tuple(emb.shape), "median top-2 gap", float(np.median(srt[:, 1] - srt[:, 0])),
+              "min gap", float((srt[:, 1] - srt[:, 0]).min()))
+    np.savez_compressed(os.path.join(OUT, "config1.npz"), **out)
+
+
+def gen_config5():
+    """BASELINE configs[4] / SURVEY 8(c, d): the reference's evaluate_all (reid/evaluate.py:33-105) on the synthetic
+    Market-1501-sized problem - qf[3368,512], gf[15913,512] around 751 centroids, 6 cameras, pid 0 distractors - giving
+    CMC, mAP, the per-query AP and the per-query top-1 gallery index of the reference's own ranking
+    (argsort(score)[::-1][0], evaluate.py:58-63).  sigma 0.3 is the survey's configuration (well separated identities);
+    sigma 3.0 makes the ranks non-trivial (same-identity cosine ~0.1 against the ~0.18 maximum over 15 913 negatives).  Inputs are regenerated in the tests from synth.clustered_embeddings."""
+    import io, contextlib
+    from reid_amd import synth
+    from reid.evaluate import evaluate, evaluate_all
+
+    out = {}
+    for tag, sigma in (("s03", 0.3), ("s30", 3.0)):
+        qf, ql, qc, gf, gl, gc = synth.clustered_embeddings(3368, 15913, d=512, n_ids=751, n_cams=6, seed=4, sigma=sigma)
+        tq, tql, tqc = torch.from_numpy(qf), torch.from_numpy(ql), torch.from_numpy(qc)
+        tg, tgl, tgc = torch.from_numpy(gf), torch.from_numpy(gl), torch.from_numpy(gc)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cmc, mAP = evaluate_all(tq, tql, tqc, tg, tgl, tgc)
+        ap = np.zeros(3368, np.float64)
+        top1 = np.zeros(3368, np.int32)
+        first_good = np.zeros(3368, np.int32)
+        for i in range(3368):
+            a, c = evaluate(tq[i], tql[i], tqc[i], tg, tgl, tgc)
+            ap[i] = a
+            first_good[i] = -1 if c[0] == -1 else int(np.flatnonzero(c.numpy())[0])
+            score = torch.mm(tg, tq[i].view(-1, 1)).squeeze(1).numpy()      # evaluate.py:58-60
+            top1[i] = np.argsort(score)[::-1][0]                             # evaluate.py:62-63
+        out.update({tag + "_cmc": cmc.numpy().astype(np.float32), tag + "_map": np.float64(mAP), tag + "_ap": ap,
+                    tag + "_top1": top1, tag + "_first_good": first_good})
+        print("config5", tag, "Rank-1 %.6f Rank-5 %.6f mAP %.6f" % (float(cmc[0]), float(cmc[4]), float(mAP)))
+    np.savez_compressed(os.path.join(OUT, "config5.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -315,3 +381,5 @@ if __name__ == "__main__":
     gen_swin()
     gen_rerank()
     gen_postproc()
+    gen_config1()
+    gen_config5()

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libreid_hip.so")
 LIB_PATH = os.environ.get("REID_HIP_LIB", LIB_PATH)   # A/B experiments: an alternative build of the same library
 
 METRIC_L2, METRIC_L2SQR, METRIC_COS_HALF, METRIC_COS, METRIC_DOT = range(5)
+COMM_ID_BYTES = 128
 K_CONV_GEMM, K_DIST_GEMM, K_ELEMENTWISE, K_SELECT = range(4)
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -71,14 +72,22 @@ _SIGS = {
     "reid_diou": (_i, [_vp, _vp, _vp, _i, _vp]),
     "reid_diou_cost": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "reid_rank_eval": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "reid_comm_unique_id": (_i, [_vp]),
+    "reid_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "reid_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "reid_comm_destroy": (_i, [_vp]),
+    "reid_allgather_dev": (_i, [_vp, _vp, _vp, _sz]),
+    "reid_allgather_rows_dev": (_i, [_vp, _vp, _i, _sz, _vp, _vp, C.POINTER(_i)]),
+    "reid_allreduce_f64": (_i, [_vp, C.POINTER(C.c_double), _i, _i]),
+    "reid_knn_gallery_sharded_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "reid_conv2d_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "reid_gemm_nt": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
 }
 EXPORTS = tuple(sorted(_SIGS))
 
 DEBUG_LIB_PATH = os.path.join(_HERE, "libreid_hip_debug.so")
-DEBUG_EXPORTS = ("reid_debug_conv_c64", "reid_debug_conv_diag", "reid_debug_conv_f16", "reid_debug_conv_f32",
-                 "reid_debug_feed", "reid_debug_gemm_f16", "reid_debug_mfma_shape")   # include/reid_hip_debug.h
+DEBUG_EXPORTS = ("reid_debug_coissue", "reid_debug_conv_c64", "reid_debug_conv_diag", "reid_debug_conv_f16", "reid_debug_conv_f32",
+                 "reid_debug_feed", "reid_debug_gemm_f16", "reid_debug_knn_merge", "reid_debug_mfma_shape")   # include/reid_hip_debug.h
 
 _lib = None
 _dbg = None

@@ -33,7 +33,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
         reid_set_error("reid_ctx_create: device %d not available (%d visible)", device, n);
         return REID_ERR_ARG;
     }
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard _dev_guard(device);   // streams / events below are created on `device`; the caller's current device is restored
     reid_ctx* c = new reid_ctx();
     c->device = device;
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
@@ -53,8 +53,9 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
 
 extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     if (!ctx) return REID_OK;
-    hipSetDevice(ctx->device);
+    DeviceGuard _dev_guard(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
     swin_release(ctx);
     for (auto& kv : ctx->ws) hipFree(kv.second.first);
     if (ctx->se18.blob) hipFree(ctx->se18.blob);
@@ -76,24 +77,28 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
 
 extern "C" int reid_ctx_set_stream(reid_ctx* ctx, void* s) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
     return REID_OK;
 }
 
 extern "C" int reid_ctx_sync(reid_ctx* ctx) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return REID_OK;
 }
 
 extern "C" int reid_ctx_set_chunk(reid_ctx* ctx, int n) {
     ARG_CHECK(ctx && n >= 1 && n <= 1024);
+    CTX_GUARD(ctx);
     ctx->chunk = n;
     return REID_OK;
 }
 
 extern "C" int reid_ctx_set_precision(reid_ctx* ctx, int mode) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     if (mode != 0 && mode != 1) {
         reid_set_error("reid_ctx_set_precision: mode must be 0 (exact fp32 MFMA) or 1 (fp16 storage / fp32 accumulate)");
         return REID_ERR_ARG;
@@ -104,6 +109,7 @@ extern "C" int reid_ctx_set_precision(reid_ctx* ctx, int mode) {
 
 extern "C" int reid_ctx_set_debug_keep(reid_ctx* ctx, int on) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     ctx->debug_keep = on < 0 ? 0 : (on > 2 ? 2 : on);   // 1: every kernel unfused, 2: production kernels, stage 0 not produced
     return REID_OK;
 }
@@ -133,6 +139,7 @@ int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out) {
 
 extern "C" int reid_malloc(reid_ctx* ctx, size_t bytes, void** dptr) {
     ARG_CHECK(ctx && dptr);
+    CTX_GUARD(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
     if (e != hipSuccess) {
@@ -143,18 +150,21 @@ extern "C" int reid_malloc(reid_ctx* ctx, size_t bytes, void** dptr) {
 }
 extern "C" int reid_free(reid_ctx* ctx, void* dptr) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(dptr));
     return REID_OK;
 }
 extern "C" int reid_memcpy_h2d(reid_ctx* ctx, void* dst, const void* src, size_t bytes) {
     ARG_CHECK(ctx && dst && src);
+    CTX_GUARD(ctx);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return REID_OK;
 }
 extern "C" int reid_memcpy_d2h(reid_ctx* ctx, void* dst, const void* src, size_t bytes) {
     ARG_CHECK(ctx && dst && src);
+    CTX_GUARD(ctx);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return REID_OK;
@@ -163,11 +173,13 @@ extern "C" int reid_memcpy_d2h(reid_ctx* ctx, void* dst, const void* src, size_t
 // ------------------------------------------------------------------------------------------------ timing
 extern "C" int reid_timer_start(reid_ctx* ctx) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     HIP_TRY(hipEventRecord(ctx->t0, ctx->stream));
     return REID_OK;
 }
 extern "C" int reid_timer_stop(reid_ctx* ctx, float* ms) {
     ARG_CHECK(ctx && ms);
+    CTX_GUARD(ctx);
     HIP_TRY(hipEventRecord(ctx->t1, ctx->stream));
     HIP_TRY(hipEventSynchronize(ctx->t1));
     HIP_TRY(hipEventElapsedTime(ms, ctx->t0, ctx->t1));
@@ -209,18 +221,21 @@ static int prof_drain(reid_ctx* ctx) {
 }
 extern "C" int reid_profile_enable(reid_ctx* ctx, int on) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     REID_TRY(prof_drain(ctx));
     ctx->profile = on != 0;
     return REID_OK;
 }
 extern "C" int reid_profile_reset(reid_ctx* ctx) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     REID_TRY(prof_drain(ctx));
     for (auto& s : ctx->prof) s = ProfSlot();
     return REID_OK;
 }
 extern "C" int reid_profile_get(reid_ctx* ctx, int kind, double* ms, long long* launches, double* flops, double* bytes) {
     ARG_CHECK(ctx && kind >= 0 && kind < REID_K_COUNT);
+    CTX_GUARD(ctx);
     REID_TRY(prof_drain(ctx));
     if (ms) *ms = ctx->prof[kind].ms;
     if (launches) *launches = ctx->prof[kind].launches;
@@ -239,6 +254,7 @@ static const char* kBlkName[8] = {"b11", "b12", "b21", "b22", "b31", "b32", "b41
 
 extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floats, const char* manifest) {
     ARG_CHECK(ctx && blob && manifest && n_floats > 0);
+    CTX_GUARD(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     std::map<std::string, std::pair<size_t, size_t>> tab;
     {
@@ -357,6 +373,7 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
 
 extern "C" int reid_seres18_dims(reid_ctx* ctx, int* embed_dim, int* num_class) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     if (!ctx->se18.loaded) {
         reid_set_error("no weights loaded");
         return REID_ERR_STATE;
@@ -680,6 +697,7 @@ static const size_t kStageElems[11] = {524288, 131072, 131072, 131072, 65536, 65
 
 extern "C" int reid_debug_stage(reid_ctx* ctx, int stage, float* out, size_t max_floats, size_t* count) {
     ARG_CHECK(ctx && stage >= 0 && stage < 11 && out);
+    CTX_GUARD(ctx);
     if (!ctx->debug_keep || ctx->last_n <= 0) {
         reid_set_error("reid_debug_stage: enable reid_ctx_set_debug_keep before the embed call");
         return REID_ERR_STATE;
@@ -701,6 +719,7 @@ extern "C" int reid_debug_stage(reid_ctx* ctx, int stage, float* out, size_t max
 
 extern "C" int reid_embed_u8_dev(reid_ctx* ctx, const uint8_t* d_crops, int n, float* d_emb, float* d_logits) {
     ARG_CHECK(ctx && d_crops && d_emb && n >= 0);
+    CTX_GUARD(ctx);
     const int nc = ctx->se18.num_class;
     for (int i = 0; i < n; i += ctx->chunk) {
         const int m = n - i < ctx->chunk ? n - i : ctx->chunk;
@@ -712,6 +731,7 @@ extern "C" int reid_embed_u8_dev(reid_ctx* ctx, const uint8_t* d_crops, int n, f
 
 extern "C" int reid_embed_u8(reid_ctx* ctx, const uint8_t* crops, int n, float* emb, float* logits) {
     ARG_CHECK(ctx && crops && emb && n >= 0);
+    CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     const int nc = ctx->se18.num_class;
     uint8_t* d_in;
@@ -730,6 +750,7 @@ extern "C" int reid_embed_u8(reid_ctx* ctx, const uint8_t* crops, int n, float* 
 
 extern "C" int reid_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, float* d_emb, float* d_logits) {
     ARG_CHECK(ctx && d_x && d_emb && n >= 0);
+    CTX_GUARD(ctx);
     const int nc = ctx->se18.num_class;
     const size_t img = (size_t)IMG_H * IMG_W * 3;
     for (int i = 0; i < n; i += ctx->chunk) {
@@ -744,6 +765,7 @@ extern "C" int reid_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, f
 
 extern "C" int reid_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, float* emb, float* logits) {
     ARG_CHECK(ctx && x && emb && n >= 0);
+    CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     const int nc = ctx->se18.num_class;
     const size_t img = (size_t)IMG_H * IMG_W * 3;
@@ -762,6 +784,7 @@ extern "C" int reid_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, float* 
 extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
                                     float* emb, float* logits) {
     ARG_CHECK(ctx && packed && offsets && hw && emb && n >= 0);
+    CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     const int nc = ctx->se18.num_class;
     size_t total = 0;
@@ -802,6 +825,7 @@ extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const 
 extern "C" int reid_embed_frame_u8(reid_ctx* ctx, const uint8_t* frame, int fh, int fw, const int32_t* boxes_xyxy, int n,
                                    float* emb, float* logits) {
     ARG_CHECK(ctx && frame && boxes_xyxy && emb && fh >= 1 && fw >= 1 && n >= 0);
+    CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     const int nc = ctx->se18.num_class;
     std::vector<long long> off(n);
@@ -862,6 +886,7 @@ static int pad_rows(reid_ctx* ctx, const char* name, const float* d_x, int m, in
 extern "C" int reid_distmat_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric,
                                 float* d_out) {
     ARG_CHECK(ctx && d_x && d_y && d_out && m >= 0 && n >= 0 && d >= 1);
+    CTX_GUARD(ctx);
     ARG_CHECK(metric >= REID_METRIC_L2 && metric <= REID_METRIC_DOT);
     if (m == 0 || n == 0) return REID_OK;
     const float *xp, *yp;
@@ -900,6 +925,7 @@ struct HostIO {
 
 extern "C" int reid_distmat(reid_ctx* ctx, const float* x, int m, const float* y, int n, int d, int metric, float* out) {
     ARG_CHECK(ctx && x && y && out && m >= 0 && n >= 0 && d >= 1);
+    CTX_GUARD(ctx);
     if (m == 0 || n == 0) return REID_OK;
     HostIO io{ctx};
     REID_TRY(io.upload(x, m, y, n, d));
@@ -914,6 +940,7 @@ extern "C" int reid_distmat(reid_ctx* ctx, const float* x, int m, const float* y
 extern "C" int reid_argmin_rows_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric,
                                     int32_t* d_idx, float* d_val) {
     ARG_CHECK(ctx && d_idx && m >= 0 && n >= 1);
+    CTX_GUARD(ctx);
     if (m == 0) return REID_OK;
     float* dist;
     REID_TRY(ctx_ws(ctx, "sel.dist", (size_t)m * n * 4, (void**)&dist));
@@ -924,6 +951,7 @@ extern "C" int reid_argmin_rows_dev(reid_ctx* ctx, const float* d_x, int m, cons
 extern "C" int reid_argmin_rows(reid_ctx* ctx, const float* x, int m, const float* y, int n, int d, int metric, int32_t* idx,
                                 float* val) {
     ARG_CHECK(ctx && x && y && idx && m >= 0 && n >= 1 && d >= 1);
+    CTX_GUARD(ctx);
     if (m == 0) return REID_OK;
     HostIO io{ctx};
     REID_TRY(io.upload(x, m, y, n, d));
@@ -941,6 +969,7 @@ extern "C" int reid_argmin_rows(reid_ctx* ctx, const float* x, int m, const floa
 extern "C" int reid_knn_dev(reid_ctx* ctx, const float* d_xq, int nq, const float* d_xb, int nb, int d, int k, float* d_D,
                             int32_t* d_I) {
     ARG_CHECK(ctx && d_D && d_I && nq >= 0 && nb >= 1 && k >= 1);
+    CTX_GUARD(ctx);
     if (nq == 0) return REID_OK;
     // query tiles bound the scratch matrix to ~1 GiB
     const int rows_per = (int)((size_t(1) << 28) / (size_t)nb) > 0 ? (int)((size_t(1) << 28) / (size_t)nb) : 1;
@@ -957,6 +986,7 @@ extern "C" int reid_knn_dev(reid_ctx* ctx, const float* d_xq, int nq, const floa
 
 extern "C" int reid_knn(reid_ctx* ctx, const float* xq, int nq, const float* xb, int nb, int d, int k, float* D, int32_t* I) {
     ARG_CHECK(ctx && xq && xb && D && I && nq >= 0 && nb >= 1 && d >= 1 && k >= 1);
+    CTX_GUARD(ctx);
     if (nq == 0) return REID_OK;
     HostIO io{ctx};
     REID_TRY(io.upload(xq, nq, xb, nb, d));
@@ -974,6 +1004,7 @@ extern "C" int reid_knn(reid_ctx* ctx, const float* xq, int nq, const float* xb,
 static int reid_diou_cost_impl(reid_ctx* ctx, const double* tracks, int t, const double* dets, int m, double* out,
                                    int as_cost) {
     ARG_CHECK(ctx && tracks && dets && out && t >= 0 && m >= 0);
+    CTX_GUARD(ctx);
     if (t == 0 || m == 0) return REID_OK;
     double *dt, *dd, *dout;
     REID_TRY(ctx_ws(ctx, "diou.t", (size_t)t * 32, (void**)&dt));
@@ -997,6 +1028,7 @@ extern "C" int reid_rank_eval(reid_ctx* ctx, const float* qf, const int64_t* ql,
                               const int64_t* gl, const int64_t* gc, int ng, int d, int32_t* cmc_sum, double* ap,
                               int32_t* valid) {
     ARG_CHECK(ctx && qf && ql && qc && gf && gl && gc && cmc_sum && ap && valid && nq >= 1 && ng >= 1 && d >= 1);
+    CTX_GUARD(ctx);
     HostIO io{ctx};
     REID_TRY(io.upload(qf, nq, gf, ng, d));
     long long *dql, *dqc, *dgl, *dgc;
@@ -1037,6 +1069,7 @@ extern "C" int reid_conv2d_nhwc(reid_ctx* ctx, const float* x, int n, int h, int
                                 int s, int stride, int pad, const float* scale, const float* shift, const float* residual,
                                 int relu, float* out) {
     ARG_CHECK(ctx && x && wgt && out && n >= 1 && cin % 32 == 0 && (scale == nullptr) == (shift == nullptr));
+    CTX_GUARD(ctx);
     const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - s) / stride + 1;
     const size_t nin = (size_t)n * h * w * cin, nw = (size_t)cout * r * s * cin, nout = (size_t)n * ho * wo * cout;
     float *dx, *dw, *dout, *dsc = nullptr, *dsh = nullptr, *dres = nullptr;
@@ -1064,6 +1097,7 @@ extern "C" int reid_conv2d_nhwc(reid_ctx* ctx, const float* x, int n, int h, int
 
 extern "C" int reid_gemm_nt(reid_ctx* ctx, const float* a, int m, const float* b, int n, int k, const float* bias, float* c) {
     ARG_CHECK(ctx && a && b && c && m >= 1 && n >= 1 && k >= 1);
+    CTX_GUARD(ctx);
     float *da, *db, *dc, *dbias = nullptr;
     REID_TRY(ctx_ws(ctx, "op.x", (size_t)m * k * 4, (void**)&da));
     REID_TRY(ctx_ws(ctx, "op.w", (size_t)n * k * 4, (void**)&db));

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void bank_cost_kernel(const float* __restrict_
 
 extern "C" int reid_bank_create(reid_ctx* ctx, int max_tracks, int budget, int d, reid_bank** out) {
     ARG_CHECK(ctx && out && max_tracks >= 1 && budget >= 1 && d >= 1 && d <= 2048);
+    CTX_GUARD(ctx);
     ARG_CHECK((double)max_tracks * budget * d * 4.0 < 64e9);
     reid_bank* b = new reid_bank();
     b->ctx = ctx;
@@ -138,6 +139,7 @@ extern "C" int reid_bank_create(reid_ctx* ctx, int max_tracks, int budget, int d
 
 extern "C" int reid_bank_destroy(reid_bank* b) {
     if (!b) return REID_OK;
+    DeviceGuard _dev_guard(b->ctx->device);
     hipFree(b->feat);
     hipFree(b->sq);
     hipFree(b->count);
@@ -208,11 +210,13 @@ static int bank_update_impl(reid_ctx* ctx, reid_bank* b, const float* d_feats, c
 
 extern "C" int reid_bank_update_dev(reid_ctx* ctx, reid_bank* b, const float* d_feats, const int32_t* slots, int n) {
     ARG_CHECK(ctx && b && b->ctx == ctx && n >= 0 && (n == 0 || (d_feats && slots)));
+    CTX_GUARD(ctx);
     return bank_update_impl(ctx, b, d_feats, slots, n);
 }
 
 extern "C" int reid_bank_update(reid_ctx* ctx, reid_bank* b, const float* feats, const int32_t* slots, int n) {
     ARG_CHECK(ctx && b && b->ctx == ctx && n >= 0 && (n == 0 || (feats && slots)));
+    CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     float* d_f;
     REID_TRY(ctx_ws(ctx, "bank.in", (size_t)n * b->d * 4, (void**)&d_f));
@@ -223,6 +227,7 @@ extern "C" int reid_bank_update(reid_ctx* ctx, reid_bank* b, const float* feats,
 // forget tracks (the reference drops every target not in `active_targets`): their slots can be handed out again
 extern "C" int reid_bank_clear(reid_ctx* ctx, reid_bank* b, const int32_t* slots, int n) {
     ARG_CHECK(ctx && b && b->ctx == ctx && n >= 0 && (n == 0 || slots));
+    CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     std::vector<int32_t> h(2 * n, 0);
     for (int i = 0; i < n; ++i) {
@@ -260,6 +265,7 @@ static int bank_cost_impl(reid_ctx* ctx, reid_bank* b, const int32_t* slots, int
 extern "C" int reid_bank_cost_dev(reid_ctx* ctx, reid_bank* b, const int32_t* slots, int t, const float* d_dets, int m,
                                   int metric, float max_dist, float* d_out) {
     ARG_CHECK(ctx && b && b->ctx == ctx && t >= 0 && m >= 0);
+    CTX_GUARD(ctx);
     ARG_CHECK(metric == REID_METRIC_COS || metric == REID_METRIC_L2SQR);
     if (t == 0 || m == 0) return REID_OK;
     ARG_CHECK(slots && d_dets && d_out);
@@ -269,6 +275,7 @@ extern "C" int reid_bank_cost_dev(reid_ctx* ctx, reid_bank* b, const int32_t* sl
 extern "C" int reid_bank_cost(reid_ctx* ctx, reid_bank* b, const int32_t* slots, int t, const float* dets, int m, int metric,
                               float max_dist, float* out) {
     ARG_CHECK(ctx && b && b->ctx == ctx && t >= 0 && m >= 0);
+    CTX_GUARD(ctx);
     ARG_CHECK(metric == REID_METRIC_COS || metric == REID_METRIC_L2SQR);
     if (t == 0 || m == 0) return REID_OK;
     ARG_CHECK(slots && dets && out);

@@ -10,6 +10,7 @@
 extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int cfg,
                                    int iters, float* ms_per_launch) {
     ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded);
+    CTX_GUARD(ctx);
     typedef _Float16 f16;
     const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - r) / stride + 1;
     const size_t nin = (size_t)n * h * w * cin, nw = (size_t)cout * r * r * cin, nout = (size_t)n * ho * wo * cout;
@@ -52,6 +53,7 @@ extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, 
 extern "C" int reid_debug_conv_c64(reid_ctx* ctx, int n, const float* x, const float* w_krsc, const float* scale,
                                    const float* shift, const float* residual, int relu, float* out, float* stats) {
     ARG_CHECK(ctx && x && w_krsc && out && n >= 1);
+    CTX_GUARD(ctx);
     typedef _Float16 f16;
     const size_t nact = (size_t)n * 64 * 32 * 64, nw = 64 * 576;
     float *xf, *wf, *rf = nullptr, *sc = nullptr, *sh = nullptr, *st = nullptr, *of;
@@ -94,6 +96,7 @@ extern "C" int reid_debug_conv_c64(reid_ctx* ctx, int n, const float* x, const f
 extern "C" int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, int iters, float* ms_per_launch,
                                    unsigned long long* diag_host /* [64*8*4] or NULL */) {
     ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded);
+    CTX_GUARD(ctx);
     unsigned long long* d_diag = nullptr;
     if (diag_host) {
         REID_TRY(ctx_ws(ctx, "dbg.diag", 64 * 8 * 4 * 8, (void**)&d_diag));
@@ -133,6 +136,7 @@ extern "C" int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, 
 
 extern "C" int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long long* out_host /* [64*8*4] when disabling */) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     if (enable) {
         REID_TRY(ctx_ws(ctx, "dbg.cdiag", 64 * 8 * 5 * 8, (void**)&ctx->conv_diag));
         HIP_TRY(hipMemsetAsync(ctx->conv_diag, 0, 64 * 8 * 5 * 8, ctx->stream));
@@ -152,6 +156,7 @@ extern "C" int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long lon
 extern "C" int reid_debug_conv_f32(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int flags,
                                    int variant, int iters, float* ms_per_launch) {
     ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded && n >= 1);
+    CTX_GUARD(ctx);
     const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - r) / stride + 1;
     const size_t nin = (size_t)n * h * w * cin, nw = (size_t)cout * r * r * cin, nout = (size_t)n * ho * wo * cout;
     float *x, *wt, *out, *res, *asc, *ash, *stats;
@@ -192,4 +197,25 @@ extern "C" int reid_debug_conv_f32(reid_ctx* ctx, int n, int h, int w, int cin, 
     ctx->f32_conv = v0;
     *ms_per_launch = ms / (iters > 0 ? iters : 1);
     return st;
+}
+
+// The device k-way merge of reid_knn_gallery_sharded_dev on host lists (tests: any number of virtual shards on one GPU).
+extern "C" int reid_debug_knn_merge(reid_ctx* ctx, const float* Dall, const int32_t* Iall, int world, int nq, int kk, int k, float* D,
+                                    int32_t* I) {
+    ARG_CHECK(ctx && Dall && Iall && D && I && world >= 1 && nq >= 1 && kk >= 1 && k >= 1);
+    CTX_GUARD(ctx);
+    float *dD, *oD;
+    int32_t *dI, *oI;
+    const size_t cnt = (size_t)world * nq * kk;
+    REID_TRY(ctx_ws(ctx, "dbg.mD", cnt * 4, (void**)&dD));
+    REID_TRY(ctx_ws(ctx, "dbg.mI", cnt * 4, (void**)&dI));
+    REID_TRY(ctx_ws(ctx, "dbg.moD", (size_t)nq * k * 4, (void**)&oD));
+    REID_TRY(ctx_ws(ctx, "dbg.moI", (size_t)nq * k * 4, (void**)&oI));
+    HIP_TRY(hipMemcpyAsync(dD, Dall, cnt * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dI, Iall, cnt * 4, hipMemcpyHostToDevice, ctx->stream));
+    REID_TRY(launch_knn_merge(ctx, dD, dI, world, nq, kk, k, oD, oI));
+    HIP_TRY(hipMemcpyAsync(D, oD, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(I, oI, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
 }

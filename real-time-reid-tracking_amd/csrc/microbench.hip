@@ -128,6 +128,7 @@ __global__ __launch_bounds__(512) void mfma_shape_kernel(int iters, float* __res
 // shape 32 or 16; returns TFLOP/s of the chip over a launch of `iters` 32-k steps per wave (64 x 64 wave tile, 8 waves, 256+ blocks)
 extern "C" int reid_debug_mfma_shape(reid_ctx* ctx, int shape, int iters, int blocks, float* tflops) {
     ARG_CHECK(ctx && tflops && (shape == 32 || shape == 16) && iters > 0 && blocks > 0);
+    CTX_GUARD(ctx);
     float* sink;
     REID_TRY(ctx_ws(ctx, "dbg.sink", 64, (void**)&sink));
     for (int rep = 0; rep < 2; ++rep) {
@@ -145,6 +146,7 @@ extern "C" int reid_debug_mfma_shape(reid_ctx* ctx, int shape, int iters, int bl
 extern "C" int reid_debug_feed(reid_ctx* ctx, int mode, size_t footprint, int rowb, size_t stride, int iters, int inflight,
                                float* gbs_per_cu, float* tbs_chip) {
     ARG_CHECK(ctx && gbs_per_cu && tbs_chip && (rowb == 64 || rowb == 128 || rowb == 256 || rowb == 1024));
+    CTX_GUARD(ctx);
     char* buf;
     float* sink;
     REID_TRY(ctx_ws(ctx, "dbg.feed", footprint + 4096, (void**)&buf));
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(512) void coissue_kernel(int iters, int roles, cons
 
 extern "C" int reid_debug_coissue(reid_ctx* ctx, int mode, int iters, int roles, double* cyc_mfma_wave, double* cyc_other_wave) {
     ARG_CHECK(ctx && mode >= 0 && mode <= 3 && iters > 0 && cyc_mfma_wave && cyc_other_wave);
+    CTX_GUARD(ctx);
     float* src;
     unsigned long long* out;
     float* sink;

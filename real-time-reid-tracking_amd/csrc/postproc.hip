@@ -183,6 +183,7 @@ int gemm_nt_dev(reid_ctx* ctx, const float* a, int m, const float* b, int n, int
 // data_transforms.py:56-130); out: [n][512 + num_class].  flip_tta != 0 averages the descriptor of the mirrored image.
 extern "C" int reid_descriptor_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int flip_tta, float* d_out) {
     ARG_CHECK(ctx && d_x && d_out && n >= 0);
+    CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     int de = 0, nc = 0;
     REID_TRY(reid_seres18_dims(ctx, &de, &nc));
@@ -218,6 +219,7 @@ extern "C" int reid_descriptor_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int
 
 extern "C" int reid_descriptor_f32_nchw(reid_ctx* ctx, const float* x, int n, int flip_tta, float* out) {
     ARG_CHECK(ctx && x && out && n >= 0);
+    CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     int de = 0, nc = 0;
     REID_TRY(reid_seres18_dims(ctx, &de, &nc));
@@ -236,6 +238,7 @@ extern "C" int reid_descriptor_f32_nchw(reid_ctx* ctx, const float* x, int n, in
 // torch.inverse of an all-zero matrix would raise).  iters <= 0 selects the default number of Newton-Schulz steps.
 extern "C" int reid_cam_debias_dev(reid_ctx* ctx, float* d_x, const int32_t* cams, int n, int d, float la, int iters) {
     ARG_CHECK(ctx && d_x && cams && n >= 1 && d >= 1 && la > 0.f);
+    CTX_GUARD(ctx);
     if (iters <= 0) iters = 40;   // upper bound; the residual rule below stops after ~8-14 steps
     int ncam = 0;
     for (int i = 0; i < n; ++i) {
@@ -322,6 +325,7 @@ extern "C" int reid_cam_debias_dev(reid_ctx* ctx, float* d_x, const int32_t* cam
 
 extern "C" int reid_cam_debias(reid_ctx* ctx, float* x, const int32_t* cams, int n, int d, float la, int iters) {
     ARG_CHECK(ctx && x && cams && n >= 1 && d >= 1);
+    CTX_GUARD(ctx);
     float* dx;
     REID_TRY(ctx_ws(ctx, "cd.x", (size_t)n * d * 4, (void**)&dx));
     HIP_TRY(hipMemcpyAsync(dx, x, (size_t)n * d * 4, hipMemcpyHostToDevice, ctx->stream));

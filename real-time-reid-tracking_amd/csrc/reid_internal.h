@@ -7,6 +7,7 @@
 #include <map>
 #include <vector>
 #include "../../include/reid_hip.h"
+struct reid_ctx;
 
 void reid_set_error(const char* fmt, ...);
 
@@ -191,8 +192,14 @@ struct Se18Weights {
     const _Float16* h(const float* p) const { return blob16 + (p - blob); }
 };
 
+struct reid_comm;   // comm.hip: the RCCL communicator of this rank
+void comm_release(reid_ctx* ctx);
+// k-way merge of per-shard top-k lists [world][nq][kk] (global indices, -1 = padding) -> [nq][k] (comm.hip)
+int launch_knn_merge(reid_ctx* ctx, const float* Dall, const int32_t* Iall, int world, int nq, int kk, int k, float* D, int32_t* I);
+
 struct reid_ctx {
     int device = 0;
+    reid_comm* comm = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     int chunk = 64;
@@ -231,6 +238,23 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
 int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H, int W, int Cin, const _Float16* wgt, int Cout,
                 int R, int S, int stride, int pad, int K, const float* col_scale, const float* col_shift,
                 const _Float16* residual, int relu, float* stats, _Float16* out, int Hp = 0, int Wp = 0);
+
+// Every entry point runs on the context's device, whatever device the calling thread had current (hipSetDevice is
+// per-thread: a worker thread starts on device 0; a host application may have switched devices).  Restores on exit.
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define CTX_GUARD(ctx) DeviceGuard _dev_guard((ctx)->device)
+
 void swin_release(reid_ctx* ctx);   // frees the Swin weights held for this context (swin.hip)
 int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out);  // grow-only named workspace
 void prof_begin(reid_ctx* ctx, int kind, double flops, double bytes);

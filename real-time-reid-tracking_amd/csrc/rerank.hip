@@ -281,6 +281,7 @@ __global__ __launch_bounds__(512) void jaccard_kernel(int n, int w, const int32_
 extern "C" int reid_rerank_jaccard_dev(reid_ctx* ctx, const float* d_x, int n, int d, int k1, int k2, const int32_t* d_rank,
                                        float* d_out) {
     ARG_CHECK(ctx && d_x && d_out && n >= 1 && d >= 1 && k1 >= 1 && k1 <= MAX_K1 && k1 <= n && k2 >= 1);
+    CTX_GUARD(ctx);
     const int kh = (int)nearbyint(k1 / 2.0);   // np.around: half to even
     const int kh1 = kh + 1 < k1 ? kh + 1 : k1;
     const int k2e = k2 < k1 ? k2 : k1;         // initial_rank[i, :k2] has at most k1 columns
@@ -387,6 +388,7 @@ extern "C" int reid_rerank_jaccard_dev(reid_ctx* ctx, const float* d_x, int n, i
 extern "C" int reid_rerank_jaccard(reid_ctx* ctx, const float* x, int n, int d, int k1, int k2, const int32_t* rank,
                                    float* out) {
     ARG_CHECK(ctx && x && out && n >= 1 && d >= 1);
+    CTX_GUARD(ctx);
     float *dx, *dout;
     int32_t* drank = nullptr;
     REID_TRY(ctx_ws(ctx, "rr.x", (size_t)n * d * 4, (void**)&dx));

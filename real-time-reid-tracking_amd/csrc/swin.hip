@@ -442,6 +442,7 @@ void swin_release(reid_ctx* ctx) {
 
 extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats, const char* manifest) {
     ARG_CHECK(ctx && blob && manifest && n_floats > 0);
+    CTX_GUARD(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     std::map<std::string, std::pair<size_t, size_t>> tab;
     {
@@ -569,6 +570,7 @@ extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats,
 
 extern "C" int reid_swin_dims(reid_ctx* ctx, int* embed_dim, int* num_class) {
     ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
     auto it = swin_registry().find(ctx);
     if (it == swin_registry().end()) {
         reid_set_error("no Swin weights loaded");
@@ -746,6 +748,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
 
 extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int h, int w, float* d_emb, float* d_logits) {
     ARG_CHECK(ctx && d_x && d_emb && n >= 0 && h > 0 && w > 0 && h % 224 == 0 && w % 224 == 0);
+    CTX_GUARD(ctx);
     auto it = swin_registry().find(ctx);
     if (it == swin_registry().end() || !it->second.loaded) {
         reid_set_error("reid_swin_embed_*: call reid_swin_load first");
@@ -764,6 +767,7 @@ extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int
 
 extern "C" int reid_swin_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, int h, int w, float* emb, float* logits) {
     ARG_CHECK(ctx && x && emb && n >= 0);
+    CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     auto it = swin_registry().find(ctx);
     if (it == swin_registry().end()) {

@@ -656,3 +656,141 @@ def test_f16_path_small_and_odd_batches(eng_w0, n):
     assert (1 - cos).max() < 1e-4
     scale = np.abs(ref).max()
     assert np.abs(again[:n] - got).max() <= 2e-3 * scale and np.abs(again[n:][::-1] - got).max() <= 2e-3 * scale
+
+
+# ----------------------------------------------------------------------------- reference-held vectors at BASELINE sizes
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("tag,crops_fn,seed", [("rand0", synth.crops_u8, 0), ("smooth5", synth.smooth_crops_u8, 5)])
+def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, crops_fn, seed):
+    """BASELINE configs[0]: 256 crops -> emb[256,512] -> (1 - cos) / 2 matrix -> row arg-min, against vectors the REFERENCE's own
+    SERse18_IBN + cosine_dist produced (tests/golden/config1.npz, oracle/gen_golden.py:gen_config1).  The arg-min vector is
+    compared on ALL 256 rows: the number of differing rows is printed and every one of them must be a row whose top-2 gap in the
+    reference is inside the arithmetic's own noise (north_star: "argmin ranks bit-exact" - a rank can only be decided where the
+    reference itself separates the two candidates by more than one rounding of the distance)."""
+    eng, _ = eng_w0
+    g = np.load(os.path.join(golden_dir, "config1.npz"))
+    ref, gap = g[tag + "_emb"], g[tag + "_gap"]
+    eng.set_precision(precision)
+    try:
+        emb = eng.embed_u8(crops_fn(256, seed))
+    finally:
+        eng.set_precision(0)
+    cos = (emb * ref).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (1 - cos).max() < (1e-4 if precision else 1e-5)                # north_star allows 1e-3
+    dist = eng.distmat(emb, emb, _ffi.METRIC_COS_HALF)
+    np.testing.assert_allclose(dist, g[tag + "_cosdist"], atol=(2e-4 if precision else 2e-6))
+    d = dist.copy()
+    np.fill_diagonal(d, np.inf)
+    flips = np.flatnonzero(d.argmin(1) != g[tag + "_argmin"])
+    noise = 2e-4 if precision else 2e-6                                   # twice the distance error asserted above
+    decided = int((gap >= noise).sum())
+    print("config1 %s precision %d: %d of 256 rows decided (reference top-2 gap >= %.0e), %d arg-mins differ, largest gap among "
+          "them %.2e" % (tag, precision, decided, noise, len(flips), gap[flips].max() if len(flips) else 0.0))
+    assert (gap[flips] < noise).all(), (flips, gap[flips])
+    if tag == "smooth5":
+        assert decided >= (150 if precision else 250)                     # realistic crops: (nearly) every row is decided
+
+
+@pytest.mark.parametrize("tag,sigma", [("s03", 0.3), ("s30", 3.0)])
+def test_config5_market_full_size_against_reference(eng, golden_dir, tag, sigma):
+    """BASELINE configs[4] at full size, single GPU: 3368 x 15913 x 512 similarity + evaluate_all against the REFERENCE's
+    evaluate_all on the same synthetic Market-1501-sized problem (tests/golden/config5.npz): CMC exact, per-query first-good
+    rank exact, mAP, and the top-1 gallery index of every query (bit-exact wherever the top-2 score gap exceeds fp32 rounding)."""
+    from reid_amd.evaluate import evaluate_all
+    g = np.load(os.path.join(golden_dir, "config5.npz"))
+    qf, ql, qc, gf, gl, gc = synth.clustered_embeddings(3368, 15913, d=512, n_ids=751, n_cams=6, seed=4, sigma=sigma)
+    cmc, mean_ap = evaluate_all(qf, ql, qc, gf, gl, gc, verbose=False)
+    np.testing.assert_array_equal(np.asarray(cmc), g[tag + "_cmc"])       # Rank-1 .. Rank-15913 exact
+    assert abs(mean_ap - float(g[tag + "_map"])) < 1e-7                   # a near-tie may swap two ranks of one query
+    _, ap, valid = eng.rank_eval(qf, ql, qc, gf, gl, gc)
+    dap = np.abs(ap - g[tag + "_ap"])                                     # per-query AP: equal except where two gallery items tie to
+    assert (dap > 1e-9).sum() <= 0.02 * len(dap) and dap.max() < 5e-3, ((dap > 1e-9).sum(), dap.max())   # rounding and swap ranks
+    top1, _ = eng.argmin_rows(qf, gf, _ffi.METRIC_COS)                    # unit-norm rows: arg-min of 1 - cos = arg-max of gf @ q
+    flips = np.flatnonzero(top1 != g[tag + "_top1"])
+    for q in flips:                                                       # only exact or rounding-level ties may move
+        s = gf.astype(np.float64) @ qf[q].astype(np.float64)
+        assert abs(s[top1[q]] - s[g[tag + "_top1"][q]]) < 2e-7, (q, s[top1[q]], s[g[tag + "_top1"][q]])
+    print("config5 %s: Rank-1 %.6f mAP %.6f, %d of 3368 per-query APs differ by > 1e-9 (max %.1e), %d of 3368 top-1 indices differ "
+          "(all within 2e-7 of the reference's best score)" % (tag, float(np.asarray(cmc)[0]), mean_ap, int((dap > 1e-9).sum()), dap.max(), len(flips)))
+
+
+def test_entry_points_from_a_worker_thread(eng_w0):
+    """hipSetDevice is per-thread: a fresh thread starts on device 0 whatever the engine's device is.  Every C entry point
+    switches to the context's device itself (DeviceGuard), so a call from another thread gives the same bits."""
+    import threading
+    eng, _ = eng_w0
+    crops = synth.smooth_crops_u8(5, 77)
+    want = eng.embed_u8(crops)
+    got = {}
+
+    def work():
+        got["emb"] = eng.embed_u8(crops)
+        got["dist"] = eng.distmat(got["emb"], got["emb"], _ffi.METRIC_L2)
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert np.array_equal(got["emb"], want)
+    assert np.array_equal(got["dist"], eng.distmat(want, want, _ffi.METRIC_L2))
+
+
+# ----------------------------------------------------------------------------- multi-GPU exchange behind the C ABI (one GPU here)
+def test_rccl_single_rank_communicator_and_device_resident_sharding(eng_w0):
+    """The RCCL branch of parallel.py with a REAL 1-rank communicator (ncclCommInitRank with nranks = 1): every collective goes
+    through librccl, the sharded entry points stay in HBM, and the results equal the plain single-process calls."""
+    from reid_amd import parallel
+    eng, _ = eng_w0
+    comm = parallel.RcclComm(eng, 0, 1, parallel.RcclComm.unique_id())
+    try:
+        assert comm.all_reduce([3.0, -1.0], "max").tolist() == [3.0, -1.0]
+        comm.barrier()
+        x = np.random.default_rng(3).normal(size=(37, 512)).astype(np.float32)
+        dx = parallel.DevArray.from_numpy(eng, x)
+        dy = parallel.DevArray(eng, x.shape)
+        comm.all_gather(dx.ptr, dy.ptr, x.nbytes)                       # ncclAllGather, one rank
+        assert np.array_equal(dy.numpy(), x)
+        dz = parallel.DevArray(eng, x.shape)
+        assert comm.all_gather_rows(dx.ptr, 37, 512 * 4, dz.ptr) == [37]
+        assert np.array_equal(dz.numpy(), x)
+        crops = synth.smooth_crops_u8(9, 3)
+        emb_all, (lo, hi) = parallel.embed_sharded(eng, crops, comm=comm)   # DevArray, never on the host
+        assert (lo, hi) == (0, 9) and isinstance(emb_all, parallel.DevArray)
+        want = eng.embed_u8(crops)
+        assert np.array_equal(emb_all.numpy(), want)
+        block = parallel.distmat_row_block(eng, emb_all, 2, 7, _ffi.METRIC_L2)
+        assert np.array_equal(block.numpy(), eng.distmat(want[2:7], want, _ffi.METRIC_L2))
+        xb = np.random.default_rng(6).normal(size=(301, 64)).astype(np.float32)
+        xq = xb[:11] + 0.01
+        D, I = parallel.knn_gallery_sharded(eng, xq, xb, 7, comm=comm)
+        Dr, Ir = eng.knn(xq, xb, 7)
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    finally:
+        comm.close()
+    # without a communicator the same calls are local copies
+    solo = parallel.RcclComm(eng, 0, 1, None)
+    try:
+        D2, I2 = parallel.knn_gallery_sharded(eng, xq, xb, 7, comm=solo)
+        assert np.array_equal(I2, Ir)
+    finally:
+        solo.close()
+
+
+@pytest.mark.parametrize("world,kk,k", [(2, 5, 5), (8, 20, 20), (3, 4, 6)])
+def test_device_knn_merge_equals_host_merge(eng, world, kk, k):
+    """The merge kernel of reid_knn_gallery_sharded_dev on virtual shards: equal distances across shards (ties -> lowest global
+    row), -1 padding of short shards, fewer candidates than k."""
+    import ctypes as C
+    from reid_amd import parallel
+    rng = np.random.default_rng(world * 100 + k)
+    nq = 13
+    D = np.sort(rng.integers(0, 6, (world, nq, kk)).astype(np.float32) * 0.25, axis=2)      # many exact ties
+    I = rng.permutation(world * nq * kk).reshape(world, nq, kk).astype(np.int32)
+    I[-1, :, kk - 2:] = -1                                                                   # a short last shard
+    D[-1, :, kk - 2:] = np.inf
+    outD, outI = np.empty((nq, k), np.float32), np.empty((nq, k), np.int32)
+    fn = _ffi.debug_lib().reid_debug_knn_merge
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    _ffi.check(fn(eng.h, D.ctypes.data, I.ctypes.data, world, nq, kk, k, outD.ctypes.data, outI.ctypes.data))
+    wantD, wantI = parallel.merge_topk(list(D), list(I), k)
+    assert np.array_equal(outI, wantI)
+    assert np.array_equal(outD, wantD)
