@@ -162,6 +162,11 @@ int reid_descriptor_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int fli
  * iteration of fp32 GEMMs that stops when the residual reaches the fp32 noise floor (iters = upper bound, <= 0: 40). */
 int reid_cam_debias(reid_ctx* ctx, float* x, const int32_t* cams, int n, int d, float la, int iters);
 int reid_cam_debias_dev(reid_ctx* ctx, float* d_x, const int32_t* cams, int n, int d, float la, int iters);
+/* smooth_tracklets, reid/inference_utils.py:18-27, in place on x fp32 [n][d]: every row with valid[i] != 0 (valid NULL = all)
+ * becomes keep * row + (1 - keep) * mean of the valid rows that share its sequence id (keep = 0.1 in the reference).
+ * seqs / valid are host arrays. */
+int reid_smooth_tracklets(reid_ctx* ctx, float* x, const int32_t* seqs, const uint8_t* valid, int n, int d, float keep);
+int reid_smooth_tracklets_dev(reid_ctx* ctx, float* d_x, const int32_t* seqs, const uint8_t* valid, int n, int d, float keep);
 /* ---- DeepSORT appearance metric with the feature bank on the device ---------------------------
  * [external] deep_sort/sort/nn_matching.py NearestNeighborDistanceMetric (the per-frame consumer of Extractor.__call__;
  * MAX_DIST / NN_BUDGET from modification_deepsort/deep_sort.yaml:3,9).  A bank holds, per track slot, the last `budget`

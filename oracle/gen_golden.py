@@ -300,8 +300,19 @@ def gen_postproc():
     gf = gf + 0.15 * np.random.default_rng(42).normal(0, 1, (4, 93)).astype(np.float32)[gc]   # a per-camera offset to remove
     gf = (gf / np.linalg.norm(gf, axis=1, keepdims=True)).astype(np.float32)
     out = diminish_camera_bias(torch.from_numpy(gf.copy()), torch.from_numpy(gc), la=0.05).numpy()
-    np.savez_compressed(os.path.join(OUT, "postproc.npz"), x=gf, cams=gc.astype(np.int32), debiased=out)
-    print("postproc: debias", gf.shape, "mean |delta|", float(np.abs(out - gf).mean()))
+    # smooth_tracklets (reid/inference_utils.py:18-27) from the reference function: 9 tracklets, ~30 % of the rows not valid,
+    # one tracklet without any valid row (the reference's mean of nothing is caught by its bare except)
+    from reid.inference_utils import smooth_tracklets
+    rng = np.random.default_rng(44)
+    st_x = rng.normal(0, 1, (260, 77)).astype(np.float32)
+    st_seq = rng.integers(0, 9, 260).astype(np.int64) * 3 + 1
+    st_valid = rng.random(260) > 0.3
+    st_valid[st_seq == 7] = False
+    st_out = smooth_tracklets(torch.from_numpy(st_x.copy()), torch.from_numpy(st_seq), torch.from_numpy(st_valid)).numpy()
+    np.savez_compressed(os.path.join(OUT, "postproc.npz"), x=gf, cams=gc.astype(np.int32), debiased=out,
+                        st_x=st_x, st_seq=st_seq.astype(np.int32), st_valid=st_valid, st_out=st_out)
+    print("postproc: debias", gf.shape, "mean |delta|", float(np.abs(out - gf).mean()), "| smooth_tracklets mean |delta|",
+          float(np.abs(st_out - st_x).mean()))
 
 
 def gen_config1():

@@ -59,6 +59,8 @@ _SIGS = {
     "reid_descriptor_f32_nchw_dev": (_i, [_vp, _vp, _i, _i, _vp]),
     "reid_cam_debias": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _i]),
     "reid_cam_debias_dev": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _i]),
+    "reid_smooth_tracklets": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_float]),
+    "reid_smooth_tracklets_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_float]),
     "reid_bank_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
     "reid_bank_destroy": (_i, [_vp]),
     "reid_bank_update": (_i, [_vp, _vp, _vp, _vp, _i]),

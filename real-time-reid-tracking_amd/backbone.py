@@ -28,6 +28,43 @@ def _device_index(device):
     return int(s)
 
 
+def _copy_matching(dst, src, strict, resizable=()):
+    """Copies checkpoint tensors into the held state_dict.  A shape mismatch raises when ``strict`` (as torch does:
+    "size mismatch for ..."); otherwise the tensor is skipped with a warning naming it - except the classifier, whose row
+    count (num_classes of the training set) is taken from the checkpoint.  Returns the skipped keys."""
+    bad = []
+    for k, v in src.items():
+        if k not in dst:
+            continue
+        v = np.asarray(v)
+        if tuple(dst[k].shape) == tuple(v.shape):
+            dst[k] = v.astype(dst[k].dtype)
+        elif k in resizable and v.ndim == dst[k].ndim and v.shape[1:] == dst[k].shape[1:]:
+            dst[k] = v.astype(dst[k].dtype)             # a checkpoint trained with another number of identities
+        else:
+            bad.append("%s: checkpoint %s vs model %s" % (k, tuple(v.shape), tuple(dst[k].shape)))
+    if bad:
+        if strict:
+            raise RuntimeError("Error(s) in loading state_dict: size mismatch for " + "; ".join(bad[:5]))
+        import warnings
+        warnings.warn("load_state_dict(strict=False): skipped tensors with another shape (seeded values kept): " + "; ".join(bad))
+    return [b.split(":")[0] for b in bad]
+
+
+def _torch_cuda_forward(x, embed_dev, engine, out_dims):
+    """CUDA tensor in -> CUDA tensors out, no host round trip: the device entry point runs on ``x.data_ptr()`` on torch's
+    current stream of that device (the yolov8_tracking multibackend hands the model CUDA batches every frame)."""
+    import torch
+    xf = x.detach()
+    if xf.dtype != torch.float32 or not xf.is_contiguous():
+        xf = xf.float().contiguous()
+    with torch.cuda.device(xf.device):
+        engine.use_torch_stream()
+        outs = [torch.empty((xf.shape[0], d), dtype=torch.float32, device=xf.device) for d in out_dims]
+        embed_dev(xf, outs)
+    return outs
+
+
 class SERes18IBN:
     """ResNet18-IBN-a + SE + GeM + BNNeck ("ResNet18-SE"), eval mode only.
 
@@ -94,13 +131,11 @@ class SERes18IBN:
         unexpected = [k for k in sd if k not in self._sd]
         if strict and (missing or unexpected):
             raise RuntimeError("Error(s) in loading state_dict: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
-        for k, v in sd.items():
-            if k in self._sd and tuple(self._sd[k].shape) == tuple(v.shape):
-                self._sd[k] = np.asarray(v).astype(self._sd[k].dtype)
+        mismatched = _copy_matching(self._sd, sd, strict, resizable=("classifier.0.weight",))
         if "classifier.0.weight" in self._sd:
             self.num_classes = self._sd["classifier.0.weight"].shape[0]
         self._dirty = True
-        return missing, unexpected
+        return missing, unexpected + mismatched
 
     # ---- engine
     def _engine(self):
@@ -121,17 +156,23 @@ class SERes18IBN:
         if cam is not None:
             raise NotImplementedError("camera-bias term (SERes18_IBN.py:269-270) is never used by the extractor path")
         is_torch = hasattr(x, "detach")
-        if is_torch:
-            dev = x.device
-            x_np = x.detach().float().cpu().numpy()
+        if not is_torch:
+            x = np.asarray(x, np.float32)
+        if x.ndim != 4 or tuple(x.shape[1:]) != (3, IMG_H, IMG_W):
+            raise ValueError("expected [N,3,%d,%d] input, got %s" % (IMG_H, IMG_W, tuple(x.shape)))
+        if is_torch and x.is_cuda:
+            if x.device.index != self._device:
+                self.to(x.device.index)
+            eng = self._engine()
+            emb, logits = _torch_cuda_forward(
+                x, lambda xf, o: eng.embed_f32_nchw_dev(xf.data_ptr(), xf.shape[0], o[0].data_ptr(), o[1].data_ptr()), eng,
+                (self.embed_dim, self.num_classes))
         else:
-            x_np = np.asarray(x, np.float32)
-        if x_np.ndim != 4 or x_np.shape[1:] != (3, IMG_H, IMG_W):
-            raise ValueError("expected [N,3,%d,%d] input, got %s" % (IMG_H, IMG_W, tuple(x_np.shape)))
-        emb, logits = self._engine().embed_f32_nchw(x_np, logits=True)
-        if is_torch:
-            import torch
-            emb, logits = torch.from_numpy(emb).to(dev), torch.from_numpy(logits).to(dev)
+            x_np = x.detach().float().cpu().numpy() if is_torch else np.asarray(x, np.float32)
+            emb, logits = self._engine().embed_f32_nchw(x_np, logits=True)
+            if is_torch:
+                import torch
+                emb, logits = torch.from_numpy(emb), torch.from_numpy(logits)
         if self.is_reid:
             return logits                                   # SERes18_IBN.py:272-273
         return (emb, logits) if return_logits else emb
@@ -186,11 +227,12 @@ class SwinT:
         unexpected = [k for k in sd if k not in self._sd]
         if strict and (missing or unexpected):
             raise RuntimeError("Error(s) in loading state_dict: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
-        for k, v in sd.items():
-            if k in self._sd and tuple(self._sd[k].shape) == tuple(v.shape):
-                self._sd[k] = np.asarray(v).astype(self._sd[k].dtype)
+        mismatched = _copy_matching(self._sd, sd, strict, resizable=("classifier.weight", "classifier.0.weight"))
+        for k in ("classifier.weight", "classifier.0.weight"):
+            if k in self._sd:
+                self.num_classes = self._sd[k].shape[0]
         self._dirty = True
-        return missing, unexpected
+        return missing, unexpected + mismatched
 
     def _engine(self):
         eng = get_engine(self._device)
@@ -209,15 +251,21 @@ class SwinT:
         if view_index is not None:
             raise NotImplementedError("side-information embedding (swin_transformer.py:301-302) is not used by the plugin path")
         is_torch = hasattr(x, "detach")
-        if is_torch:
-            dev = x.device
-            x_np = x.detach().float().cpu().numpy()
+        if is_torch and x.is_cuda:
+            if x.ndim != 4 or x.shape[1] != 3 or x.shape[2] % 224 or x.shape[3] % 224:
+                raise ValueError("expected float[n,3,224k,224m], got %s" % (tuple(x.shape),))
+            if x.device.index != self._device:
+                self.to(x.device.index)
+            eng = self._engine()
+            emb, logits = _torch_cuda_forward(
+                x, lambda xf, o: eng.swin_embed_dev(xf.data_ptr(), xf.shape[0], xf.shape[2], xf.shape[3], o[0].data_ptr(), o[1].data_ptr()),
+                eng, (self.embed_dim, self.num_classes))
         else:
-            x_np = np.asarray(x, np.float32)
-        emb, logits = self._engine().swin_embed_f32_nchw(x_np, logits=True)
-        if is_torch:
-            import torch
-            emb, logits = torch.from_numpy(emb).to(dev), torch.from_numpy(logits).to(dev)
+            x_np = x.detach().float().cpu().numpy() if is_torch else np.asarray(x, np.float32)
+            emb, logits = self._engine().swin_embed_f32_nchw(x_np, logits=True)
+            if is_torch:
+                import torch
+                emb, logits = torch.from_numpy(emb), torch.from_numpy(logits)
         return (logits, emb) if return_logits else emb
 
     forward = __call__

@@ -304,6 +304,10 @@ extern "C" int reid_cam_debias_dev(reid_ctx* ctx, float* d_x, const int32_t* cam
             HIP_TRY(hipStreamSynchronize(st));
             const float r = sqrtf(r2);
             if (getenv("REID_DEBUG_CD")) fprintf(stderr, "cam %d it %d r %g\n", c, it, r);
+            if (it == 0 && !(r < INFINITY)) {   // NaN / inf in the input rows: there is no previous iterate to fall back to
+                reid_set_error("reid_cam_debias: non-finite residual for camera %d (NaN or inf in its rows?)", c);
+                return REID_ERR_ARG;
+            }
             if (!(r < r_prev)) {            // got worse (or NaN): the previous iterate is the answer
                 float* t = xa; xa = xb; xb = t;
                 break;
@@ -330,6 +334,63 @@ extern "C" int reid_cam_debias(reid_ctx* ctx, float* x, const int32_t* cams, int
     REID_TRY(ctx_ws(ctx, "cd.x", (size_t)n * d * 4, (void**)&dx));
     HIP_TRY(hipMemcpyAsync(dx, x, (size_t)n * d * 4, hipMemcpyHostToDevice, ctx->stream));
     REID_TRY(reid_cam_debias_dev(ctx, dx, cams, n, d, la, iters));
+    HIP_TRY(hipMemcpyAsync(x, dx, (size_t)n * d * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
+// ---- smooth_tracklets, reid/inference_utils.py:18-27: every valid row of a tracklet (rows with the same sequence id) becomes
+// keep * row + (1 - keep) * mean(valid rows of the tracklet), keep = 0.1 in the reference.  Rows are grouped on the host (CSR
+// of row indices per tracklet); one block column-slice per tracklet: a thread owns a column, sums it over the tracklet's rows
+// in row order (coalesced across the 256 columns of the slice), then rewrites the rows.
+__global__ __launch_bounds__(256) void smooth_tracklets_kernel(float* __restrict__ x, const int32_t* __restrict__ rows,
+                                                               const int32_t* __restrict__ start, int d, float keep) {
+    const int g = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
+    if (col >= d) return;
+    const int b = start[g], e = start[g + 1];
+    float acc = 0.f;
+    for (int i = b; i < e; ++i) acc += x[(long long)rows[i] * d + col];
+    const float avg = acc / (float)(e - b);
+    for (int i = b; i < e; ++i) {
+        float* p = x + (long long)rows[i] * d + col;
+        *p = *p * keep + avg * (1.0f - keep);
+    }
+}
+
+extern "C" int reid_smooth_tracklets_dev(reid_ctx* ctx, float* d_x, const int32_t* seqs, const uint8_t* valid, int n, int d,
+                                         float keep) {
+    ARG_CHECK(ctx && d_x && seqs && n >= 0 && d >= 1);
+    CTX_GUARD(ctx);
+    if (n == 0) return REID_OK;
+    std::map<int32_t, std::vector<int32_t>> groups;   // ordered like np.unique(seqs)
+    for (int i = 0; i < n; ++i)
+        if (!valid || valid[i]) groups[seqs[i]].push_back(i);
+    if (groups.empty()) return REID_OK;
+    std::vector<int32_t> rows, start(1, 0);
+    for (auto& kv : groups) {
+        rows.insert(rows.end(), kv.second.begin(), kv.second.end());
+        start.push_back((int32_t)rows.size());
+    }
+    int32_t *d_rows, *d_start;
+    REID_TRY(ctx_ws(ctx, "st.rows", rows.size() * 4, (void**)&d_rows));
+    REID_TRY(ctx_ws(ctx, "st.start", start.size() * 4, (void**)&d_start));
+    HIP_TRY(hipMemcpyAsync(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_start, start.data(), start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(smooth_tracklets_kernel, dim3((unsigned)groups.size(), (d + 255) / 256), dim3(256), 0, ctx->stream, d_x, d_rows,
+                       d_start, d, keep);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // rows / start are locals
+    return REID_OK;
+}
+
+extern "C" int reid_smooth_tracklets(reid_ctx* ctx, float* x, const int32_t* seqs, const uint8_t* valid, int n, int d, float keep) {
+    ARG_CHECK(ctx && x && seqs && n >= 0 && d >= 1);
+    CTX_GUARD(ctx);
+    if (n == 0) return REID_OK;
+    float* dx;
+    REID_TRY(ctx_ws(ctx, "cd.x", (size_t)n * d * 4, (void**)&dx));
+    HIP_TRY(hipMemcpyAsync(dx, x, (size_t)n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+    REID_TRY(reid_smooth_tracklets_dev(ctx, dx, seqs, valid, n, d, keep));
     HIP_TRY(hipMemcpyAsync(x, dx, (size_t)n * d * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return REID_OK;

@@ -49,7 +49,18 @@ class Engine:
         check(self.lib.reid_ctx_sync(self.h))
 
     def set_stream(self, hip_stream):
-        check(self.lib.reid_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+        """Run on another HIP stream (0 / None = the context's own).  Work already enqueued on the old stream shares the
+        context's workspaces with what follows, so a switch drains the old stream first."""
+        new = int(hip_stream or 0)
+        if new != getattr(self, "_stream", 0):
+            self.sync()
+            check(self.lib.reid_ctx_set_stream(self.h, C.c_void_p(new)))
+            self._stream = new
+
+    def use_torch_stream(self):
+        """Enqueue on torch's current stream of this device (CUDA-tensor entry points of the backbones)."""
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
     def set_chunk(self, n):
         check(self.lib.reid_ctx_set_chunk(self.h, int(n)))
@@ -178,6 +189,9 @@ class Engine:
         check(self.lib.reid_embed_f32_nchw(self.h, _ptr(x), x.shape[0], _ptr(emb), _ptr(lg)))
         return (emb, lg) if logits else emb
 
+    def embed_f32_nchw_dev(self, d_x, n, d_emb, d_logits=None):
+        check(self.lib.reid_embed_f32_nchw_dev(self.h, C.c_void_p(d_x), int(n), C.c_void_p(d_emb), C.c_void_p(d_logits or 0)))
+
     def embed_u8_dev(self, d_crops, n, d_emb, d_logits=None):
         check(self.lib.reid_embed_u8_dev(self.h, C.c_void_p(d_crops), int(n), C.c_void_p(d_emb),
                                          C.c_void_p(d_logits or 0)))
@@ -246,6 +260,16 @@ class Engine:
         if x.ndim != 2 or cams.shape[0] != x.shape[0]:
             raise ValueError("cam_debias expects x[n,d] and cams[n]")
         check(self.lib.reid_cam_debias(self.h, _ptr(x), _ptr(cams), x.shape[0], x.shape[1], C.c_float(la), int(iters)))
+        return x
+
+    def smooth_tracklets(self, x, seqs, valid=None, keep=0.1):
+        """smooth_tracklets (reid/inference_utils.py:18-27) on the device; returns a new float32 [n, d] array."""
+        x = np.array(_f32(x), copy=True)
+        seqs = np.ascontiguousarray(seqs, dtype=np.int32).reshape(-1)
+        if x.ndim != 2 or seqs.shape[0] != x.shape[0]:
+            raise ValueError("smooth_tracklets expects x[n,d] and seqs[n]")
+        v = None if valid is None else np.ascontiguousarray(np.asarray(valid).reshape(-1) != 0, dtype=np.uint8)
+        check(self.lib.reid_smooth_tracklets(self.h, _ptr(x), _ptr(seqs), _ptr(v), x.shape[0], x.shape[1], C.c_float(keep)))
         return x
 
     def rerank_jaccard(self, x, k1=20, k2=6, rank=None):

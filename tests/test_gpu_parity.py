@@ -794,3 +794,67 @@ def test_device_knn_merge_equals_host_merge(eng, world, kk, k):
     wantD, wantI = parallel.merge_topk(list(D), list(I), k)
     assert np.array_equal(outI, wantI)
     assert np.array_equal(outD, wantD)
+
+
+# ----------------------------------------------------------------------------- plugin surface on the device
+def test_build_model_warmup_and_cuda_tensor_entry(eng_w0):
+    """What track_yolov5.py:167-171 does with the object build_model returns: .to(device).eval(), warmup(), then
+    model(cuda_batch) every frame.  A CUDA tensor goes through the device entry point on torch's current stream (no host
+    round trip: the result is a CUDA tensor) and equals the numpy entry bit for bit; fp16 CUDA batches are widened on entry."""
+    from reid_amd.models import build_model
+    eng, sd = eng_w0
+    model = build_model("seres18_ibn", num_classes=751, loss="triplet", pretrained=False, use_gpu=True)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval().half()
+    assert model.warmup() is model                                      # no-arg warmup(): one dummy batch
+    x = seres18.preprocess_u8(synth.smooth_crops_u8(6, 21))              # float32 [6,3,256,128]
+    want = model(x.numpy())
+    xc = x.cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                                          # a non-default current stream, as a tracker thread may have
+        got = model(xc)
+        e2, lg = model(xc.half(), return_logits=True)
+    s.synchronize()
+    assert got.is_cuda and got.dtype == torch.float32 and tuple(got.shape) == (6, 512)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert lg.is_cuda and tuple(lg.shape) == (6, 751)
+    cos = F.cosine_similarity(e2.float().cpu(), torch.from_numpy(want), dim=1)
+    assert float((1 - cos).max()) < 1e-5                                # inputs rounded to fp16, arithmetic still fp32
+    # host call right after a device call on another stream: the engine drains the old stream before it switches
+    eng.set_stream(None)
+    assert np.array_equal(eng.embed_f32_nchw(x.numpy()), want)
+
+
+def test_swin_cuda_tensor_entry(eng):
+    from reid_amd.models import build_model
+    model = build_model("swin_transformer", num_classes=751, loss="softmax", pretrained=False, use_gpu=True).to("cuda").eval()
+    model.warmup()
+    x = synth.images_f32(2, 3)
+    want = model(x)
+    got = model(torch.from_numpy(x).cuda())
+    assert got.is_cuda and np.array_equal(got.cpu().numpy(), want)
+    eng.set_stream(None)
+
+
+def test_cam_debias_rejects_non_finite_rows(eng):
+    x = np.random.default_rng(0).normal(size=(40, 32)).astype(np.float32)
+    x[3, 5] = np.nan
+    with pytest.raises(_ffi.ReidHipError, match="non-finite"):
+        eng.cam_debias(x, np.zeros(40, np.int32))
+
+
+def test_smooth_tracklets_matches_reference_fixture(eng, golden_dir):
+    """reid_smooth_tracklets against the reference's own smooth_tracklets output (tests/golden/postproc.npz, st_* keys)."""
+    from reid_amd import inference_utils
+    z = np.load(os.path.join(golden_dir, "postproc.npz"))
+    got = eng.smooth_tracklets(z["st_x"], z["st_seq"], z["st_valid"])
+    np.testing.assert_allclose(got, z["st_out"], rtol=0, atol=2e-6)       # the mean is summed in row order, torch's in a tree
+    assert np.array_equal(got[~z["st_valid"]], z["st_x"][~z["st_valid"]])
+    t = torch.from_numpy(z["st_x"].copy())
+    assert inference_utils.smooth_tracklets(t, torch.from_numpy(z["st_seq"]), torch.from_numpy(z["st_valid"])) is t   # in place
+    np.testing.assert_allclose(t.numpy(), z["st_out"], rtol=0, atol=2e-6)
+    assert eng.smooth_tracklets(np.zeros((0, 8), np.float32), np.zeros(0, np.int32)).shape == (0, 8)
+    wide = np.random.default_rng(1).normal(size=(50, 1263)).astype(np.float32)      # descriptor width of the evaluation script
+    from oracle import postproc
+    seq = np.arange(50) % 4
+    np.testing.assert_allclose(eng.smooth_tracklets(wide, seq), postproc.smooth_tracklets(wide, seq, np.ones(50, bool)), atol=2e-6)

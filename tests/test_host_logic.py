@@ -27,6 +27,20 @@ def test_library_exports_every_declared_symbol(built_lib):
     for sym in declared:
         assert hasattr(built_lib, sym), sym
     assert declared == set(_ffi.EXPORTS)          # the ctypes binding covers exactly the header
+    # ... and the product library exports nothing else under the reid_ prefix: experiments live in libreid_hip_debug.so
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (reid_\w+)$", nm, flags=re.M))
+    assert exported == declared, exported ^ declared
+
+
+def test_debug_library_matches_its_header(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "reid_hip_debug.h")).read()
+    declared = set(re.findall(r"^int\s+(reid_debug_\w+)\s*\(", hdr, flags=re.M))
+    dbg = _ffi.debug_lib()
+    for sym in declared:
+        assert hasattr(dbg, sym), sym
+    assert declared == set(_ffi.DEBUG_EXPORTS)
 
 
 def test_no_gpu_means_loud_failure(built_lib):
@@ -191,3 +205,24 @@ def test_nn_matching_oracle_known_answers():
     m2.partial_fit([], [], [2])                                 # target 1 is dropped
     with pytest.raises(KeyError):
         m2.distance(e[:1], [1])
+
+
+def test_load_state_dict_shape_mismatch_is_loud():
+    """A checkpoint tensor of another shape raises when strict (torch: "size mismatch for ..."), is reported when not strict, and
+    a classifier trained on another number of identities is taken from the checkpoint (silent skips left seeded
+    tensors in place)."""
+    import warnings
+    from reid_amd.backbone import SERes18IBN
+    m = SERes18IBN(num_classes=751)
+    sd = {k: np.array(v) for k, v in m.state_dict().items()}
+    sd["classifier.0.weight"] = np.ones((123, 512), np.float32)          # Market -> another dataset: resized, not skipped
+    m.load_state_dict(sd, strict=True)
+    assert m.num_classes == 123 and m._sd["classifier.0.weight"].shape == (123, 512)
+    bad = dict(sd)
+    bad["bnneck.weight"] = np.ones(7, np.float32)
+    with pytest.raises(RuntimeError, match="size mismatch for bnneck.weight"):
+        m.load_state_dict(bad, strict=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        missing, skipped = m.load_state_dict(bad, strict=False)
+    assert "bnneck.weight" in skipped and any("bnneck.weight" in str(x.message) for x in w)

@@ -199,3 +199,13 @@ def test_config5_oracle_matches_reference(golden_dir, tag, sigma):
     # numpy's gf @ q and torch.mm sum in different orders: a near-tie between two gallery items may swap two ranks of one query
     # (seen: 1e-9 on the mean); first-good ranks (the CMC) are exact
     assert abs(mean_ap - float(g[tag + "_map"])) < 1e-7
+
+
+def test_smooth_tracklets_oracle_matches_reference(golden_dir):
+    """oracle/postproc.py:smooth_tracklets against the reference's own function (reid/inference_utils.py:18-27)."""
+    from oracle import postproc
+    z = np.load(os.path.join(golden_dir, "postproc.npz"))
+    got = postproc.smooth_tracklets(z["st_x"], z["st_seq"], z["st_valid"])
+    np.testing.assert_allclose(got, z["st_out"], rtol=0, atol=2e-6)
+    untouched = ~z["st_valid"]
+    assert np.array_equal(got[untouched], z["st_x"][untouched]) and untouched.sum() > 40   # incl. the tracklet with no valid row
