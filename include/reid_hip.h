@@ -67,6 +67,8 @@ int reid_ctx_create(int device, reid_ctx** out);
 int reid_ctx_destroy(reid_ctx* ctx);
 /* run on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own stream */
 int reid_ctx_set_stream(reid_ctx* ctx, void* hip_stream);
+/* run on the HIP null (legacy default) stream - torch's default stream; its handle 0 means "own stream" to reid_ctx_set_stream */
+int reid_ctx_set_null_stream(reid_ctx* ctx);
 int reid_ctx_sync(reid_ctx* ctx);
 /* crops per pass through the network (activation working set = chunk * 3.2 MB, kept inside the 256 MiB Infinity Cache) */
 int reid_ctx_set_chunk(reid_ctx* ctx, int crops_per_pass);
@@ -118,6 +120,9 @@ int reid_ctx_set_debug_keep(reid_ctx* ctx, int on);   /* tests only: give every 
                                                         * fp16 stem into conv + pool kernels so that stage 0 exists,
                                                         * 2 keeps the production (fused) kernels: stage 0 is not written */
 int reid_debug_stage(reid_ctx* ctx, int stage, float* out_host, size_t max_floats, size_t* count);
+/* the same for the Swin backbone: stage 0 = ShadowFeatureExtraction output [n][H/4][W/4][96], 1..4 = the four stage outputs (NHWC),
+ * 5 = GeM_1D output [n][96]; valid after a reid_swin_embed_* call that ran as one pass (n <= min(chunk, 256)) */
+int reid_debug_swin_stage(reid_ctx* ctx, int stage, float* out_host, size_t max_floats, size_t* count);
 
 /* ---- Swin-T backbone (reference "v1": reid/backbones/swin_transformer.py:339-427, swin_t :508-513) -------------------
  * Packed weights from reid_amd.weights.pack_swin.  Input: normalised float images fp32[n][3][h][w] NCHW with h, w multiples

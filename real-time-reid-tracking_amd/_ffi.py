@@ -22,6 +22,7 @@ _SIGS = {
     "reid_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "reid_ctx_destroy": (_i, [_vp]),
     "reid_ctx_set_stream": (_i, [_vp, _vp]),
+    "reid_ctx_set_null_stream": (_i, [_vp]),
     "reid_ctx_sync": (_i, [_vp]),
     "reid_ctx_set_chunk": (_i, [_vp, _i]),
     "reid_ctx_set_precision": (_i, [_vp, _i]),
@@ -49,6 +50,7 @@ _SIGS = {
     "reid_swin_embed_f32_nchw_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "reid_ctx_set_debug_keep": (_i, [_vp, _i]),
     "reid_debug_stage": (_i, [_vp, _i, _vp, _sz, C.POINTER(_sz)]),
+    "reid_debug_swin_stage": (_i, [_vp, _i, _vp, _sz, C.POINTER(_sz)]),
     "reid_distmat": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "reid_distmat_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "reid_argmin_rows": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),

@@ -38,6 +38,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     c->device = device;
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
     if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
+    if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
     if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e);   // 0 GEMM + pool, 1 fused, 2 fused reading uint8 crops
@@ -79,6 +80,15 @@ extern "C" int reid_ctx_set_stream(reid_ctx* ctx, void* s) {
     ARG_CHECK(ctx);
     CTX_GUARD(ctx);
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return REID_OK;
+}
+
+// The HIP null ("legacy default") stream: what torch.cuda.current_stream() is unless the host changed it; its handle is 0, which
+// reid_ctx_set_stream reads as "back to the context's own stream", hence a separate entry point.
+extern "C" int reid_ctx_set_null_stream(reid_ctx* ctx) {
+    ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
+    ctx->stream = nullptr;
     return REID_OK;
 }
 

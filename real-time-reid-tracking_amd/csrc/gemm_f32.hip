@@ -315,6 +315,8 @@ int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int 
     if (amode == A_IM2COL) ARG_CHECK(p.Cin % 32 == 0 && p.K == p.R * p.S * p.Cin);
     if (amode == A_STEM_F32 || amode == A_STEM_U8) ARG_CHECK(p.K == 192 && p.Cin == 3);
     if (epi == E_CONV && p.stats) ARG_CHECK(p.M % BM == 0);
+    // dense contractions (distance matrix, Linear layers): the LDS-DMA kernel (REID_F32_CONV=0 / 2 keep this file's kernel for A/B)
+    if (ctx->f32_conv == 1 && gemm_f32_dma_supported(amode, epi, p)) return launch_gemm_f32_dma(ctx, epi, p, kind, flops, bytes);
     prof_begin(ctx, kind, flops, bytes);
     int st = REID_ERR_ARG;
     if (amode == A_DENSE && epi == E_DIST) st = launch_bn<A_DENSE, E_DIST>(ctx, p);

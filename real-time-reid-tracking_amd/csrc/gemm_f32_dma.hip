@@ -1,0 +1,229 @@
+// C[M][N] = A[M][K] . B[N][K]^T (dense, row-major, K contiguous) on v_mfma_f32_32x32x2_f32 with LDS-DMA staging - the
+// dense sibling of conv_f32_dma_kernel (conv_f32.hip) for
+//   * the N x M distance matrix (reid/losses/utils.py:12-35, reid/evaluate.py:58): distance epilogue,
+//   * the Swin Linear layers in exact-fp32 mode (swin_transformer.py:23-39, 191-232): bias / erf-GELU / residual epilogue,
+//   * the classifier (SERes18_IBN.py:271).
+// Same reasoning as there: beside back-to-back fp32 MFMAs a SIMD issues one VALU instruction per ~19 cycles, so the loader
+// must not cost VALU.  A K-tile is 8 x buffer_load_dwordx4 ... lds per wave with per-lane byte offsets fixed for the whole
+// kernel and the K offset in the scalar operand; ragged edges need no predicates in the loop: the buffer descriptors end at
+// row M of A / row N of B, so rows past the edge read as zeros.  128 x {64,128} tile, 4 waves, BK = 32, two LDS stages,
+// XOR-swizzled 128-byte rows (conflict-free ds_read_b128), one s_waitcnt vmcnt(0) + one raw s_barrier per K-tile.
+// Requirements: K % 32 == 0, 16-byte aligned rows (lda, ldb % 4 == 0); everything else falls back to gemm_f32_kernel.
+#include "reid_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(uintptr_t)(p))
+#define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
+    constexpr int ROWB = BK * 4;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int AJ = BM / 8 / 4, BJ = BN / 8 / 4;
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nnt = (p.N + BN - 1) / BN;
+    int mtile, ntile;
+    {
+        const int nwg = gridDim.x;
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        mtile = L / nnt;
+        ntile = L - mtile * nnt;
+    }
+    const int m_blk = mtile * BM, n_blk = ntile * BN;
+
+    // descriptors start at this block's first row and end at the matrix' last row: rows past M / N read as zeros
+    const int rows_a = p.M - m_blk < BM ? p.M - m_blk : BM;
+    const int rows_b = p.N - n_blk < BN ? p.N - n_blk : BN;
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const float*)p.A + (long long)m_blk * p.lda), 0, (int)((long long)(rows_a - 1) * p.lda * 4 + (long long)p.K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.B + (long long)n_blk * p.ldb), 0, (int)((long long)(rows_b - 1) * p.ldb * 4 + (long long)p.K * 4), 0x00020000);
+    int a_voff[AJ], b_voff[BJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int row = (wave * AJ + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        // a row past the edge must stay out of range for every K-tile: push it beyond the descriptor
+        a_voff[j] = row < rows_a ? (int)(((long long)row * p.lda + chunk * 4) * 4) : (int)0x7fffff00;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (wave * BJ + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        b_voff[j] = row < rows_b ? (int)(((long long)row * p.ldb + chunk * 4) * 4) : (int)0x7fffff00;
+    }
+    const int nk = p.K / BK;
+    int l_k = 0;
+    auto stage = [&](int slot) {
+        char* As = lds + slot * STAGE;
+        char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(As + (wave * AJ + j) * 1024), 16, a_voff[j], l_k * 4, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, LPTR(Bs + (wave * BJ + j) * 1024), 16, b_voff[j], l_k * 4, 0, 0);
+        l_k += BK;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int swz = (li >> 1) & 7;
+    int a_rd[4], b_rd[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int pos = ((kk * 2 + lh) ^ swz) * 16;
+        a_rd[kk] = (wm * 64 + li) * ROWB + pos;
+        b_rd[kk] = A_BYTES + (wn * WN + li) * ROWB + pos;
+    }
+    auto mfma_tile = [&](int slot) {
+        const char* base = lds + slot * STAGE;
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[0][a] = *(const f32x4*)(base + a_rd[0] + a * 32 * ROWB);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[0][b] = *(const f32x4*)(base + b_rd[0] + b * 32 * ROWB);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[(kk + 1) & 1][a] = *(const f32x4*)(base + a_rd[kk + 1] + a * 32 * ROWB);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[(kk + 1) & 1][b] = *(const f32x4*)(base + b_rd[kk + 1] + b * 32 * ROWB);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][a][e], bf[kk & 1][b][e], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    stage(0);
+    for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (kt + u < nk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                if (kt + u + 1 < nk) stage(u ^ 1);
+                mfma_tile(u);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue (ragged edges predicated)
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n_blk + wn * WN + b * 32 + li;
+        const bool colok = col < p.N;
+        float sh = 0.f, cq = 0.f;
+        if constexpr (EPI == E_BIAS) {
+            if (colok && p.col_shift) sh = p.col_shift[col];
+        } else {
+            if (colok && p.col_sq) cq = p.col_sq[col];
+            if (p.metric == REID_METRIC_COS_HALF || p.metric == REID_METRIC_COS) cq = sqrtf(cq);
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int row0 = m_blk + wm * 64 + a * 32 + 4 * lh;
+            float res[16];
+            if constexpr (EPI == E_BIAS) {
+                if (p.residual && p.scat_h == 0) {   // plain residual: fetch the 16 values up front
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = row0 + (e & 3) + 8 * (e >> 2);
+                        res[e] = (colok && row < p.M) ? p.residual[(long long)row * p.ldc + col] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + (e & 3) + 8 * (e >> 2);
+                const bool ok = colok && row < p.M;
+                float v = acc[a][b][e];
+                if constexpr (EPI == E_BIAS) {
+                    long long orow = row;
+                    if (p.scat_h > 0) {   // ConvTranspose2d(4,2,1) output parity: (img, j, i) -> (img, 2j+py, 2i+px)
+                        const int hw = p.scat_h * p.scat_w;
+                        const int img = row / hw, rem = row - img * hw;
+                        const int j = rem / p.scat_w, i = rem - j * p.scat_w;
+                        orow = ((long long)img * 2 * p.scat_h + 2 * j + p.scat_py) * (2 * p.scat_w) + 2 * i + p.scat_px;
+                    }
+                    const long long idx = orow * p.ldc + col;
+                    v += sh;
+                    if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU() (erf form)
+                    if (p.residual) v += p.scat_h == 0 ? res[e] : (ok ? p.residual[idx] : 0.f);
+                    if (ok) p.C[idx] = v;
+                } else {
+                    float rs = 0.f;
+                    if (ok && p.row_sq) rs = p.row_sq[row];
+                    switch (p.metric) {
+                        case REID_METRIC_L2: v = sqrtf(fmaxf((rs + cq) - 2.0f * v, 1e-12f)); break;
+                        case REID_METRIC_L2SQR: v = (rs + cq) - 2.0f * v; break;
+                        case REID_METRIC_COS_HALF: v = (1.0f - v / (sqrtf(rs) * cq)) / 2.0f; break;
+                        case REID_METRIC_COS: v = 1.0f - v / (sqrtf(rs) * cq); break;
+                        default: break;
+                    }
+                    if (ok) p.C[(long long)row * p.ldc + col] = v;
+                }
+            }
+        }
+    }
+#endif
+}
+
+template <int EPI>
+void launch_epi(reid_ctx* ctx, const GemmParams& p) {
+    const int nmt = (p.M + BM - 1) / BM;
+    // 64-wide tiles waste fewer padded columns on narrow / odd outputs (288, 192) but run ~12 % below the 128-wide tile per column
+    const double cost64 = ((p.N + 63) / 64) * 64 * 1.12, cost128 = ((p.N + 127) / 128) * 128;
+    if (p.N <= 64 || cost64 < cost128) {
+        const int nnt = (p.N + 63) / 64;
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<64, EPI>), dim3(nmt * nnt), dim3(256), 0, ctx->stream, p);
+    } else {
+        const int nnt = (p.N + 127) / 128;
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<128, EPI>), dim3(nmt * nnt), dim3(256), 0, ctx->stream, p);
+    }
+}
+
+}  // namespace
+
+bool gemm_f32_dma_supported(int amode, int epi, const GemmParams& p) {
+    return amode == A_DENSE && (epi == E_BIAS || epi == E_DIST) && p.K % BK == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
+           (long long)BM * p.lda * 4 < 0x7fff0000ll && (long long)128 * p.ldb * 4 < 0x7fff0000ll &&
+           ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0;
+}
+
+int launch_gemm_f32_dma(reid_ctx* ctx, int epi, const GemmParams& p, int kind, double flops, double bytes) {
+    prof_begin(ctx, kind, flops, bytes);
+    if (epi == E_BIAS) launch_epi<E_BIAS>(ctx, p);
+    else launch_epi<E_DIST>(ctx, p);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}

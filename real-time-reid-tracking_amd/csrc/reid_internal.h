@@ -135,6 +135,8 @@ int launch_stem_pool_f16(reid_ctx*, const _Float16* pad_in, const uint8_t* crops
                          _Float16* pooled);
 int launch_conv_w16_chunked(reid_ctx*, const float* w_f32, int cout, int rs, int cin, _Float16* out);  // -> [Cout][Cin/64][RS][64]   // [64][8][24] -> [64][8][8][4]
 int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int kind, double flops, double bytes);
+bool gemm_f32_dma_supported(int amode, int epi, const GemmParams& p);   // gemm_f32_dma.hip: dense GEMM with LDS-DMA staging
+int launch_gemm_f32_dma(reid_ctx* ctx, int epi, const GemmParams& p, int kind, double flops, double bytes);
 bool conv_f32_supported(const GemmParams& p);   // conv_f32.hip: pipelined implicit-GEMM convolution of the fp32 path (full tiles)
 int launch_conv_f32(reid_ctx* ctx, const GemmParams& p, int kind, double flops, double bytes);
 
@@ -214,6 +216,7 @@ struct reid_ctx {
     std::map<std::string, std::pair<void*, size_t>> ws;
     Se18Weights se18;
     int last_n = 0;  // crops in the last embed chunk (for reid_debug_stage)
+    int swin_last_n = 0, swin_last_tok = 0;   // images / stage-1 tokens per image of the last Swin pass (reid_debug_swin_stage)
     int debug_keep = 0;      // 0 off, 1 stage buffers + unfused kernels, 2 stage buffers + production kernels
     bool last_f16 = false;
     int f16_loader_waves = 1; // LDS-halo kernel: 8 compute + 4 dedicated loader waves (REID_F16_LOADERS)
@@ -225,6 +228,8 @@ struct reid_ctx {
                              // (REID_F16_STEMPOOL=1: from the padded f16 image, 0: GEMM + pool kernels)
     int f32_conv = 1;        // fp32 path (REID_F32_CONV): 1 = conv_f32.hip LDS-DMA kernel, norms in the producer's epilogue / in_apply;
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
+    int swin_attn_mfma = 1;  // Swin window attention (REID_SWIN_ATTN): 1 = matrix cores in fp16-storage mode, VALU kernel in exact fp32
+                             // (v_mfma_f32_32x32x2_f32 runs at the fp32 VALU rate: no gain); 2 = matrix cores in both; 0 = VALU in both
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
     float* stage_ptr[11] = {nullptr};
     unsigned long long* conv_diag = nullptr;   // experiments (debug.hip): stamps of the loader-wave conv kernel

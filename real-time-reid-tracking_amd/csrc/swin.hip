@@ -281,6 +281,294 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ 
     }
 }
 
+
+// ---- WindowAttention v1 on the matrix cores (swin_transformer.py:191-232; north_star: "MFMA only on the Swin qk^T / attn.v").
+// One wave per (image, window, head); the 49 tokens of a window are padded to 64.
+//   S^T[key][query] = K . Q^T      (operands swapped so that a query's scores are lane-local: C layout col = lane & 31)
+//   softmax over the keys: 32 scores in the lane's registers + one exchange with lane ^ 32
+//   O[query][dim]   = P . V        with the S^T accumulator tile itself as the A operand (cdna_hip_programming.md section 3,
+//                                  "An accumulator tile as the next MFMA's operand": X^T . B, k order permuted)
+// The relative-position bias (one 13 x 13 table per layer, shared by the heads) is expanded once per block into a
+// [key][query] table in LDS, padded keys carry -inf; the masks of the last window row / column of a shifted block
+// (create_mask, :95-108) are applied from per-key flags.
+typedef f16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void build_bias_table(const float* __restrict__ pos, float* sbias, int* kflag, int nthreads) {
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += nthreads) {
+        const int key = idx >> 6, query = idx & 63;
+        float b = 0.f;
+        if (key >= 49) b = -INFINITY;
+        else if (query < 49) {
+            const int jy = key / 7, jx = key - jy * 7, iy = query / 7, ix = query - iy * 7;
+            b = pos[(jy - iy + 6) * 13 + (jx - ix + 6)];
+        }
+        sbias[idx] = b;
+    }
+    for (int key = threadIdx.x; key < 64; key += nthreads) {
+        const int jy = key / 7, jx = key - jy * 7;
+        kflag[key] = key < 49 ? ((jy >= 4 ? 1 : 0) | (jx >= 4 ? 2 : 0)) : 0;
+    }
+}
+
+// scores of one lane: acc[kt][qt][e] = S^T[key = kt*32 + (e&3) + 8*(e>>2) + 4*(lane>>5)][query = qt*32 + (lane&31)]
+// -> probabilities (scale, bias, masks, softmax over the 64 keys of each query), in place
+__device__ __forceinline__ void softmax_scores(f32x16 (&acc)[2][2], const float* sbias, const int* kflag, int lane, bool last_row,
+                                               bool last_col) {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int query = qt * 32 + li;
+        const int iy = query / 7, ix = query - iy * 7;
+        const int qf = (iy >= 4 ? 1 : 0) | (ix >= 4 ? 2 : 0);
+        const int msel = (last_row ? 1 : 0) | (last_col ? 2 : 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float v = acc[kt][qt][e] * 0.17677669529663687f + sbias[key * 64 + query];   // 32^-0.5
+                if (msel && ((kflag[key] ^ qf) & msel)) v = -INFINITY;
+                acc[kt][qt][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float den = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = expf(acc[kt][qt][e] - mx);
+                acc[kt][qt][e] = p;
+                den += p;
+            }
+        den += __shfl_xor(den, 32);
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[kt][qt][e] *= inv;
+    }
+}
+
+// fp16-storage mode: v_mfma_f32_32x32x16_f16, 8 MFMAs for S^T and 8 for P.V per (window, head)
+__global__ __launch_bounds__(256) void window_attn_mfma_f16_kernel(const f16* __restrict__ qkv, int ldq, int n_img, int H, int W,
+                                                                   int heads, int shifted, const float* __restrict__ pos,
+                                                                   f16* __restrict__ out) {
+    constexpr int VP = 72;   // V^T row pitch in f16 (144 B)
+    constexpr int ZP = 40;   // Z row pitch in f16 (80 B, 16-byte aligned rows)
+    __shared__ float sbias[64 * 64];
+    __shared__ int kflag[64];
+    __shared__ __attribute__((aligned(16))) f16 wbuf[4][64 * ZP];   // per wave: V^T [32][VP] (4 608 B), later Z [64][ZP] (5 120 B)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    build_bias_table(pos, sbias, kflag, 256);
+    const int nwh = H / 7, nww = W / 7;
+    const long long task = blockIdx.x * 4LL + wave;
+    const long long ntask = (long long)n_img * nwh * nww * heads;
+    const bool live = task < ntask;
+    const int C = heads * 32;
+    int head = 0, wx = 0, wy = 0, img = 0;
+    if (live) {
+        head = (int)(task % heads);
+        long long t = task / heads;
+        wx = (int)(t % nww);
+        t /= nww;
+        wy = (int)(t % nwh);
+        img = (int)(t / nwh);
+    }
+    const int sh = shifted ? 3 : 0;
+    auto token = [&](int idx) -> long long {   // window position idx (< 49) -> token row
+        const int iy = idx / 7, ix = idx - iy * 7;
+        const int y = (wy * 7 + iy + sh) % H, x = (wx * 7 + ix + sh) % W;
+        return ((long long)img * H + y) * W + x;
+    };
+    f16* vt = wbuf[wave];
+    // V^T of this (window, head): lane = token, 32 dims -> vt[dim][token]; padded tokens are zero rows
+    {
+        half8 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (live && lane < 49) {
+            const f16* base = qkv + token(lane) * ldq + 2 * C + head * 32;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = *(const half8*)(base + c * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vt[(c * 8 + j) * VP + lane] = v[c][j];
+    }
+    // Q / K fragments: lane (li, lh) holds dims 8*lh .. +7 (k-step 0) and 16 + 8*lh .. (k-step 1) of tokens li and 32 + li
+    half8 qf[2][2], kf[2][2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+        const int idx = t2 * 32 + li;
+        const bool ok = live && idx < 49;
+        const f16* base = ok ? qkv + token(idx) * ldq + head * 32 + 8 * lh : qkv;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            qf[t2][s2] = ok ? *(const half8*)(base + s2 * 16) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+            kf[t2][s2] = ok ? *(const half8*)(base + C + s2 * 16) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    __syncthreads();   // bias table ready (the wave's own V^T writes are ordered before its reads)
+    if (!live) return;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[kt][qt][e] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s2], qf[qt][s2], acc[kt][qt], 0, 0, 0);
+        }
+    softmax_scores(acc, sbias, kflag, lane, shifted && wy == nwh - 1, shifted && wx == nww - 1);
+    // O = P . V: A = registers 8*s2 .. 8*s2+7 of the S^T tile as f16 (element j of lane half h is key
+    // 16*s2 + 8*(j>>2) + 4*h + (j&3) of the tile), B = V^T[dim = li][those keys]
+    f32x16 z[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[qt][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const f16* vrow = vt + li * VP + kt * 32 + 16 * s2 + 4 * lh;
+            const half4 v0 = *(const half4*)vrow, v1 = *(const half4*)(vrow + 8);
+            const half8 vb = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                half8 pa;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pa[j] = (f16)acc[kt][qt][8 * s2 + j];
+                z[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, vb, z[qt], 0, 0, 0);
+            }
+        }
+    // Z[query][dim] (col = dim on the lane, rows in registers) -> LDS -> one 64-byte row per token
+    f16* zl = wbuf[wave];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zl[(qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * ZP + li] = (f16)z[qt][e];
+    if (lane < 49) {
+        f16* dst = out + token(lane) * C + head * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(half8*)(dst + c * 8) = *(const half8*)(zl + lane * ZP + c * 8);
+    }
+}
+
+// exact-fp32 mode: v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain per output), 64 MFMAs for S^T and 64 for P.V.
+// Q, K, V rows of the window/head sit in LDS with a 33-float pitch (ds_read_b32 of 32 different rows: conflict-free).
+__global__ __launch_bounds__(128) void window_attn_mfma_f32_kernel(const float* __restrict__ qkv, int ldq, int n_img, int H, int W,
+                                                                   int heads, int shifted, const float* __restrict__ pos,
+                                                                   float* __restrict__ out) {
+    constexpr int RP = 33;
+    __shared__ float sbias[64 * 64];
+    __shared__ int kflag[64];
+    __shared__ float rows[2][3][64 * RP];   // per wave: Q, K, V
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    build_bias_table(pos, sbias, kflag, 128);
+    const int nwh = H / 7, nww = W / 7;
+    const long long task = blockIdx.x * 2LL + wave;
+    const long long ntask = (long long)n_img * nwh * nww * heads;
+    const bool live = task < ntask;
+    const int C = heads * 32;
+    int head = 0, wx = 0, wy = 0, img = 0;
+    if (live) {
+        head = (int)(task % heads);
+        long long t = task / heads;
+        wx = (int)(t % nww);
+        t /= nww;
+        wy = (int)(t % nwh);
+        img = (int)(t / nwh);
+    }
+    const int sh = shifted ? 3 : 0;
+    long long tok = 0;
+    const bool act = live && lane < 49;
+    if (act) {
+        const int iy = lane / 7, ix = lane - iy * 7;
+        const int y = (wy * 7 + iy + sh) % H, x = (wx * 7 + ix + sh) % W;
+        tok = ((long long)img * H + y) * W + x;
+    }
+    float* Qs = rows[wave][0];
+    float* Ks = rows[wave][1];
+    float* Vs = rows[wave][2];
+    {
+        const float* base = qkv + tok * ldq + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, c = a;
+            if (act) {
+                a = *(const f32x4*)(base + d);
+                b = *(const f32x4*)(base + C + d);
+                c = *(const f32x4*)(base + 2 * C + d);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Qs[lane * RP + d + e] = a[e];
+                Ks[lane * RP + d + e] = b[e];
+                Vs[lane * RP + d + e] = c[e];
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[kt][qt][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {   // k-step t covers dims 2t, 2t+1 (lane half = k)
+        float ka[2], qb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ka[u] = Ks[(u * 32 + li) * RP + 2 * t + lh];
+            qb[u] = Qs[(u * 32 + li) * RP + 2 * t + lh];
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kt], qb[qt], acc[kt][qt], 0, 0, 0);
+    }
+    softmax_scores(acc, sbias, kflag, lane, shifted && wy == nwh - 1, shifted && wx == nww - 1);
+    // O = P . V: register e of an S^T tile is the A operand of one k-step (keys (e&3) + 8*(e>>2) + 4*h of the tile)
+    f32x16 z[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[qt][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float vb = Vs[(kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * RP + li];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) z[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[kt][qt][e], vb, z[qt], 0, 0, 0);
+        }
+    float* zl = Qs;   // Q is dead
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zl[(qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * RP + li] = z[qt][e];
+    if (act) {
+        float* dst = out + tok * C + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            const f32x4 v = {zl[lane * RP + d], zl[lane * RP + d + 1], zl[lane * RP + d + 2], zl[lane * RP + d + 3]};
+            *(f32x4*)(dst + d) = v;
+        }
+    }
+}
+
 // ---- tail (:414-420): LayerNorm(96, eps 1e-6) per token -> GeM_1D over the tokens -> BatchNorm1d.
 // Stage 1: grid (image, slice): the sum over a slice of the tokens of clamp(LN(x), 1e-6)^p per channel -> part[img][slice][96]
 // (one block per image left 3136 tokens to four waves and 7 % of the forward in this kernel).
@@ -654,8 +942,12 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 prof_end(ctx);
                 REID_TRY(linear16(ctx, ln16, T, C, C, h.qkv, nullptr, 3 * C, 0, nullptr, big16, nullptr, ldq));
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
-                hipLaunchKernelGGL(window_attn_kernel<f16>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big16, ldq, n,
-                                   Hs, Ws, heads, shifted, k.pos, att16);
+                if (ctx->swin_attn_mfma)
+                    hipLaunchKernelGGL(window_attn_mfma_f16_kernel, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big16, ldq,
+                                       n, Hs, Ws, heads, shifted, k.pos, att16);
+                else
+                    hipLaunchKernelGGL(window_attn_kernel<f16>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big16, ldq, n,
+                                       Hs, Ws, heads, shifted, k.pos, att16);
                 prof_end(ctx);
                 LAUNCH_CHECK();
                 REID_TRY(linear16(ctx, att16, T, C, C, h.out, k.out_b, C, 0, nullptr, tmp16, nullptr, C));
@@ -674,8 +966,12 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
             prof_end(ctx);
             REID_TRY(linear(ctx, lnb, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big));
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 16);
-            hipLaunchKernelGGL(window_attn_kernel<float>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, 3 * C, n,
-                               Hs, Ws, heads, shifted, k.pos, att);
+            if (ctx->swin_attn_mfma == 2)   // fp32 MFMA runs at the fp32 VALU rate: measured 5 % slower than the VALU kernel, kept for A/B
+                hipLaunchKernelGGL(window_attn_mfma_f32_kernel, dim3((unsigned)((ntask + 1) / 2)), dim3(128), 0, ctx->stream, big, 3 * C, n,
+                                   Hs, Ws, heads, shifted, k.pos, att);
+            else
+                hipLaunchKernelGGL(window_attn_kernel<float>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, 3 * C, n,
+                                   Hs, Ws, heads, shifted, k.pos, att);
             prof_end(ctx);
             LAUNCH_CHECK();
             REID_TRY(linear(ctx, att, T, C, k.out_w, k.out_b, C, 0, nullptr, tmp));
@@ -743,6 +1039,29 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
         }
         REID_TRY(linear(ctx, d_emb, n, 96, w.cls_w, nullptr, w.num_class, 0, nullptr, d_logits));
     }
+    ctx->swin_last_n = n;
+    ctx->swin_last_tok = H1 * W1;
+    return REID_OK;
+}
+
+// Intermediate activations of the last reid_swin_embed_* call (stage-level parity tests): 0 = ShadowFeatureExtraction output
+// [n][56][56][96], 1..4 = outputs of the four stages (NHWC fp32 residual streams), 5 = GeM_1D output [n][96].  Valid when the
+// call ran as ONE pass (n <= min(chunk, 256)); the buffers are the forward's own workspaces.
+extern "C" int reid_debug_swin_stage(reid_ctx* ctx, int stage, float* out, size_t max_floats, size_t* count) {
+    ARG_CHECK(ctx && out && stage >= 0 && stage <= 5);
+    CTX_GUARD(ctx);
+    static const char* names[6] = {"swin.sfe", "swin.x0", "swin.x1", "swin.x2", "swin.x3", "swin.gem"};
+    auto it = ctx->ws.find(names[stage]);
+    if (it == ctx->ws.end() || ctx->swin_last_n <= 0) {
+        reid_set_error("reid_debug_swin_stage: no Swin forward has run on this context");
+        return REID_ERR_STATE;
+    }
+    const size_t per = stage == 5 ? 96 : ((size_t)ctx->swin_last_tok * 96) >> (stage <= 1 ? 0 : stage - 1);
+    const size_t total = per * ctx->swin_last_n;
+    if (count) *count = total;
+    const size_t ncopy = total < max_floats ? total : max_floats;
+    HIP_TRY(hipMemcpyAsync(out, it->second.first, ncopy * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return REID_OK;
 }
 

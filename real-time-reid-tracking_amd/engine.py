@@ -54,13 +54,18 @@ class Engine:
         new = int(hip_stream or 0)
         if new != getattr(self, "_stream", 0):
             self.sync()
-            check(self.lib.reid_ctx_set_stream(self.h, C.c_void_p(new)))
+            if new == -1:      # the HIP null stream (handle 0, which set_stream reads as "own")
+                check(self.lib.reid_ctx_set_null_stream(self.h))
+            else:
+                check(self.lib.reid_ctx_set_stream(self.h, C.c_void_p(new)))
             self._stream = new
 
     def use_torch_stream(self):
-        """Enqueue on torch's current stream of this device (CUDA-tensor entry points of the backbones)."""
+        """Enqueue on torch's current stream of this device (CUDA-tensor entry points of the backbones).  torch's default
+        stream is the HIP null stream, handle 0."""
         import torch
-        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.set_stream(s if s else -1)
 
     def set_chunk(self, n):
         check(self.lib.reid_ctx_set_chunk(self.h, int(n)))
@@ -205,6 +210,19 @@ class Engine:
         cnt = C.c_size_t()
         check(self.lib.reid_debug_stage(self.h, int(stage), _ptr(out), out.size, C.byref(cnt)))
         assert cnt.value == out.size
+        return out
+
+    def debug_swin_stage(self, stage, n, h=224, w=224):
+        """Stage activations of the last Swin pass as NHWC arrays (0 sfe, 1..4 stage outputs, 5 GeM output [n,96])."""
+        if stage == 5:
+            shape = (n, 96)
+        else:
+            s = max(stage - 1, 0)
+            shape = (n, (h // 4) >> s, (w // 4) >> s, 96 << s)
+        out = np.empty(shape, np.float32)
+        cnt = C.c_size_t()
+        check(self.lib.reid_debug_swin_stage(self.h, int(stage), _ptr(out), out.size, C.byref(cnt)))
+        assert cnt.value == out.size, (cnt.value, out.size)
         return out
 
     # ---- matching

@@ -815,6 +815,8 @@ def test_build_model_warmup_and_cuda_tensor_entry(eng_w0):
         got = model(xc)
         e2, lg = model(xc.half(), return_logits=True)
     s.synchronize()
+    got0 = model(xc)                                                    # torch's DEFAULT stream (the HIP null stream, handle 0)
+    assert np.array_equal(got0.cpu().numpy(), want)                     # .cpu() orders itself after the kernels on that stream
     assert got.is_cuda and got.dtype == torch.float32 and tuple(got.shape) == (6, 512)
     assert np.array_equal(got.cpu().numpy(), want)
     assert lg.is_cuda and tuple(lg.shape) == (6, 751)
@@ -858,3 +860,47 @@ def test_smooth_tracklets_matches_reference_fixture(eng, golden_dir):
     from oracle import postproc
     seq = np.arange(50) % 4
     np.testing.assert_allclose(eng.smooth_tracklets(wide, seq), postproc.smooth_tracklets(wide, seq, np.ones(50, bool)), atol=2e-6)
+
+
+@pytest.mark.parametrize("precision,tol", [(0, 2e-5), (1, 2e-2)])
+def test_swin_stage_taps_match_reference_fixture(eng, golden_dir, precision, tol):
+    """Stage-level localisation for Swin, from the taps the REFERENCE's swin_t produced (tests/golden/swin_seed0.npz): the
+    ShadowFeatureExtraction output, the four stage outputs and the GeM_1D output, sampled exactly as gen_golden.py sampled them.
+    fp32 mode within 2e-5 of the stage's range; fp16-storage mode within 2e-2 (its residual stream is fp32, its linears f16)."""
+    g = np.load(os.path.join(golden_dir, "swin_seed0.npz"))
+    seed, n = int(g["seed"]), int(g["n"])
+    eng.load_swin(*weights.pack_swin(synth.swin_state_dict(seed))[:2])
+    eng.set_precision(precision)
+    try:
+        eng.swin_embed_f32_nchw(synth.images_f32(n, seed))
+        for stage, name in ((0, "sfe"), (1, "stage1"), (2, "stage2"), (3, "stage3"), (4, "stage4")):
+            t = torch.from_numpy(eng.debug_swin_stage(stage, n)).permute(0, 3, 1, 2)          # NHWC -> the reference's NCHW
+            c, h, w = t.shape[1:]
+            got = t[:, :: max(1, c // 8), :: max(1, h // 8), :: max(1, w // 4)].numpy()
+            ref = g["tap_" + name]
+            assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (name, np.abs(got - ref).max(), np.abs(ref).max())
+            assert abs(float(t.double().mean()) - float(g["mean_" + name])) <= tol * float(g["absmean_" + name]), name
+        gem = eng.debug_swin_stage(5, n)[:, :: 96 // 8]                    # the fixture keeps every 12th channel of [n,96,1]
+        ref = g["tap_avgpool"].reshape(gem.shape)
+        assert np.abs(gem - ref).max() <= tol * np.abs(ref).max()
+    finally:
+        eng.set_precision(0)
+
+
+def test_swin_window_attention_mfma_equals_valu_kernel(eng):
+    """The matrix-core window attention (S^T = K.Q^T, softmax in the accumulator layout, P.V with the accumulator tile as the
+    MFMA operand) against round 1's one-lane-per-query VALU kernel (REID_SWIN_ATTN=0), both arithmetic modes, on 448x224 so that
+    shifted blocks see inner windows as well as the masked last row / column."""
+    import subprocess, sys, json as _json
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from reid_amd import synth, weights; from reid_amd.engine import get_engine;"
+            "eng = get_engine(0); eng.load_swin(*weights.pack_swin(synth.swin_state_dict(0))[:2]); x = synth.images_f32(3, 9, h=448, w=224);"
+            "a = eng.swin_embed_f32_nchw(x); eng.set_precision(1); b = eng.swin_embed_f32_nchw(x); print(json.dumps([a.tolist(), b.tolist()]))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = {}
+    for mode in ("0", "2"):                 # 0 = VALU kernel in both modes, 2 = matrix-core kernel in both
+        env = dict(os.environ, REID_SWIN_ATTN=mode)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+        res[mode] = [np.asarray(v, np.float32) for v in _json.loads(out.strip().splitlines()[-1])]
+    for i, tol in ((0, 2e-5), (1, 2e-3)):
+        a, b = res["0"][i], res["2"][i]
+        assert np.abs(a - b).max() <= tol * np.abs(a).max(), (i, np.abs(a - b).max(), np.abs(a).max())
