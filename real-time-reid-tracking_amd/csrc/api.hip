@@ -449,8 +449,12 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
     (void)nt;
 
     // stem: conv7x7 s2 p3 + BN, no ReLU (SERes18_IBN.py:251-253), then MaxPool2d(3,2,1) (:254)
-    REID_TRY(conv_gemm(ctx, is_u8 ? A_STEM_U8 : A_STEM_F32, x, n, IMG_H, IMG_W, 3, w.stem_w, 64, 7, 7, 2, 3, 192, nullptr,
-                       nullptr, 0, w.stem_scale, w.stem_shift, nullptr, 0, nullptr, b.stem));
+    if (ctx->f32_conv == 1) {   // stem_f32.hip: weights resident in LDS, A operand read from an fp32 LDS image of the input rows
+        REID_TRY(launch_stem_f32(ctx, x, is_u8, n, w.stem_w, w.stem_scale, w.stem_shift, b.stem));
+    } else {
+        REID_TRY(conv_gemm(ctx, is_u8 ? A_STEM_U8 : A_STEM_F32, x, n, IMG_H, IMG_W, 3, w.stem_w, 64, 7, 7, 2, 3, 192, nullptr,
+                           nullptr, 0, w.stem_scale, w.stem_shift, nullptr, 0, nullptr, b.stem));
+    }
     REID_TRY(launch_maxpool3s2(ctx, b.stem, n, 128, 64, 64, b.pool));
     b.stage[0] = b.stem;
     b.stage[1] = b.pool;
