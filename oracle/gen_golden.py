@@ -381,6 +381,39 @@ def gen_config5():
     np.savez_compressed(os.path.join(OUT, "config5.npz"), **out)
 
 
+def gen_siblings():
+    """The sibling backbones of SERse18_IBN on the same IBN-Net skeleton, from the reference's own classes:
+    CARes18_IBN (reid/backbones/CARes18.py:185-281 - its blocks use TripletAttention, :148) and EMARes18_IBN
+    (reid/backbones/EMA_Res18.py:118-181).  Seeded weights load with strict=True, which pins the state_dict key layout."""
+    from reid_amd import synth
+    from reid.backbones.CARes18 import cares18_ibn
+    from reid.backbones.EMA_Res18 import emares18_ibn
+
+    out = {}
+    for tag, ctor, sd_fn in (("ca", cares18_ibn, synth.cares18_state_dict), ("ema", emares18_ibn, synth.emares18_state_dict)):
+        sd_np = sd_fn(0)
+        model = ctor(num_classes=751, loss="triplet")
+        res = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        model.eval()
+        crops = synth.smooth_crops_u8(3, 7)
+        x = torch.from_numpy(crops).float().div(255.0).sub(0.5).div(0.5).permute(0, 3, 1, 2).contiguous()
+        taps, hooks = {}, []
+        for name in [b[0] for b in synth.SERES18_BLOCKS] + ["avgpooling"]:
+            hooks.append(getattr(model, name).register_forward_hook(
+                lambda m, i, o, name=name: taps.__setitem__(name, o.detach().clone())))
+        with torch.no_grad():
+            emb, logits = model(x)
+        for h in hooks:
+            h.remove()
+        out.update({tag + "_emb": emb.numpy(), tag + "_logits": logits.numpy()})
+        for k, v in taps.items():
+            out["%s_tap_%s" % (tag, k)] = _sample(v)
+            out["%s_absmean_%s" % (tag, k)] = np.float64(v.double().abs().mean().item())
+        print("siblings", tag, "emb", tuple(emb.shape), "|emb| row0", float(emb[0].norm()))
+    np.savez_compressed(os.path.join(OUT, "siblings.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -394,3 +427,4 @@ if __name__ == "__main__":
     gen_postproc()
     gen_config1()
     gen_config5()
+    gen_siblings()

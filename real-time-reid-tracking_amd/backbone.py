@@ -75,6 +75,7 @@ class SERes18IBN:
     """
 
     embed_dim = 512
+    arch = "seres18_ibn"
 
     def __init__(self, num_classes=751, loss="triplet", pretrained=False, use_gpu=True, seed=0, **_):
         if loss not in ("triplet", "softmax"):
@@ -83,7 +84,9 @@ class SERes18IBN:
         self.is_reid = loss == "softmax"
         self.training = False
         self._device = 0
-        self._sd = synth.seres18_state_dict(seed, num_class=num_classes, gem_p=3.0)
+        # held with SERse18_IBN's named keys; state_dict() hands out the reference's own key layout (positional for the siblings'
+        # downsample blocks), load_state_dict() accepts both
+        self._sd = weights.normalize_state_dict(synth.seres18_state_dict(seed, num_class=num_classes, gem_p=3.0, arch=self.arch))
         self._dirty = True
         if pretrained:
             import warnings
@@ -118,12 +121,16 @@ class SERes18IBN:
     def parameters(self):
         return iter(())
 
+    def _ref_key(self, k):
+        ds = ("basicBlock21", "basicBlock31", "basicBlock41")
+        return synth.sibling_key(k) if getattr(self, "arch", "seres18_ibn") != "seres18_ibn" and k.startswith(ds) else k
+
     def state_dict(self):
         try:
             import torch
-            return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._sd.items())
+            return OrderedDict((self._ref_key(k), torch.from_numpy(np.array(v))) for k, v in self._sd.items())
         except ImportError:
-            return OrderedDict((k, np.array(v)) for k, v in self._sd.items())
+            return OrderedDict((self._ref_key(k), np.array(v)) for k, v in self._sd.items())
 
     def load_state_dict(self, state_dict, strict=True):
         sd = weights.normalize_state_dict(state_dict)
@@ -189,6 +196,28 @@ def seres18_ibn(num_classes=751, loss="triplet", pretrained=False, use_gpu=True,
     return SERes18IBN(num_classes=num_classes, loss=loss, pretrained=pretrained, use_gpu=use_gpu, **kwargs)
 
 
+class CARes18IBN(SERes18IBN):
+    """CARes18_IBN (reid/backbones/CARes18.py:185-281): the same IBN-Net skeleton, every block ends in
+    relu(TripletAttention(y) + shortcut) (:148-157; triplet_attention.py:69-101).  Exact fp32 arithmetic only."""
+    arch = "cares18_ibn"
+
+
+class EMARes18IBN(SERes18IBN):
+    """EMARes18_IBN (reid/backbones/EMA_Res18.py:118-181): every block ends in relu(EMA(y) + shortcut) (:79-86), EMA with 32
+    channel groups (:10-38).  Exact fp32 arithmetic only."""
+    arch = "emares18_ibn"
+
+
+def cares18_ibn(num_classes=751, loss="triplet", pretrained=False, use_gpu=True, **kwargs):
+    """Same name as the reference's factory (CARes18.py:270-281)."""
+    return CARes18IBN(num_classes=num_classes, loss=loss, pretrained=pretrained, use_gpu=use_gpu, **kwargs)
+
+
+def emares18_ibn(num_classes=751, loss="triplet", pretrained=False, use_gpu=True, **kwargs):
+    """Same name as the reference's factory (EMA_Res18.py:184-195)."""
+    return EMARes18IBN(num_classes=num_classes, loss=loss, pretrained=pretrained, use_gpu=use_gpu, **kwargs)
+
+
 class SwinT:
     """The reference's custom Swin-T, version "v1" (reid/backbones/swin_transformer.py:339-427, swin_t :508-513): conv stem,
     4 stages of (W-MSA, SW-MSA) blocks, top-down ConvTranspose fusion, LN -> GeM_1D -> BatchNorm1d(96).
@@ -220,6 +249,7 @@ class SwinT:
     train = SERes18IBN.train
     parameters = SERes18IBN.parameters
     state_dict = SERes18IBN.state_dict
+    _ref_key = SERes18IBN._ref_key
 
     def load_state_dict(self, state_dict, strict=True):
         sd = weights.normalize_state_dict(state_dict)

@@ -310,6 +310,7 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         }
         return w.blob + it->second.first;
     };
+    w.arch = tab.count("b11.ta") ? 1 : (tab.count("b11.ema") ? 2 : 0);   // sibling backbones carry their attention tensors instead of se.*
     w.stem_w = get("stem.w", 64 * 192);
     w.stem_scale = get("stem.scale", 64);
     w.stem_shift = get("stem.shift", 64);
@@ -330,8 +331,16 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         b.ds_w = b.ds ? get(n + ".ds.w", (size_t)b.c * b.cin) : nullptr;
         b.ds_scale = b.ds ? get(n + ".ds.scale", b.c) : nullptr;
         b.ds_shift = b.ds ? get(n + ".ds.shift", b.c) : nullptr;
-        b.se_w1 = get(n + ".se.w1", (size_t)b.mid * b.c);
-        b.se_w2 = get(n + ".se.w2t", (size_t)b.c * b.mid);   // [mid][C]
+        b.se_w1 = b.se_w2 = b.ta = b.ema = nullptr;
+        if (w.arch == 0) {
+            b.se_w1 = get(n + ".se.w1", (size_t)b.mid * b.c);
+            b.se_w2 = get(n + ".se.w2t", (size_t)b.c * b.mid);   // [mid][C]
+        } else if (w.arch == 1) {
+            b.ta = get(n + ".ta", 300);
+        } else {
+            const size_t cg = b.c / 32;
+            b.ema = get(n + ".ema", cg * cg + cg + cg * cg * 9 + cg + 2 * cg);
+        }
     }
     w.gem_p = get("gem.p", 1);
     w.neck_scale = get("neck.scale", 512);
@@ -507,9 +516,17 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
                                k.ds_scale, k.ds_shift, nullptr, 0, nullptr, sc));
             shortcut = sc;
         }
-        REID_TRY(launch_se_finalize(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, b.se));
         float* out = c1;  // conv1 output is dead after conv2
-        REID_TRY(launch_se_combine(ctx, y, shortcut, b.se, n, hw, k.c, out));
+        if (w.arch == 1) {          // CARes18_IBN: TripletAttention + shortcut + ReLU (CARes18.py:150-157)
+            REID_TRY(launch_ta_tail(ctx, y, shortcut, n, Ho, Wo, k.c, k.ta, out));
+        } else if (w.arch == 2) {   // EMARes18_IBN: EMA + shortcut + ReLU (EMA_Res18.py:79-86)
+            REID_TRY(launch_ema_tail(ctx, y, shortcut, n, Ho, Wo, k.c, k.ema, out));
+        } else if (ctx->f32_conv == 1) {   // SE gate + combine in one launch
+            REID_TRY(launch_se_tail(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, y, shortcut, out));
+        } else {
+            REID_TRY(launch_se_finalize(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, b.se));
+            REID_TRY(launch_se_combine(ctx, y, shortcut, b.se, n, hw, k.c, out));
+        }
         b.stage[2 + i] = out;
         cur = out;
         H = Ho;
@@ -631,16 +648,18 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
         const bool c64 = ctx->f16_c64 && per_image_ok && i < 2 && conv3x3_c64_f16_supported(H, W, k.cin, k.c, 3, 3, k.stride, 1) && !k.ds;
         if (c64) {
             REID_TRY(launch_conv3x3_c64_f16(ctx, cur, n, w.h(k.conv1_w), nullptr, nullptr, 0, stats, c1, w.zero_page));
-            REID_TRY(launch_norm_finalize(ctx, stats, n, 1, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift,
-                                          a_scale, a_shift));
-            REID_TRY(launch_affine_relu_f16(ctx, c1, a_scale, a_shift, n, hw, k.c));
+            REID_TRY(launch_norm_apply_f16(ctx, c1, stats, n, 1, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift));
         } else if (k.ibn) {
             // conv1 raw + per-(image, channel) statistics, then InstanceNorm/BN + ReLU in place
             REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.conv1_w), k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr,
                                  nullptr, nullptr, 0, stats, c1));
-            REID_TRY(launch_norm_finalize(ctx, stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift,
-                                          a_scale, a_shift));
-            REID_TRY(launch_affine_relu_f16(ctx, c1, a_scale, a_shift, n, hw, k.c));
+            if (ctx->debug_keep == 1) {   // unfused reference sequence
+                REID_TRY(launch_norm_finalize(ctx, stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift,
+                                              a_scale, a_shift));
+                REID_TRY(launch_affine_relu_f16(ctx, c1, a_scale, a_shift, n, hw, k.c));
+            } else {
+                REID_TRY(launch_norm_apply_f16(ctx, c1, stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, k.bn1_scale, k.bn1_shift));
+            }
         } else {
             // plain BatchNorm (layer 4): BN + ReLU go straight into the conv1 epilogue
             REID_TRY(conv_gemm16(ctx, A16_IM2COL, cur, n, H, W, k.cin, w.h(k.conv1_w), k.c, 3, 3, k.stride, 1, 9 * k.cin,
@@ -669,7 +688,7 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
             shortcut = sc;
         }
         f16* out = c1;
-        if (ctx->f16_se_tail && per_image_ok) {   // one block per image: only with enough images to fill the chip
+        if (ctx->f16_se_tail && ctx->debug_keep != 1) {   // gate + combine in one launch, sliced per image when there are few images
             REID_TRY(launch_se_tail_f16(ctx, stats, n, c64 ? 1 : tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, y, shortcut, out));
         } else {
             REID_TRY(launch_se_finalize(ctx, stats, n, c64 ? 1 : tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, se));
@@ -703,8 +722,9 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
 }
 
 static int seres18_run(reid_ctx* ctx, const void* x, bool is_u8, int n, float* d_emb, float* d_logits) {
-    return ctx->precision == 1 ? seres18_forward_f16(ctx, x, is_u8, n, d_emb, d_logits)
-                               : seres18_forward(ctx, x, is_u8, n, d_emb, d_logits);
+    // the sibling backbones (CARes18 / EMARes18) exist in the reference's arithmetic only
+    return (ctx->precision == 1 && ctx->se18.arch == 0) ? seres18_forward_f16(ctx, x, is_u8, n, d_emb, d_logits)
+                                                         : seres18_forward(ctx, x, is_u8, n, d_emb, d_logits);
 }
 
 static const size_t kStageElems[11] = {524288, 131072, 131072, 131072, 65536, 65536, 32768, 32768, 65536, 65536, 512};

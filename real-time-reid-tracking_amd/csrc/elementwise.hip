@@ -218,6 +218,50 @@ __global__ void se_combine_kernel(const float* __restrict__ y, const float* __re
     }
 }
 
+// ---- SE gate + combine in ONE launch (SERes18_IBN.py:32-41 + :123-128): grid (slices, images).  Every block recomputes its
+// image's gate from the conv2 epilogue's partial sums exactly as se_finalize_kernel does (a few microseconds), then streams its
+// slice of the image: out = relu(gate * y + shortcut).  One launch instead of two, and enough blocks for a tracking-sized batch.
+__global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ stats, int tiles, int c, int mid, int hw,
+                                                      const float* __restrict__ w1, const float* __restrict__ w2,
+                                                      const float* __restrict__ y, const float* __restrict__ sc, int rows,
+                                                      float* __restrict__ out) {
+    __shared__ float pooled[512];
+    __shared__ float hid[64];
+    __shared__ __attribute__((aligned(16))) float gate[512];
+    const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int ch = tid; ch < c; ch += 256) {
+        double acc = 0.0;
+        for (int t = 0; t < tiles; ++t) acc += (double)stats[(((long long)img * tiles + t) * c + ch) * 2];
+        pooled[ch] = (float)(acc / hw);
+    }
+    __syncthreads();
+    for (int m = wave; m < mid; m += 4) {
+        float acc = 0.f;
+        for (int ch = lane; ch < c; ch += 64) acc += w1[m * c + ch] * pooled[ch];
+        acc = wave_sum(acc);
+        if (lane == 0) hid[m] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 256) {
+        float acc = 0.f;
+        for (int m = 0; m < mid; ++m) acc += w2[m * c + ch] * hid[m];
+        gate[ch] = 1.0f / (1.0f + expf(-acc));
+    }
+    __syncthreads();
+    const int c4n = c >> 2;
+    const long long base = ((long long)img * hw + (long long)blockIdx.x * rows) * c;
+    const int total4 = rows * c4n;
+    for (int i = tid; i < total4; i += 256) {
+        const int cc = i % c4n;
+        const f32x4 yy = *(const f32x4*)(y + base + (long long)i * 4);
+        const f32x4 rr = *(const f32x4*)(sc + base + (long long)i * 4);
+        const f32x4 ss = *(const f32x4*)&gate[cc * 4];
+        f32x4 o = ss * yy + rr;
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        *(f32x4*)(out + base + (long long)i * 4) = o;
+    }
+}
+
 // ---- GeM (attention_pooling.py:58-60) + BNNeck (SERes18_IBN.py:268).  One block per image, thread = channel.
 __global__ __launch_bounds__(256) void gem_neck_kernel(const float* __restrict__ x, int hw, int c,
                                                        const float* __restrict__ p_ptr, const float* __restrict__ scale,
@@ -322,6 +366,25 @@ int launch_se_combine(reid_ctx* ctx, const float* y, const float* sc, const floa
     const long long total4 = (long long)n_img * hw * (c / 4);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, total4 * 48.0);
     hipLaunchKernelGGL(se_combine_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, ctx->stream, y, sc, s, total4, hw, c, out);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+// slices per image of the fused SE tail / in-place norm kernels: enough blocks to fill the chip, at least 16 rows per block
+int tail_slices(int n_img, int hw) {
+    int s = 1;
+    while ((long long)n_img * s < 1024 && hw / (s * 2) >= 16 && hw % (s * 2) == 0) s *= 2;
+    return s;
+}
+
+int launch_se_tail(reid_ctx* ctx, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1, const float* w2,
+                   const float* y, const float* sc, float* out) {
+    ARG_CHECK(c % 4 == 0 && c <= 512 && mid <= 64);
+    const int slices = tail_slices(n_img, hw);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 12.0);
+    hipLaunchKernelGGL(se_tail_kernel, dim3(slices, n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2, y, sc,
+                       hw / slices, out);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

@@ -205,17 +205,72 @@ int launch_affine_relu_f16(reid_ctx* ctx, f16* x, const float* a, const float* b
     LAUNCH_CHECK();
     return REID_OK;
 }
+// IBN / BN finalisation + application in ONE launch (fp16 path, SERes18_IBN.py:88-93): grid (slices, images).  Every block
+// derives its image's per-channel (a, b) as norm_finalize_kernel does (InstanceNorm half from the conv epilogue's partial sums,
+// BatchNorm half folded), then rewrites its rows in place: x = relu(x * a + b).
+__global__ __launch_bounds__(256) void norm_apply_f16_kernel(f16* __restrict__ x, const float* __restrict__ stats, int tiles, int c,
+                                                             int half, int hw, int rows, const float* __restrict__ in_gamma,
+                                                             const float* __restrict__ in_beta, const float* __restrict__ bn_scale,
+                                                             const float* __restrict__ bn_shift) {
+    __shared__ float sa[512], sb[512];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    for (int ch = tid; ch < c; ch += 256) {
+        float a, b;
+        if (ch < half) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int t = 0; t < tiles; ++t) {
+                const float* st = stats + (((long long)img * tiles + t) * c + ch) * 2;
+                s1 += (double)st[0];
+                s2 += (double)st[1];
+            }
+            const double mean = s1 / hw;
+            double var = s2 / hw - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double inv = 1.0 / sqrt(var + 1e-5);
+            a = (float)(inv * (double)in_gamma[ch]);
+            b = (float)((double)in_beta[ch] - mean * inv * (double)in_gamma[ch]);
+        } else {
+            a = bn_scale[ch - half];
+            b = bn_shift[ch - half];
+        }
+        sa[ch] = a;
+        sb[ch] = b;
+    }
+    __syncthreads();
+    const int c8n = c >> 3;
+    f16* base = x + ((long long)img * hw + (long long)blockIdx.x * rows) * c;
+    for (int i = tid; i < rows * c8n; i += 256) {
+        const int cc = i % c8n;
+        half8 v = *(const half8*)(base + (long long)i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (f16)fmaxf((float)v[e] * sa[cc * 8 + e] + sb[cc * 8 + e], 0.f);
+        *(half8*)(base + (long long)i * 8) = v;
+    }
+}
+
+int launch_norm_apply_f16(reid_ctx* ctx, f16* x, const float* stats, int n_img, int tiles, int c, int half, int hw,
+                          const float* in_gamma, const float* in_beta, const float* bn_scale, const float* bn_shift) {
+    ARG_CHECK(c % 8 == 0 && c <= 512);
+    const int slices = tail_slices(n_img, hw);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 4.0);
+    hipLaunchKernelGGL(norm_apply_f16_kernel, dim3(slices, n_img), dim3(256), 0, ctx->stream, x, stats, tiles, c, half, hw, hw / slices,
+                       in_gamma, in_beta, bn_scale, bn_shift);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
 // SE gate + combine of one SE block in one launch (SERes18_IBN.py:32-41 + :120-128): block = image.  Phase 1 is se_finalize
 // (pooled mean from the conv2 epilogue's partial sums -> 8..32 hidden units -> sigmoid gate, kept in LDS), phase 2 streams the
 // image: out = relu(gate * y + shortcut).  Several blocks per CU overlap one image's gate with another's streaming.
 __global__ __launch_bounds__(256) void se_tail_f16_kernel(const float* __restrict__ stats, int tiles, int c, int mid, int hw,
                                                           const float* __restrict__ w1, const float* __restrict__ w2t,
                                                           const f16* __restrict__ y, const f16* __restrict__ sc,
-                                                          f16* __restrict__ out) {
+                                                          int rows, f16* __restrict__ out) {
     __shared__ float pooled[512];
     __shared__ float hid[64];
     __shared__ float gate[512];
-    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // grid (slices, images)
     for (int ch = tid; ch < c; ch += 256) {
         double acc = 0.0;
         for (int t = 0; t < tiles; ++t) acc += (double)stats[(((long long)img * tiles + t) * c + ch) * 2];
@@ -236,8 +291,8 @@ __global__ __launch_bounds__(256) void se_tail_f16_kernel(const float* __restric
     }
     __syncthreads();
     const int c8n = c >> 3;
-    const long long base = (long long)img * hw * c;
-    const int total8 = hw * c8n;
+    const long long base = ((long long)img * hw + (long long)blockIdx.x * rows) * c;
+    const int total8 = rows * c8n;
     for (int i = tid; i < total8; i += 256) {
         const int cc = i % c8n;
         const half8 yy = *(const half8*)(y + base + (long long)i * 8);
@@ -252,8 +307,10 @@ __global__ __launch_bounds__(256) void se_tail_f16_kernel(const float* __restric
 int launch_se_tail_f16(reid_ctx* ctx, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1,
                        const float* w2t, const f16* y, const f16* sc, f16* out) {
     ARG_CHECK(c % 8 == 0 && c <= 512 && mid <= 64);
+    const int slices = tail_slices(n_img, hw);   // one slice per image at 1024 crops; 8-16 for a tracking frame
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 6.0);
-    hipLaunchKernelGGL(se_tail_f16_kernel, dim3(n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2t, y, sc, out);
+    hipLaunchKernelGGL(se_tail_f16_kernel, dim3(slices, n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2t, y, sc,
+                       hw / slices, out);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

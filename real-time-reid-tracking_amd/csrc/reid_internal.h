@@ -117,6 +117,8 @@ int launch_prep_u8_pad_f16(reid_ctx*, const uint8_t* crops, int n, int h, int w,
 int launch_prep_f32_pad_f16(reid_ctx*, const float* nhwc3, int n, int h, int w, int hp, int wp, _Float16* out);
 int launch_maxpool3s2_f16(reid_ctx*, const _Float16* x, int n, int h, int w, int c, _Float16* out);
 int launch_affine_relu_f16(reid_ctx*, _Float16* x, const float* a_scale, const float* a_shift, int n_img, int hw, int c);
+int launch_norm_apply_f16(reid_ctx*, _Float16* x, const float* stats, int n_img, int tiles, int c, int half, int hw,
+                          const float* in_gamma, const float* in_beta, const float* bn_scale, const float* bn_shift);
 int launch_se_tail_f16(reid_ctx*, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1, const float* w2t,
                        const _Float16* y, const _Float16* sc, _Float16* out);
 int launch_se_combine_f16(reid_ctx*, const _Float16* y, const _Float16* sc, const float* s, int n_img, int hw, int c,
@@ -135,6 +137,8 @@ int launch_stem_pool_f16(reid_ctx*, const _Float16* pad_in, const uint8_t* crops
                          _Float16* pooled);
 int launch_conv_w16_chunked(reid_ctx*, const float* w_f32, int cout, int rs, int cin, _Float16* out);  // -> [Cout][Cin/64][RS][64]   // [64][8][24] -> [64][8][8][4]
 int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int kind, double flops, double bytes);
+int launch_ta_tail(reid_ctx* ctx, const float* y, const float* sc, int n_img, int H, int W, int C, const float* wts, float* out);
+int launch_ema_tail(reid_ctx* ctx, const float* y, const float* sc, int n_img, int H, int W, int C, const float* prm, float* out);
 int launch_stem_f32(reid_ctx* ctx, const void* x, bool is_u8, int n, const float* wgt, const float* scale, const float* shift,
                     float* out);   // stem_f32.hip: 7x7 s2 conv + BN of the fp32 path
 bool gemm_f32_dma_supported(int amode, int epi, const GemmParams& p);   // gemm_f32_dma.hip: dense GEMM with LDS-DMA staging
@@ -154,6 +158,9 @@ int launch_in_apply(reid_ctx*, float* x, const float* stats, int n_img, int tile
                     const float* in_beta);
 int launch_se_finalize(reid_ctx*, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1,
                        const float* w2, float* s);
+int tail_slices(int n_img, int hw);   // elementwise.hip: blocks per image of the fused tail kernels
+int launch_se_tail(reid_ctx*, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1, const float* w2,
+                   const float* y, const float* sc, float* out);
 int launch_se_combine(reid_ctx*, const float* y, const float* sc, const float* s, int n_img, int hw, int c, float* out);
 int launch_gem_neck(reid_ctx*, const float* x, int n_img, int hw, int c, const float* p, const float* scale,
                     const float* shift, float* gem_out, float* emb);
@@ -176,6 +183,7 @@ struct Se18Block {
     int c, cin, stride, ibn, ds, mid;
     const float *conv1_w, *in_gamma, *in_beta, *bn1_scale, *bn1_shift, *conv2_w, *bn2_scale, *bn2_shift;
     const float *ds_w, *ds_scale, *ds_shift, *se_w1, *se_w2;
+    const float *ta, *ema;   // sibling backbones: TripletAttention gates [3][100] / EMA parameters (attention_f32.hip)
 };
 
 struct Se18Weights {
@@ -183,6 +191,7 @@ struct Se18Weights {
     float* blob = nullptr;
     size_t n_floats = 0;
     int num_class = 0;
+    int arch = 0;                 // 0 SERse18_IBN, 1 CARes18_IBN (TripletAttention), 2 EMARes18_IBN
     const float *stem_w, *stem_scale, *stem_shift;
     Se18Block blk[8];
     const float *gem_p, *neck_scale, *neck_shift, *cls_w;

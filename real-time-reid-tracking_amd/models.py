@@ -4,10 +4,12 @@ The reference's registry maps ~55 names to torchreid constructors that are not v
 own additions are 'vit' and 'swin_transformer' (:79-80).  This registry holds the backbones that exist as HIP
 kernel sequences; every other name raises the same ``KeyError`` the reference raises for an unknown model.
 """
-from .backbone import seres18_ibn, swin_t
+from .backbone import cares18_ibn, emares18_ibn, seres18_ibn, swin_t
 
 __model_factory = {
     'seres18_ibn': seres18_ibn,
+    'cares18_ibn': cares18_ibn,          # sibling backbones of reid/backbones (CARes18.py, EMA_Res18.py)
+    'emares18_ibn': emares18_ibn,
     'swin_transformer': swin_t,          # the reference's own addition (models/__init__.py:80)
 }
 

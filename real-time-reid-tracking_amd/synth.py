@@ -46,11 +46,75 @@ def _conv(rng, cout, cin, k, gain=2.0):
     return rng.normal(0.0, std, (cout, cin, k, k)).astype(np.float32)
 
 
-def seres18_state_dict(seed=0, num_class=751, num_cams=6, gem_p=None):
+def _attention_seres18(rng, sd, name, c, ibn):
+    mid = se_mid(c)
+    sd[name + ".seblock.fc1.weight"] = rng.normal(0.0, np.sqrt(2.0 / c), (mid, c, 1, 1)).astype(np.float32)
+    # the SE norm layer exists in the state_dict but is never applied
+    # (SERes18_IBN.py:36 is commented out): LBN_1D for layers 1-3, BatchNorm1d for layer 4
+    if ibn:
+        h = mid // 2
+        sd[name + ".seblock.bn.LN.weight"] = np.ones(h, np.float32)
+        sd[name + ".seblock.bn.LN.bias"] = np.zeros(h, np.float32)
+        _bn(rng, sd, name + ".seblock.bn.BN", mid - h)
+    else:
+        _bn(rng, sd, name + ".seblock.bn", mid)
+    sd[name + ".seblock.fc2.weight"] = rng.normal(0.0, np.sqrt(2.0 / mid), (c, mid)).astype(np.float32)
+
+
+def _attention_cares18(rng, sd, name, c, ibn):
+    """TripletAttention (reid/backbones/triplet_attention.py:69-101): three AttentionGates, each conv7x7 (2 -> 1, no bias) + BN(1).
+    CABasicBlock instantiates it in place of CABlock (CARes18.py:148)."""
+    for gate in ("cw", "hc", "hw"):
+        sd["%s.cablock.%s.conv.conv.weight" % (name, gate)] = rng.normal(0.0, 0.25, (1, 2, 7, 7)).astype(np.float32)
+        _bn(rng, sd, "%s.cablock.%s.conv.bn" % (name, gate), 1)
+
+
+def _attention_emares18(rng, sd, name, c, ibn):
+    """EMA (reid/backbones/EMA_Res18.py:10-38), factor 32: GroupNorm, conv1x1 and conv3x3 over c / 32 channels, with biases."""
+    cg = c // 32
+    sd[name + ".emablock.gn.weight"] = rng.uniform(0.5, 1.5, cg).astype(np.float32)
+    sd[name + ".emablock.gn.bias"] = rng.normal(0.0, 0.1, cg).astype(np.float32)
+    sd[name + ".emablock.conv1x1.weight"] = rng.normal(0.0, np.sqrt(1.0 / cg), (cg, cg, 1, 1)).astype(np.float32)
+    sd[name + ".emablock.conv1x1.bias"] = rng.normal(0.0, 0.1, cg).astype(np.float32)
+    sd[name + ".emablock.conv3x3.weight"] = rng.normal(0.0, np.sqrt(1.0 / (9 * cg)), (cg, cg, 3, 3)).astype(np.float32)
+    sd[name + ".emablock.conv3x3.bias"] = rng.normal(0.0, 0.1, cg).astype(np.float32)
+
+
+_ATTENTION = {"seres18_ibn": _attention_seres18, "cares18_ibn": _attention_cares18, "emares18_ibn": _attention_emares18}
+
+
+_SEQ_NAMES = ((".block_pre.conv1.", ".block_pre.0."), (".block_pre.bn1.", ".block_pre.1."), (".block_pre.conv2.", ".block_pre.3."),
+              (".block_pre.bn2.", ".block_pre.4."), (".block_post.conv.", ".block_post.0."), (".block_post.bn.", ".block_post.1."))
+
+
+def sibling_key(k, to_reference=True):
+    """CABasicBlock / EMABasicBlock build block_pre of a downsample block as nn.Sequential(*children) (CARes18.py:141-142,
+    EMA_Res18.py:69-70): its state_dict keys are positional (block_pre.0 = conv1, .1 = bn1, .3 = conv2, .4 = bn2; block_post.0 /
+    .1 = the downsample conv / BN), where SEBasicBlock's are named.  Maps named <-> positional."""
+    for named, pos in _SEQ_NAMES:
+        a, b = (named, pos) if to_reference else (pos, named)
+        if a in k:
+            return k.replace(a, b)
+    return k
+
+
+def cares18_state_dict(seed=0, num_class=751, num_cams=6, gem_p=None):
+    """numpy ``state_dict`` of CARes18_IBN (reid/backbones/CARes18.py:185-248): the SERse18_IBN skeleton with a
+    TripletAttention per block instead of the SE block."""
+    return seres18_state_dict(seed, num_class, num_cams, gem_p, arch="cares18_ibn")
+
+
+def emares18_state_dict(seed=0, num_class=751, num_cams=6, gem_p=None):
+    """numpy ``state_dict`` of EMARes18_IBN (reid/backbones/EMA_Res18.py:118-181): the same skeleton with an EMA block."""
+    return seres18_state_dict(seed, num_class, num_cams, gem_p, arch="emares18_ibn")
+
+
+def seres18_state_dict(seed=0, num_class=751, num_cams=6, gem_p=None, arch="seres18_ibn"):
     """numpy ``state_dict`` for SERse18_IBN (default ctor: gem pooling, se_lbn=True).
 
     Running stats, affine terms and (optionally) the GeM exponent are
     randomised so that a folding/ordering bug shows up in the outputs.
+    ``arch`` selects the attention module of the sibling backbones (same conv skeleton, same key order otherwise).
     """
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
@@ -72,22 +136,14 @@ def seres18_state_dict(seed=0, num_class=751, num_cams=6, gem_p=None):
         if ds:
             sd[name + ".block_post.conv.weight"] = _conv(rng, c, cin, 1, gain=1.0)
             _bn(rng, sd, name + ".block_post.bn", c)
-        mid = se_mid(c)
-        sd[name + ".seblock.fc1.weight"] = rng.normal(0.0, np.sqrt(2.0 / c), (mid, c, 1, 1)).astype(np.float32)
-        # the SE norm layer exists in the state_dict but is never applied
-        # (SERes18_IBN.py:36 is commented out): LBN_1D for layers 1-3, BatchNorm1d for layer 4
-        if ibn:
-            h = mid // 2
-            sd[name + ".seblock.bn.LN.weight"] = np.ones(h, np.float32)
-            sd[name + ".seblock.bn.LN.bias"] = np.zeros(h, np.float32)
-            _bn(rng, sd, name + ".seblock.bn.BN", mid - h)
-        else:
-            _bn(rng, sd, name + ".seblock.bn", mid)
-        sd[name + ".seblock.fc2.weight"] = rng.normal(0.0, np.sqrt(2.0 / mid), (c, mid)).astype(np.float32)
+        _ATTENTION[arch](rng, sd, name, c, ibn)
     p = float(rng.uniform(2.5, 3.5)) if gem_p is None else float(gem_p)
     sd["avgpooling.p"] = np.asarray([p], dtype=np.float32)
     _bn(rng, sd, "bnneck", 512)
     sd["classifier.0.weight"] = rng.normal(0.0, 0.05, (num_class, 512)).astype(np.float32)
+    if arch != "seres18_ibn":       # the siblings' downsample blocks carry positional keys (sibling_key)
+        ds_blocks = tuple(b[0] for b in SERES18_BLOCKS if b[3])
+        sd = OrderedDict((sibling_key(k) if k.startswith(ds_blocks) else k, v) for k, v in sd.items())
     return sd
 
 

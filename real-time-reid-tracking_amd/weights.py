@@ -33,13 +33,16 @@ def _np(v):
 
 
 def normalize_state_dict(state_dict):
-    """Unwraps {'state_dict': ...}, strips 'module.', converts to numpy."""
+    """Unwraps {'state_dict': ...}, strips 'module.', converts to numpy; the positional keys of the sibling backbones' downsample
+    blocks (block_pre.0 / .1 / .3 / .4, block_post.0 / .1: CARes18.py:141-142) become the named ones of SERse18_IBN."""
     if isinstance(state_dict, dict) and "state_dict" in state_dict and not hasattr(state_dict["state_dict"], "shape"):
         state_dict = state_dict["state_dict"]
     out = OrderedDict()
     for k, v in state_dict.items():
         if k.startswith("module."):
             k = k[7:]
+        if k.startswith("basicBlock"):
+            k = synth.sibling_key(k, to_reference=False)
         out[k] = _np(v)
     return out
 
@@ -97,6 +100,8 @@ def pack_seres18(state_dict):
     for k in required:
         if k not in sd:
             raise KeyError("state_dict is not a SERse18_IBN checkpoint: missing '%s'" % k)
+    arch = ("cares18_ibn" if any(".cablock." in k for k in sd) else
+            "emares18_ibn" if any(".emablock." in k for k in sd) else "seres18_ibn")
     pk = Packer()
     pk.add("stem.w", stem_pack(sd["conv0.weight"]))
     s, b = fold_bn(sd, "bn0")
@@ -122,10 +127,25 @@ def pack_seres18(state_dict):
             s, b = fold_bn(sd, name + ".block_post.bn")
             pk.add(sh + ".ds.scale", s)
             pk.add(sh + ".ds.shift", b)
-        mid = synth.se_mid(c)
-        pk.add(sh + ".se.w1", np.asarray(sd[name + ".seblock.fc1.weight"], np.float32).reshape(mid, c))
-        # fc2 stored transposed [mid][C]: the SE kernel reads it with consecutive threads on consecutive channels
-        pk.add(sh + ".se.w2t", np.ascontiguousarray(np.asarray(sd[name + ".seblock.fc2.weight"], np.float32).reshape(c, mid).T))
+        if arch == "cares18_ibn":
+            # TripletAttention (triplet_attention.py:69-101): per gate the 7x7 conv weight [2][7][7] (std, mean planes) + folded BN(1)
+            gates = []
+            for gate in ("cw", "hc", "hw"):
+                gp = "%s.cablock.%s.conv" % (name, gate)
+                gs, gb = fold_bn(sd, gp + ".bn")
+                gates.append(np.concatenate([np.asarray(sd[gp + ".conv.weight"], np.float32).reshape(98), gs, gb]))
+            pk.add(sh + ".ta", np.concatenate(gates))
+        elif arch == "emares18_ibn":
+            # EMA (EMA_Res18.py:10-22): conv1x1 w, b | conv3x3 w [co][ci][3][3], b | GroupNorm weight, bias
+            ep = name + ".emablock"
+            pk.add(sh + ".ema", np.concatenate([np.asarray(sd[ep + k], np.float32).reshape(-1) for k in
+                                                (".conv1x1.weight", ".conv1x1.bias", ".conv3x3.weight", ".conv3x3.bias",
+                                                 ".gn.weight", ".gn.bias")]))
+        else:
+            mid = synth.se_mid(c)
+            pk.add(sh + ".se.w1", np.asarray(sd[name + ".seblock.fc1.weight"], np.float32).reshape(mid, c))
+            # fc2 stored transposed [mid][C]: the SE kernel reads it with consecutive threads on consecutive channels
+            pk.add(sh + ".se.w2t", np.ascontiguousarray(np.asarray(sd[name + ".seblock.fc2.weight"], np.float32).reshape(c, mid).T))
     p = sd.get("avgpooling.p", np.asarray([3.0], np.float32))   # GeM init p=3 (attention_pooling.py:52)
     pk.add("gem.p", np.asarray(p, np.float32).reshape(1))
     s, b = fold_bn(sd, "bnneck")
@@ -137,7 +157,7 @@ def pack_seres18(state_dict):
         num_class = w.shape[0]
         pk.add("cls.w", w)
     blob, manifest = pk.finish()
-    return blob, manifest, {"arch": "seres18_ibn", "embed_dim": 512, "num_class": num_class}
+    return blob, manifest, {"arch": arch, "embed_dim": 512, "num_class": num_class}
 
 
 # ------------------------------------------------------------------------------------------------ Swin-T (v1)

@@ -904,3 +904,34 @@ def test_swin_window_attention_mfma_equals_valu_kernel(eng):
     for i, tol in ((0, 2e-5), (1, 2e-3)):
         a, b = res["0"][i], res["2"][i]
         assert np.abs(a - b).max() <= tol * np.abs(a).max(), (i, np.abs(a - b).max(), np.abs(a).max())
+
+
+# ----------------------------------------------------------------------------- sibling backbones
+@pytest.mark.parametrize("tag,name,sd_fn", [("ca", "cares18_ibn", synth.cares18_state_dict), ("ema", "emares18_ibn", synth.emares18_state_dict)])
+def test_sibling_backbones_match_reference_fixture(eng, golden_dir, tag, name, sd_fn):
+    """CARes18_IBN (TripletAttention blocks) and EMARes18_IBN (EMA blocks) on the ResNet18-IBN conv kernels, against the embeddings,
+    logits and per-block outputs the REFERENCE's own classes produced (tests/golden/siblings.npz)."""
+    from reid_amd.models import build_model
+    g = np.load(os.path.join(golden_dir, "siblings.npz"))
+    model = build_model(name, num_classes=751, loss="triplet", pretrained=False, use_gpu=True)
+    assert list(model.state_dict().keys()) == list(sd_fn(0).keys())       # the reference's own key layout (positional in downsample blocks)
+    model.load_state_dict(sd_fn(0), strict=True)
+    x = seres18.preprocess_u8(synth.smooth_crops_u8(3, 7)).numpy()
+    eng.debug_keep(1)
+    try:
+        emb, logits = model(x, return_logits=True)
+        for i, blk in enumerate(b[0] for b in synth.SERES18_BLOCKS):
+            c, (h, w) = [64, 64, 128, 128, 256, 256, 512, 512][i], [(64, 32), (64, 32), (32, 16), (32, 16), (16, 8), (16, 8), (16, 8), (16, 8)][i]
+            t = torch.from_numpy(eng.debug_stage(2 + i, 3).reshape(3, h, w, c)).permute(0, 3, 1, 2)
+            got = t[:, :: max(1, c // 8), :: max(1, h // 8), :: max(1, w // 4)].numpy()
+            ref = g["%s_tap_%s" % (tag, blk)]
+            assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (blk, np.abs(got - ref).max(), np.abs(ref).max())
+    finally:
+        eng.debug_keep(0)
+    cos = (emb * g[tag + "_emb"]).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(g[tag + "_emb"], axis=1)
+    assert (1 - cos).max() < 1e-5
+    assert np.abs(emb - g[tag + "_emb"]).max() <= 2e-5 * np.abs(g[tag + "_emb"]).max()
+    assert np.abs(logits - g[tag + "_logits"]).max() <= 5e-5 * np.abs(g[tag + "_logits"]).max()
+    # other batch sizes go through the same kernels: a single crop, and the crops inside a larger batch
+    e1 = model(x[:1])
+    assert np.abs(e1 - emb[:1]).max() <= 2e-5 * np.abs(emb).max()

@@ -209,3 +209,18 @@ def test_smooth_tracklets_oracle_matches_reference(golden_dir):
     np.testing.assert_allclose(got, z["st_out"], rtol=0, atol=2e-6)
     untouched = ~z["st_valid"]
     assert np.array_equal(got[untouched], z["st_x"][untouched]) and untouched.sum() > 40   # incl. the tracklet with no valid row
+
+
+@pytest.mark.parametrize("tag,arch,sd_fn", [("ca", "cares18_ibn", synth.cares18_state_dict), ("ema", "emares18_ibn", synth.emares18_state_dict)])
+def test_sibling_backbones_oracle_matches_reference(golden_dir, tag, arch, sd_fn):
+    """oracle/seres18.py with arch = cares18_ibn / emares18_ibn against the reference's own CARes18_IBN / EMARes18_IBN
+    (tests/golden/siblings.npz: embedding, logits and every block output, sampled as gen_golden.py sampled them)."""
+    g = np.load(os.path.join(golden_dir, "siblings.npz"))
+    sd = sd_fn(0)
+    taps = {}
+    emb, logits = seres18.forward(sd, seres18.preprocess_u8(synth.smooth_crops_u8(3, 7)), taps, arch=arch)
+    np.testing.assert_allclose(emb.numpy(), g[tag + "_emb"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(logits.numpy(), g[tag + "_logits"], rtol=2e-4, atol=2e-3)
+    for name in [b[0] for b in synth.SERES18_BLOCKS]:
+        got = _sample(taps[name])
+        np.testing.assert_allclose(got, g["%s_tap_%s" % (tag, name)], rtol=2e-4, atol=2e-4, err_msg=name)
