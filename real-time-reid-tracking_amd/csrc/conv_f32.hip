@@ -483,7 +483,9 @@ bool conv_f32_supported(const GemmParams& p) {
 int launch_conv_f32(reid_ctx* ctx, const GemmParams& p, int kind, double flops, double bytes) {
     ARG_CHECK(conv_f32_supported(p));
     prof_begin(ctx, kind, flops, bytes);
-    if (p.N % 128 == 0) launch_bn<128>(ctx, p);
+    // 128-wide tiles when they fill the chip; a tracking-sized batch (30 crops: 30 M-tiles) gets twice the blocks from 64-wide tiles,
+    // each with half the K-loop time
+    if (p.N % 128 == 0 && (long long)(p.M / BM) * (p.N / 128) >= 256) launch_bn<128>(ctx, p);
     else launch_bn<64>(ctx, p);
     prof_end(ctx);
     LAUNCH_CHECK();
