@@ -86,3 +86,47 @@ def test_shard_bounds_and_merge():
     d1, i1 = np.asarray([[0.5, 0.6, np.inf]], np.float32), np.asarray([[0, 12, -1]], np.int32)
     D, I = parallel.merge_topk([d0, d1], [i0, i1], 4)
     assert I.tolist() == [[4, 0, 1, 12]] and D.dtype == np.float32     # tie at 0.5 -> lower global index first
+
+
+# ----------------------------------------------------------------------------- RCCL bootstrap (no GPU: the C calls are recorded)
+class _FakeLib:
+    """Stands in for libreid_hip.so's communicator entry points: records what each rank hands to reid_comm_init."""
+
+    def __init__(self, log):
+        self.log = log
+
+    def reid_comm_init(self, h, rank, world, buf):
+        self.log.update(rank=rank, world=world, id=bytes(buf) if buf is not None else None)
+        return 0
+
+    def reid_comm_destroy(self, h):
+        return 0
+
+
+class _FakeEngine:
+    def __init__(self, log):
+        self.lib, self.h = _FakeLib(log), None
+
+
+def _bootstrap_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    log = {}
+    # rank 0's ncclGetUniqueId is replaced by a recognisable 128-byte pattern (librccl needs a GPU)
+    parallel.RcclComm.unique_id = staticmethod(lambda: bytes((7 * i + 3) % 256 for i in range(128)))
+    try:
+        comm = parallel.RcclComm.from_env(_FakeEngine(log))
+        assert (comm.rank, comm.world) == (rank, world)
+        np.save(os.path.join(tmp, "id%d.npy" % rank), np.frombuffer(log["id"], np.uint8))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_bootstrap_hands_the_same_id_to_every_rank(tmp_path):
+    """parallel.RcclComm.from_env under the torchrun environment: rank 0's 128-byte communicator id reaches every rank through
+    torch.distributed (gloo) and goes into reid_comm_init(ctx, rank, world, id) unchanged."""
+    world = 3
+    mp.spawn(_bootstrap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = np.asarray([(7 * i + 3) % 256 for i in range(128)], np.uint8)
+    for r in range(world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "id%d.npy" % r)), want)
