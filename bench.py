@@ -407,7 +407,30 @@ def run_tracking(job, args):
     if rank != 0:
         return None
     lat = np.asarray(lat) * 1e3
-    return {"metric": "frames/sec, per-frame crop batches embedded + gathered + matched (ResNet18-SE 128x256)", "value": round(frames / elapsed, 1),
+    cpu = None
+    if not args.no_cpu and world == 1:
+        # the oracle on the same stream, bounded: preprocess (cv2-style resize) + ResNet18-SE on the CPU + numpy cosine cost + DIoU
+        import torch
+        from oracle import matching, seres18
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        bank = rng.normal(size=(40, 100, 512)).astype(np.float32)
+        bank /= np.linalg.norm(bank, axis=2, keepdims=True)
+        t0c, fc, cc = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0c < 10.0 and fc < frames:
+            nf = int(counts[fc])
+            cr = [pool[(fc * 7 + i) % 256] for i in range(nf)]
+            e, _ = seres18.forward(sd, torch.from_numpy(matching.preprocess(cr)))
+            e = e.numpy()
+            e /= np.linalg.norm(e, axis=1, keepdims=True)
+            (1.0 - np.einsum("tbd,md->tbm", bank, e)).min(1)                 # _nn_cosine_distance per track
+            matching.diou_cost(boxes[:40], boxes[:nf])
+            fc += 1
+            cc += nf
+        elc = time.perf_counter() - t0c
+        cpu = {"value": round(fc / elc, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d frames, %d crops (%.1f s): oracle preprocess + oracle/seres18.py + numpy bank cost + DIoU" % (fc, cc, elc)}
+    out = {"metric": "frames/sec, per-frame crop batches embedded + gathered + matched (ResNet18-SE 128x256)", "value": round(frames / elapsed, 1),
             "unit": "frames/s", "n_gpus": world, "steps": frames, "warmup": 3, "ms_per_step": round(elapsed * 1e3 / frames, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[3] stand-in: %d frames, %d crops (Poisson(30) per frame, ragged sizes), round-robin over "
@@ -415,6 +438,9 @@ def run_tracking(job, args):
             "crops_per_s": round(ncrops / elapsed, 1), "ms_per_frame_median": round(float(np.median(lat)), 3),
             "ms_per_frame_p95": round(float(np.percentile(lat, 95)), 3),
             "allgather_us_median": round(float(np.median(gather_us)), 1) if gather_us else None}
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ configs[4]: Market-sized retrieval

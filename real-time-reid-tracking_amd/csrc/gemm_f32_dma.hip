@@ -161,6 +161,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                     }
                 }
             }
+            float rsq[16];
+            if constexpr (EPI == E_DIST) {   // squared norms of the tile's 16 rows of this lane half: four groups of four consecutive rows
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r4 = row0 + 8 * q;
+                    if (p.row_sq && r4 + 3 < p.M && ((uintptr_t)(p.row_sq + r4) & 15) == 0) {
+                        const f32x4 t = *(const f32x4*)(p.row_sq + r4);
+                        rsq[4 * q] = t.x; rsq[4 * q + 1] = t.y; rsq[4 * q + 2] = t.z; rsq[4 * q + 3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) rsq[4 * q + u] = (p.row_sq && r4 + u < p.M) ? p.row_sq[r4 + u] : 0.f;
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row0 + (e & 3) + 8 * (e >> 2);
@@ -180,8 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                     if (p.residual) v += p.scat_h == 0 ? res[e] : (ok ? p.residual[idx] : 0.f);
                     if (ok) p.C[idx] = v;
                 } else {
-                    float rs = 0.f;
-                    if (ok && p.row_sq) rs = p.row_sq[row];
+                    const float rs = rsq[e];
                     switch (p.metric) {
                         case REID_METRIC_L2: v = sqrtf(fmaxf((rs + cq) - 2.0f * v, 1e-12f)); break;
                         case REID_METRIC_L2SQR: v = (rs + cq) - 2.0f * v; break;
