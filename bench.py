@@ -110,8 +110,10 @@ class Job:
         if self.world != args.gpus:
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, self.world, args.gpus))
-        torch.cuda.set_device(self.local_rank)
-        self.eng = get_engine(self.local_rank)
+        # REID_BENCH_ONE_DEVICE=1: every rank on device 0 (rehearsal of the multi-rank path on a one-GPU box, if RCCL allows it)
+        self.device = 0 if os.environ.get("REID_BENCH_ONE_DEVICE") == "1" else self.local_rank
+        torch.cuda.set_device(self.device)
+        self.eng = get_engine(self.device)
         # one explicit (non-null) HIP stream shared by torch (synchronize) and the C ABI launches + RCCL calls
         self.stream = torch.cuda.Stream()
         torch.cuda.set_stream(self.stream)

@@ -87,6 +87,42 @@ __device__ __forceinline__ void conv_epilogue(const GemmParams& p, f32x16 (&acc)
     }
 }
 
+// Epilogue of the general variant (Swin patch merging, 8x8 alignment conv, ConvTranspose parities; swin_transformer.py:263-275,
+// 405-412): bias, optional residual, optional parity scatter (img, j, i) -> (img, 2j+py, 2i+px); ragged M and N predicated.
+template <int BN>
+__device__ __forceinline__ void bias_epilogue(const GemmParams& p, f32x16 (&acc)[2][BN / 64], int m_blk, int n_blk, int tid) {
+    constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n_blk + wn * WN + b * 32 + li;
+        const bool colok = col < p.N;
+        const float sh = (colok && p.col_shift) ? p.col_shift[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int row0 = m_blk + wm * 64 + a * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + (e & 3) + 8 * (e >> 2);
+                const bool ok = colok && row < p.M;
+                long long orow = row;
+                if (p.scat_h > 0) {
+                    const int hws = p.scat_h * p.scat_w;
+                    const int im = row / hws, rem = row - im * hws;
+                    const int j = rem / p.scat_w, i = rem - j * p.scat_w;
+                    orow = ((long long)im * 2 * p.scat_h + 2 * j + p.scat_py) * (2 * p.scat_w) + 2 * i + p.scat_px;
+                }
+                const long long idx = orow * p.ldc + col;
+                float v = acc[a][b][e] + sh;
+                if (p.residual && ok) v += p.residual[idx];
+                if (ok) p.C[idx] = v;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned long long stamp() {   // diagnostic builds only (cdna_hip_programming.md section 7, in-kernel stamps)
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -290,6 +326,7 @@ template <int BN, int FLAGS>
 __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
     constexpr bool DIAG = (FLAGS & 1) != 0;
+    constexpr bool GEN = (FLAGS & 4) != 0;          // general geometry: tiles may straddle images, ragged M / N, bias epilogue
     constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
     constexpr int ROWB = BK * 4;                    // 128-byte LDS rows
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
@@ -302,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int nnt = p.N / BN;
+    const int nnt = (p.N + BN - 1) / BN;
     int mtile, ntile;
     {
         const int nwg = gridDim.x;
@@ -313,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p
     }
     const int m_blk = mtile * BM, n_blk = ntile * BN;
     const int hw = p.Ho * p.Wo;
-    const int img = m_blk / hw;
+    const int img = m_blk / hw;                     // first image of the tile (the only one unless GEN)
     const int rem_blk = m_blk - img * hw;
 
     // ---- DMA descriptors
@@ -321,23 +358,30 @@ __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p
     // those lanes are flagged); num_records 2^28 > image + tap offsets, flagged offsets are >= 2^28
     const char* a_base = (const char*)p.A + ((long long)img * p.H * p.W - (p.pad_y * p.W + p.pad_x)) * (long long)p.Cin * 4;
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 1 << 28, 0x00020000);
-    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, GEN ? 0x7ffffe00 : 0x7fffffff, 0x00020000);
     int a_voff[AJ];
     unsigned a_flag[AJ];
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int row = (wave * AJ + j) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int rem = rem_blk + row;
+        int rem = rem_blk + row, dimg = 0;
+        if constexpr (GEN) {                                    // the tile may run over into the next images
+            dimg = rem / hw;
+            rem -= dimg * hw;
+        }
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        const int iy = oy * p.stride, ix = ox * p.stride;       // centre tap: always inside the image
-        a_voff[j] = ((iy * p.W + ix) * p.Cin + chunk * 4) * 4;
+        const int iy = oy * p.stride, ix = ox * p.stride;       // pixel of tap (pad_y, pad_x): always inside the image
+        a_voff[j] = (((dimg * p.H + iy) * p.W + ix) * p.Cin + chunk * 4) * 4;
         unsigned f = 0;
         if (iy - p.pad_y < 0) f |= 1u << 31;                    // tap row 0 is above the image
         if (iy - p.pad_y + p.R - 1 >= p.H) f |= 1u << 30;       // tap row R-1 is below it
         if (ix - p.pad_x < 0) f |= 1u << 29;
         if (ix - p.pad_x + p.S - 1 >= p.W) f |= 1u << 28;
         a_flag[j] = f;
+        if constexpr (GEN) {
+            if (m_blk + row >= p.M) a_voff[j] = 0x7fffff00;    // rows past M: out of range for every tap (num_records = 2^28)
+        }
     }
     int b_voff[BJ];
 #pragma unroll
@@ -345,6 +389,9 @@ __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p
         const int row = (wave * BJ + j) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         b_voff[j] = (int)(((long long)(n_blk + row) * p.ldb + chunk * 4) * 4);
+        if constexpr (GEN) {
+            if (n_blk + row >= p.N) b_voff[j] = 0x7fffff00;    // weight rows past N (beyond b_rs' num_records)
+        }
     }
     const int cpt = p.Cin / BK;
     const int nk = p.R * p.S * cpt;
@@ -441,8 +488,12 @@ __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p
 #pragma unroll
             for (int i = 0; i < 5; ++i) p.diag[(blockIdx.x * 8 + wave) * 5 + i] = dsum[i];
     }
-    __syncthreads();   // the epilogue reuses the tiles' LDS for the column statistics
-    conv_epilogue<BN>(p, acc, (float*)lds, m_blk, n_blk, mtile, tid);
+    if constexpr (GEN) {
+        bias_epilogue<BN>(p, acc, m_blk, n_blk, tid);
+    } else {
+        __syncthreads();   // the epilogue reuses the tiles' LDS for the column statistics
+        conv_epilogue<BN>(p, acc, (float*)lds, m_blk, n_blk, mtile, tid);
+    }
 #endif
 }
 
@@ -478,6 +529,26 @@ bool conv_f32_supported(const GemmParams& p) {
            p.Wo >= 1 && p.Wo <= 32 && 32 % p.Wo == 0 &&
            p.ldb % 4 == 0 && p.ldc == p.N && (p.a_scale == nullptr) == (p.a_shift == nullptr) &&
            (p.col_scale == nullptr) == (p.col_shift == nullptr) && (long long)p.H * p.W * p.Cin < (1ll << 31);
+}
+
+bool conv_f32_general_supported(const GemmParams& p) {
+    return p.Cin % BK == 0 && p.K == p.R * p.S * p.Cin && p.R == p.S && p.R >= 1 && p.R <= 8 && p.pad_y >= 0 && p.pad_y <= 1 &&
+           p.pad_x >= 0 && p.pad_x <= 1 && p.ldb % 4 == 0 && !p.a_scale && !p.stats && !p.col_scale && !p.relu && p.act == 0 &&
+           ((long long)5 * p.H * p.W + 16ll * p.W + 16) * p.Cin * 4 < (1ll << 28) && (long long)p.N * p.ldb * 4 < 0x7ffffe00ll &&
+           (long long)p.Ho * p.Wo * 4 >= BM;   // a 128-row tile touches at most 5 images
+}
+
+// Swin's convolutions with bias (patch merging 2x2 s2, alignment 8x8 s8, ConvTranspose parities 2x2 s1 with one-sided padding)
+int launch_conv_f32_general(reid_ctx* ctx, const GemmParams& p, int kind, double flops, double bytes) {
+    ARG_CHECK(conv_f32_general_supported(p));
+    prof_begin(ctx, kind, flops, bytes);
+    const int nmt = (p.M + BM - 1) / BM;
+    const double cost64 = ((p.N + 63) / 64) * 64 * 1.12, cost128 = ((p.N + 127) / 128) * 128;
+    if (p.N <= 64 || cost64 < cost128) hipLaunchKernelGGL((conv_f32_dma_kernel<64, 4>), dim3(nmt * ((p.N + 63) / 64)), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((conv_f32_dma_kernel<128, 4>), dim3(nmt * ((p.N + 127) / 128)), dim3(256), 0, ctx->stream, p);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
 }
 
 int launch_conv_f32(reid_ctx* ctx, const GemmParams& p, int kind, double flops, double bytes) {

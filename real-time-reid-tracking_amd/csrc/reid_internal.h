@@ -145,6 +145,8 @@ bool gemm_f32_dma_supported(int amode, int epi, const GemmParams& p);   // gemm_
 int launch_gemm_f32_dma(reid_ctx* ctx, int epi, const GemmParams& p, int kind, double flops, double bytes);
 bool conv_f32_supported(const GemmParams& p);   // conv_f32.hip: pipelined implicit-GEMM convolution of the fp32 path (full tiles)
 int launch_conv_f32(reid_ctx* ctx, const GemmParams& p, int kind, double flops, double bytes);
+bool conv_f32_general_supported(const GemmParams& p);   // same kernel, general geometry + bias epilogue (Swin's convolutions)
+int launch_conv_f32_general(reid_ctx* ctx, const GemmParams& p, int kind, double flops, double bytes);
 
 // elementwise / reduction kernels (elementwise.hip)
 int launch_nchw_to_nhwc3(reid_ctx*, const float* x_nchw, int n, int h, int w, float* out_nhwc);

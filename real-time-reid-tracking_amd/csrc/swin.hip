@@ -682,8 +682,9 @@ int conv_bias(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, const
     p.col_shift = bias; p.residual = residual;
     p.scat_h = scat_h; p.scat_w = scat_w; p.scat_py = py; p.scat_px = px;
     const double flops = 2.0 * p.M * Cout * p.K;
-    return launch_gemm_f32(ctx, A_IM2COL, E_BIAS, p, REID_K_CONV_GEMM, flops,
-                           4.0 * ((double)n * H * W * Cin + (double)Cout * p.K + (double)p.M * Cout));
+    const double bytes = 4.0 * ((double)n * H * W * Cin + (double)Cout * p.K + (double)p.M * Cout);
+    if (ctx->f32_conv == 1 && conv_f32_general_supported(p)) return launch_conv_f32_general(ctx, p, REID_K_CONV_GEMM, flops, bytes);
+    return launch_gemm_f32(ctx, A_IM2COL, E_BIAS, p, REID_K_CONV_GEMM, flops, bytes);
 }
 
 const int kDims[4] = {96, 192, 384, 768}, kLayers[4] = {2, 2, 6, 2}, kHeads[4] = {3, 6, 12, 24};
