@@ -282,6 +282,59 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ 
 }
 
 
+// ---- LayerNorm over the channel dimension, 16-byte accesses: LPT lanes per token (32 for C = 96: two tokens per wave; 64
+// otherwise), a lane owns the 4-channel chunks sub + LPT * j.  Two-pass (mean, then centred sum of squares) in registers.
+template <typename OUT, int LPT>
+__global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restrict__ x, long long ntok, int c, float eps,
+                                                           const float* __restrict__ g, const float* __restrict__ b,
+                                                           OUT* __restrict__ out) {
+    constexpr int TPW = 64 / LPT;                  // tokens per wave
+    constexpr int MAXJ = LPT == 32 ? 1 : 3;        // chunks per lane: C <= 128 (LPT 32) or C <= 768 (LPT 64)
+    const int lane = threadIdx.x & 63, sub = lane & (LPT - 1);
+    const long long tok = (blockIdx.x * 4LL + (threadIdx.x >> 6)) * TPW + lane / LPT;
+    const bool live = tok < ntok;
+    const int nch = c >> 2;
+    const float* xi = x + (live ? tok : 0) * c;
+    f32x4 v[MAXJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int ch = sub + LPT * j;
+        v[j] = (live && ch < nch) ? *(const f32x4*)(xi + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+#pragma unroll
+    for (int o = LPT / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        if (sub + LPT * j < nch) {
+            const f32x4 d = v[j] - mean;
+            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+    }
+#pragma unroll
+    for (int o = LPT / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / c + eps);
+    if (!live) return;
+    OUT* oi = out + tok * c;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int ch = sub + LPT * j;
+        if (ch < nch) {
+            const f32x4 gg = *(const f32x4*)(g + ch * 4), bb = *(const f32x4*)(b + ch * 4);
+            st4(oi + ch * 4, (v[j] - mean) * rstd * gg + bb);
+        }
+    }
+}
+
+template <typename OUT>
+void launch_layernorm(reid_ctx* ctx, const float* x, long long T, int C, const float* g, const float* b, OUT* out) {
+    if (C <= 128) hipLaunchKernelGGL((layernorm_v4_kernel<OUT, 32>), dim3((unsigned)((T + 7) / 8)), dim3(256), 0, ctx->stream, x, T, C, 1e-5f, g, b, out);
+    else hipLaunchKernelGGL((layernorm_v4_kernel<OUT, 64>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, x, T, C, 1e-5f, g, b, out);
+}
+
 // ---- WindowAttention v1 on the matrix cores (swin_transformer.py:191-232; north_star: "MFMA only on the Swin qk^T / attn.v").
 // One wave per (image, window, head); the 49 tokens of a window are padded to 64.
 //   S^T[key][query] = K . Q^T      (operands swapped so that a query's scores are lane-local: C layout col = lane & 31)
@@ -938,8 +991,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 f16* tmp16 = (f16*)tmp;                // [T][C]
                 const int ldq = (3 * C + 63) / 64 * 64;
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 6);
-                hipLaunchKernelGGL(layernorm_kernel<f16>, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f,
-                                   k.ln1_g, k.ln1_b, ln16);
+                launch_layernorm<f16>(ctx, xcur, T, C, k.ln1_g, k.ln1_b, ln16);
                 prof_end(ctx);
                 REID_TRY(linear16(ctx, ln16, T, C, C, h.qkv, nullptr, 3 * C, 0, nullptr, big16, nullptr, ldq));
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
@@ -954,8 +1006,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 REID_TRY(linear16(ctx, att16, T, C, C, h.out, k.out_b, C, 0, nullptr, tmp16, nullptr, C));
                 REID_TRY(linear16(ctx, tmp16, T, C, C, h.post, k.post_b, C, 0, xcur, nullptr, xcur, C));
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 6);
-                hipLaunchKernelGGL(layernorm_kernel<f16>, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f,
-                                   k.ln2_g, k.ln2_b, ln16);
+                launch_layernorm<f16>(ctx, xcur, T, C, k.ln2_g, k.ln2_b, ln16);
                 prof_end(ctx);
                 REID_TRY(linear16(ctx, ln16, T, C, C, h.fc1, k.fc1_b, 4 * C, 1, nullptr, big16, nullptr, 4 * C));
                 REID_TRY(linear16(ctx, big16, T, 4 * C, 4 * C, h.fc2, k.fc2_b, C, 0, xcur, nullptr, xcur, C));
@@ -963,7 +1014,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
             }
             // x = x + post_proj(to_out(attn(LN(x))))
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
-            hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f, k.ln1_g, k.ln1_b, lnb);
+            launch_layernorm<float>(ctx, xcur, T, C, k.ln1_g, k.ln1_b, lnb);
             prof_end(ctx);
             REID_TRY(linear(ctx, lnb, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big));
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 16);
@@ -979,7 +1030,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
             REID_TRY(linear(ctx, tmp, T, C, k.post_w, k.post_b, C, 0, xcur, xcur));
             // x = x + fc2(gelu(fc1(LN(x))))
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
-            hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, xcur, T, C, 1e-5f, k.ln2_g, k.ln2_b, lnb);
+            launch_layernorm<float>(ctx, xcur, T, C, k.ln2_g, k.ln2_b, lnb);
             prof_end(ctx);
             REID_TRY(linear(ctx, lnb, T, C, k.fc1_w, k.fc1_b, 4 * C, 1, nullptr, big));
             REID_TRY(linear(ctx, big, T, 4 * C, k.fc2_w, k.fc2_b, C, 0, xcur, xcur));
