@@ -394,16 +394,47 @@ def run_tracking(job, args):
         metric.partial_fit(feats[:k], tracks[:k], tracks)
         return n, cost, icost
 
-    for f in range(3):
-        frame(f)
+    def crops_of(f):
+        return [pool[(f * 7 + i) % 256] for i in range(int(counts[f]))]
+
+    def run_pipelined(first, last, lat):
+        """One GPU: the three-stage frame pipeline (csrc/bank.hip) - frame f+1 is packed into pinned memory, uploaded and embedded
+        while frame f's costs come back and its update is enqueued; one synchronisation per frame."""
+        t_sub = {first: time.perf_counter()}
+        eng.frame_submit(first & 1, crops_of(first))
+        total = 0
+        for f in range(first, last):
+            slot = f & 1
+            n = int(counts[f])
+            metric.frame_distance_begin(slot, tracks, 0.15, boxes[:40], boxes[:n])   # queued behind forward(f)
+            if f + 1 < last:
+                t_sub[f + 1] = time.perf_counter()
+                eng.frame_submit(slot ^ 1, crops_of(f + 1))                           # forward(f+1) runs under the host's work
+            feats, cost, icost = metric.frame_distance_end(slot)
+            k = min(n, 40)
+            metric.frame_partial_fit(slot, np.arange(k, dtype=np.int32), tracks[:k], tracks)
+            lat.append(time.perf_counter() - t_sub.pop(f))
+            total += n
+        eng.sync()
+        return total
+
+    pipelined = world == 1 and not args.no_pipeline
+    if pipelined:
+        run_pipelined(0, 3, [])
+    else:
+        for f in range(3):
+            frame(f)
     job.barrier()
     t0 = time.perf_counter()
     ncrops = 0
     lat = []
-    for f in range(frames):
-        t1 = time.perf_counter()
-        ncrops += frame(f, timed=True)[0]
-        lat.append(time.perf_counter() - t1)
+    if pipelined:
+        ncrops = run_pipelined(0, frames, lat)
+    else:
+        for f in range(frames):
+            t1 = time.perf_counter()
+            ncrops += frame(f, timed=True)[0]
+            lat.append(time.perf_counter() - t1)
     job.barrier()
     elapsed = float(comm.all_reduce([time.perf_counter() - t0], "max")[0])
     if rank != 0:
@@ -432,14 +463,50 @@ def run_tracking(job, args):
         elc = time.perf_counter() - t0c
         cpu = {"value": round(fc / elc, 2), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "%d frames, %d crops (%.1f s): oracle preprocess + oracle/seres18.py + numpy bank cost + DIoU" % (fc, cc, elc)}
+    multi = None
+    if pipelined and args.cameras > 1:
+        # several camera streams on the one GPU: own context (HIP stream, workspaces, bank) and host thread each
+        import threading
+        from reid_amd.tracking import CameraStream
+        blob, manifest = weights.pack_seres18(sd)[:2]
+        cams = []
+        for c in range(args.cameras):
+            cs = CameraStream(blob, manifest, 1 if args.precision == "f16" else 0)
+            cs.metric.partial_fit(rng.normal(size=(40 * 100, 512)).astype(np.float32), np.repeat(tracks, 100), tracks)
+            cams.append(cs)
+
+        def drive(cs, c, first, last):
+            cr = lambda f: [pool[(f * 7 + i + 31 * c) % 256] for i in range(int(counts[f]))]
+            cs.submit(cr(first))
+            for f in range(first, last):
+                n = int(counts[f])
+                cs.step(tracks, boxes[:40], boxes[:n], cr(f + 1) if f + 1 < last else None)
+                k = min(n, 40)
+                cs.commit(np.arange(k), tracks[:k], tracks)
+            cs.close()
+
+        for c, cs in enumerate(cams):
+            drive(cs, c, 0, 40)
+        th = [threading.Thread(target=drive, args=(cs, c, 0, frames)) for c, cs in enumerate(cams)]
+        t0m = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        elm = time.perf_counter() - t0m
+        multi = {"cameras": args.cameras, "frames_per_s_total": round(args.cameras * frames / elm, 1),
+                 "frames_per_s_per_camera": round(frames / elm, 1), "ms_per_frame_per_camera": round(elm / frames * 1e3, 3)}
     out = {"metric": "frames/sec, per-frame crop batches embedded + gathered + matched (ResNet18-SE 128x256)", "value": round(frames / elapsed, 1),
             "unit": "frames/s", "n_gpus": world, "steps": frames, "warmup": 3, "ms_per_step": round(elapsed * 1e3 / frames, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[3] stand-in: %d frames, %d crops (Poisson(30) per frame, ragged sizes), round-robin over "
-                                   "the ranks, all-gather of [n_f,512], bank cost (40 tracks x 100) + DIoU" % (frames, ncrops)},
+                                   "the ranks, all-gather of [n_f,512], bank cost (40 tracks x 100) + DIoU" % (frames, ncrops),
+                       "host_flow": "frame pipeline: cost f | submit f+1 | fetch f (the one wait) | update f" if pipelined else "one synchronous call per operation"},
             "crops_per_s": round(ncrops / elapsed, 1), "ms_per_frame_median": round(float(np.median(lat)), 3),
             "ms_per_frame_p95": round(float(np.percentile(lat, 95)), 3),
             "allgather_us_median": round(float(np.median(gather_us)), 1) if gather_us else None}
+    if multi is not None:
+        out["camera_streams"] = multi
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out
@@ -510,6 +577,8 @@ def main():
     ap.add_argument("--frames", type=int, default=600, help="--workload tracking: frames of the stream")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "1024")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cameras", type=int, default=2, help="--workload tracking, one GPU: also run this many concurrent camera streams")
+    ap.add_argument("--no-pipeline", action="store_true", help="--workload tracking: one synchronous call per operation (A/B)")
     ap.add_argument("--single", action="store_true", help="measure only --precision (skip the other arithmetic)")
     ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f32"),
                     help="arithmetic of the headline: f32 = the reference's (exact fp32 MFMA, default); f16 = fp16 storage / fp32 "

@@ -80,6 +80,10 @@ int reid_malloc(reid_ctx* ctx, size_t bytes, void** dptr);
 int reid_free(reid_ctx* ctx, void* dptr);
 int reid_memcpy_h2d(reid_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int reid_memcpy_d2h(reid_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* pinned host memory: uploads from it are asynchronous DMAs (a copy from pageable memory blocks the caller until the
+ * stream has drained) - where a tracker packs the crops it hands to reid_frame_submit */
+int reid_host_alloc(reid_ctx* ctx, size_t bytes, void** out);
+int reid_host_free(reid_ctx* ctx, void* p);
 
 /* HIP-event timing on the context's stream (bench.py) */
 int reid_timer_start(reid_ctx* ctx);
@@ -193,6 +197,23 @@ int reid_bank_cost(reid_ctx* ctx, reid_bank* bank, const int32_t* slots, int t, 
                    float max_dist, float* out_tm);
 int reid_bank_cost_dev(reid_ctx* ctx, reid_bank* bank, const int32_t* slots, int t, const float* d_dets, int m, int metric,
                        float max_dist, float* d_out_tm);
+/* ---- one DeepSORT frame as asynchronous stages with a single wait ------------------------------
+ * [external] deep_sort.py DeepSort.update: _get_features (Extractor.__call__, feature_extractor.py:48-53) -> Tracker.update
+ * -> metric.distance + iou_cost -> metric.partial_fit.  `slot` (0 / 1) names one of two frame slots that own their crops,
+ * embeddings and result staging: call cost(f), submit(f+1), fetch(f), <assign on the host>, update(f) and the device
+ * embeds frame f+1 while the host assigns frame f.
+ * submit (asynchronous): crops as for reid_embed_ragged_u8; `packed` must stay untouched until the slot's reid_frame_fetch
+ *   returns (offsets / hw are copied).  m == 0 is allowed.
+ * cost (asynchronous): appearance cost as reid_bank_cost over track slots[t] (bank NULL: skipped), DIoU cost as
+ *   reid_diou_cost over tlwh boxes tracks_t4[t] / dets_m4[m] (NULL: skipped), embeddings when want_emb != 0.  The full
+ *   t x m matrices serve every subset the matching cascade asks for.
+ * fetch (waits for the slot's cost stage only): emb fp32[m][512], cost_tm fp32[t][m], iou_tm fp64[t][m]; NULL = not wanted.
+ * update (asynchronous): partial_fit with row rows[i] of the slot's embeddings appended to track slots[i]. */
+int reid_frame_submit(reid_ctx* ctx, int slot, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int m);
+int reid_frame_cost(reid_ctx* ctx, int slot, reid_bank* bank, const int32_t* slots, int t, int metric, float max_dist,
+                    const double* tracks_t4, const double* dets_m4, int want_emb);
+int reid_frame_fetch(reid_ctx* ctx, int slot, float* emb, float* cost_tm, double* iou_tm);
+int reid_frame_update(reid_ctx* ctx, int slot, reid_bank* bank, const int32_t* rows, const int32_t* slots, int n);
 /* retrieval evaluation, reid/evaluate.py:33-105: for every query the ranks of its good gallery items among
  * non-junk items (descending similarity gf@q).  cmc_sum int32[ng] = sum over valid queries of the CMC step,
  * ap double[nq], valid int32[nq] (0 when the query has no good item). */

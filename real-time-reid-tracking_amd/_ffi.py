@@ -71,6 +71,12 @@ _SIGS = {
     "reid_bank_count": (_i, [_vp, _i, C.POINTER(_i)]),
     "reid_bank_cost": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, C.c_float, _vp]),
     "reid_bank_cost_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, C.c_float, _vp]),
+    "reid_host_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "reid_host_free": (_i, [_vp, _vp]),
+    "reid_frame_submit": (_i, [_vp, _i, _vp, _vp, _vp, _i]),
+    "reid_frame_cost": (_i, [_vp, _i, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _i]),
+    "reid_frame_fetch": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "reid_frame_update": (_i, [_vp, _i, _vp, _vp, _vp, _i]),
     "reid_rerank_jaccard": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "reid_rerank_jaccard_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "reid_diou": (_i, [_vp, _vp, _vp, _i, _vp]),

@@ -37,6 +37,9 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     reid_ctx* c = new reid_ctx();
     c->device = device;
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
+    if (const char* e = getenv("REID_F16_SPLITK")) c->f16_split_k = atoi(e);
+    if (const char* e = getenv("REID_BANK_FAST")) c->bank_fast = atoi(e);
+    if (const char* e = getenv("REID_SIDE_COPY")) c->side_copy = atoi(e);
     if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
     if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
@@ -58,7 +61,12 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     comm_release(ctx);
     swin_release(ctx);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->frame_ev[i]) hipEventDestroy(ctx->frame_ev[i]);
+    if (ctx->copy_ev) hipEventDestroy(ctx->copy_ev);
+    if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
     for (auto& kv : ctx->ws) hipFree(kv.second.first);
+    for (auto& kv : ctx->pinned) hipHostFree(kv.second.first);
     if (ctx->se18.blob) hipFree(ctx->se18.blob);
     if (ctx->se18.blob16) hipFree(ctx->se18.blob16);
     if (ctx->se18.stem_w16) hipFree(ctx->se18.stem_w16);
@@ -144,6 +152,49 @@ int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out) {
     }
     ctx->ws[name] = {p, cap};
     *out = p;
+    return REID_OK;
+}
+
+// grow-only named PINNED host buffer (staging of the frame pipeline: copies from / to it are real asynchronous DMAs, whereas a
+// hipMemcpyAsync on pageable memory blocks the caller until everything queued before it has run)
+int ctx_pinned(reid_ctx* ctx, const char* name, size_t bytes, void** out) {
+    auto it = ctx->pinned.find(name);
+    if (it != ctx->pinned.end() && it->second.second >= bytes) {
+        *out = it->second.first;
+        return REID_OK;
+    }
+    if (it != ctx->pinned.end()) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipHostFree(it->second.first));
+        ctx->pinned.erase(it);
+    }
+    void* p = nullptr;
+    size_t cap = bytes < 4096 ? 4096 : bytes + bytes / 2;
+    hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        reid_set_error("hipHostMalloc(%zu) for staging buffer '%s' failed: %s", cap, name, hipGetErrorString(e));
+        return REID_ERR_NOMEM;
+    }
+    ctx->pinned[name] = {p, cap};
+    *out = p;
+    return REID_OK;
+}
+
+extern "C" int reid_host_alloc(reid_ctx* ctx, size_t bytes, void** out) {
+    ARG_CHECK(ctx && out && bytes > 0);
+    CTX_GUARD(ctx);
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        reid_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return REID_ERR_NOMEM;
+    }
+    return REID_OK;
+}
+
+extern "C" int reid_host_free(reid_ctx* ctx, void* p) {
+    ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
+    if (p) HIP_TRY(hipHostFree(p));
     return REID_OK;
 }
 
@@ -721,6 +772,8 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
     return REID_OK;
 }
 
+// (Replaying a captured hipGraph for small batches was tried: the host saves ~150 us of launch calls per tracking frame, but
+// the device-side replay is slower than plain launches and the frame pipeline already hides the host - 1421 vs 1516 frames/s.)
 static int seres18_run(reid_ctx* ctx, const void* x, bool is_u8, int n, float* d_emb, float* d_logits) {
     // the sibling backbones (CARes18 / EMARes18) exist in the reference's arithmetic only
     return (ctx->precision == 1 && ctx->se18.arch == 0) ? seres18_forward_f16(ctx, x, is_u8, n, d_emb, d_logits)
@@ -815,11 +868,10 @@ extern "C" int reid_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, float* 
     return REID_OK;
 }
 
-extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
-                                    float* emb, float* logits) {
-    ARG_CHECK(ctx && packed && offsets && hw && emb && n >= 0);
-    CTX_GUARD(ctx);
-    if (n == 0) return REID_OK;
+// Enqueue only (no synchronisation): upload of the ragged crops, device-side resize + normalise, forward.  `tag` names the
+// device buffers (the frame pipeline keeps one set per frame slot); offsets / hw must be pinned or outlive the stream's work.
+int embed_ragged_enqueue(reid_ctx* ctx, const char* tag, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
+                         float** d_emb_out, float** d_log_out, bool side_copy) {
     const int nc = ctx->se18.num_class;
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
@@ -828,17 +880,33 @@ extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const 
         if (end > total) total = end;
     }
     uint8_t* d_pk;
-    long long* d_off;
-    int* d_hw;
+    char* d_meta;
     float *d_emb, *d_log = nullptr;
-    REID_TRY(ctx_ws(ctx, "io.in", total, (void**)&d_pk));
-    REID_TRY(ctx_ws(ctx, "io.off", (size_t)n * 8, (void**)&d_off));
-    REID_TRY(ctx_ws(ctx, "io.hw", (size_t)n * 8, (void**)&d_hw));
-    REID_TRY(ctx_ws(ctx, "io.emb", (size_t)n * 512 * 4, (void**)&d_emb));
-    if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
-    HIP_TRY(hipMemcpyAsync(d_pk, packed, total, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_hw, hw, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    const std::string t(tag);
+    REID_TRY(ctx_ws(ctx, (t + ".in").c_str(), total, (void**)&d_pk));
+    REID_TRY(ctx_ws(ctx, (t + ".meta").c_str(), (size_t)n * 16, (void**)&d_meta));
+    long long* d_off = (long long*)d_meta;
+    int* d_hw = (int*)(d_meta + (size_t)n * 8);
+    REID_TRY(ctx_ws(ctx, (t + ".emb").c_str(), (size_t)n * 512 * 4, (void**)&d_emb));
+    if (d_log_out) REID_TRY(ctx_ws(ctx, (t + ".logits").c_str(), (size_t)n * nc * 4 + 16, (void**)&d_log));
+    // side_copy (frame pipeline, pinned sources): the upload runs on a copy stream beside the previous frame's kernels
+    hipStream_t cs = ctx->stream;
+    if (side_copy) {
+        if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        if (!ctx->copy_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming));
+        cs = ctx->copy_stream;
+    }
+    HIP_TRY(hipMemcpyAsync(d_pk, packed, total, hipMemcpyHostToDevice, cs));
+    if ((const char*)hw == (const char*)offsets + (size_t)n * 8) {
+        HIP_TRY(hipMemcpyAsync(d_meta, offsets, (size_t)n * 16, hipMemcpyHostToDevice, cs));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)n * 8, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync(d_hw, hw, (size_t)n * 8, hipMemcpyHostToDevice, cs));
+    }
+    if (side_copy) {
+        HIP_TRY(hipEventRecord(ctx->copy_ev, cs));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->copy_ev, 0));
+    }
     const size_t img = (size_t)IMG_H * IMG_W * 3;
     for (int i = 0; i < n; i += ctx->chunk) {
         const int m = n - i < ctx->chunk ? n - i : ctx->chunk;
@@ -847,6 +915,19 @@ extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const 
         REID_TRY(launch_resize_norm(ctx, d_pk, d_off + i, d_hw + 2 * i, m, IMG_H, IMG_W, 0, nhwc));
         REID_TRY(seres18_run(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_log ? d_log + (size_t)i * nc : nullptr));
     }
+    *d_emb_out = d_emb;
+    if (d_log_out) *d_log_out = d_log;
+    return REID_OK;
+}
+
+extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
+                                    float* emb, float* logits) {
+    ARG_CHECK(ctx && packed && offsets && hw && emb && n >= 0);
+    CTX_GUARD(ctx);
+    if (n == 0) return REID_OK;
+    const int nc = ctx->se18.num_class;
+    float *d_emb, *d_log = nullptr;
+    REID_TRY(embed_ragged_enqueue(ctx, "io", packed, offsets, hw, n, &d_emb, logits ? &d_log : nullptr, false));
     HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

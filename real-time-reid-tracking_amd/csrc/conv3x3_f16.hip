@@ -95,12 +95,17 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
 
     const int nnt = p.N / BN;
     const int nwg = gridDim.x;
-    int mtile, ntile;
+    // Split-K (few output tiles - a tracking frame): SK blocks share one output tile, each summing Cin / SK of the input
+    // channels; the one that finishes last adds the fp32 partials in split order (deterministic) and runs the epilogue.
+    const int SK = p.split_k > 1 ? p.split_k : 1;
+    int mtile, ntile, tile_id, ksplit;
     {   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD)
         const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-        mtile = L / nnt;
-        ntile = L - mtile * nnt;
+        tile_id = L / SK;
+        ksplit = L - tile_id * SK;
+        mtile = tile_id / nnt;
+        ntile = tile_id - mtile * nnt;
     }
     const int n_blk = ntile * BN;
     // block -> (first image, first row): M rows [256*mtile, +256) in natural (image, y, x) order
@@ -137,8 +142,10 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         const f16* src = ok ? p.A + (((long long)gi * p.H + gy) * p.W + gx) * p.Cin + chunk * 64 + c * 8 : p.zero_page;
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(halo + buf * HALO_BYTES + q * 1024), 16, 0, 0);
     };
-    auto issue_b_piece = [&](int t, int slot, int j) {   // tile t = (chunk, tap): weights [Cout][(tap, channel)]
-        const int chunk = t / 9, tap = t - chunk * 9;
+    const int nchunk = p.Cin / 64 / SK;               // chunks this block sums: [chunk0, chunk0 + nchunk)
+    const int chunk0 = ksplit * nchunk;
+    auto issue_b_piece = [&](int t, int slot, int j) {   // tile t = (chunk - chunk0, tap): weights [Cout][(tap, channel)]
+        const int chunk = chunk0 + t / 9, tap = t - (t / 9) * 9;
         const int k0 = tap * p.Cin + chunk * 64;
         __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0 + b_chunk[j] * 8),
                                          LPTR(ring + slot * B_BYTES + (wave * BJ + j) * 1024), 16, 0, 0);
@@ -156,8 +163,8 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    const int nchunk = p.Cin / 64;
     const int nt = nchunk * 9;
+    const int chunk_end = chunk0 + nchunk;
     const int b_row_off = (wn * (BN / 2) + li) * 128;
     const int b_swz = (li >> 1) & 7;
 
@@ -192,11 +199,11 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         // prologue: halo of chunk 0, weight tiles 0 and 1
 #pragma unroll
         for (int k = 0; k < HPW; ++k)
-            if (wave + 8 * k < NPI) issue_halo_piece(wave + 8 * k, 0, 0);
+            if (wave + 8 * k < NPI) issue_halo_piece(wave + 8 * k, chunk0, chunk0 & 1);
         issue_b(0, 0);
         if (nt > 1) issue_b(1, 1);
         int prev_b = nt > 1 ? 1 : 0, prev_h = 0;   // what the previous iteration issued (for the counted wait)
-        int slot_c = 0, slot_i = 2, chunk = 0, tap = 0;
+        int slot_c = 0, slot_i = 2, chunk = chunk0, tap = 0;
         for (int t = 0; t < nt; ++t) {
             // everything except what was issued in the previous iteration has landed after this wait
             if (prev_b && prev_h) WAIT_VMCNT(BJ + 1);
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
             prev_b = 0;
             prev_h = 0;
             if (t + 2 < nt) { issue_b(t + 2, slot_i); prev_b = 1; }
-            if (tap < HPW && chunk + 1 < nchunk && wave + 8 * tap < NPI) { issue_halo_piece(wave + 8 * tap, chunk + 1, (chunk + 1) & 1); prev_h = 1; }
+            if (tap < HPW && chunk + 1 < chunk_end && wave + 8 * tap < NPI) { issue_halo_piece(wave + 8 * tap, chunk + 1, (chunk + 1) & 1); prev_h = 1; }
             compute_tile(chunk, tap, slot_c);
             slot_c = slot_c == 2 ? 0 : slot_c + 1;
             slot_i = slot_i == 2 ? 0 : slot_i + 1;
@@ -218,11 +225,11 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         // no longer sit in the instruction stream of the MFMA waves), waves 0..7 only read LDS and issue MFMAs.  One block
         // barrier per tile: a loader arrives once its pieces of the NEXT tile have landed, a compute wave once it has
         // finished the current tile, so after barrier t tile t is complete in LDS and the slot of tile t-1 is free.
-        int slot_c = 0, slot_i = 2, chunk = 0, tap = 0;
+        int slot_c = 0, slot_i = 2, chunk = chunk0, tap = 0;
         if (is_loader) {
             const int lw = wave - 8;
             auto loader_b = [&](int t, int slot) {   // this loader's BPL pieces of weight tile t
-                const int ck = t / 9, tp = t - ck * 9;
+                const int ck = chunk0 + t / 9, tp = t - (t / 9) * 9;
                 const int k0 = tp * p.Cin + ck * 64;
 #pragma unroll
                 for (int j = 0; j < BPL; ++j) {
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
                                                      LPTR(ring + slot * B_BYTES + inst * 1024), 16, 0, 0);
                 }
             };
-            for (int q = lw; q < NPI; q += NLW) issue_halo_piece(q, 0, 0);
+            for (int q = lw; q < NPI; q += NLW) issue_halo_piece(q, chunk0, chunk0 & 1);
             loader_b(0, 0);
             if (nt > 1) loader_b(1, 1);
             int last = nt > 1 ? BPL : 0;   // pieces in the most recently issued group
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
                 RAW_BARRIER();
                 last = 0;
                 if (t + 2 < nt) { loader_b(t + 2, slot_i); last += BPL; }
-                if (tap < 8 && chunk + 1 < nchunk) {   // halo of the next chunk: six pieces per tap over taps 0..7
+                if (tap < 8 && chunk + 1 < chunk_end) {   // halo of the next chunk: six pieces per tap over taps 0..7
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int q = tap * 6 + lw + 4 * k;
@@ -279,6 +286,49 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         }
     }
     __syncthreads();
+
+    if (SK > 1) {
+        // partial tile in register order [TM*TN*16][512 lanes]: coalesced both ways
+        constexpr int PART = 256 * BN;
+        float* part = p.splitk_ws + (long long)tile_id * SK * PART;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __hip_atomic_store(part + (long long)ksplit * PART + ((a * TN + b) * 16 + e) * 512 + tid, acc[a][b][e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        // Device-scope (sc1) stores are written through to the point all XCDs share and the loads below bypass this XCD's L2: no
+        // L2 write-back / invalidate fence is needed (a __threadfence() pair here flushed the whole L2 240 times per launch and
+        // tripled the kernel's duration).  The stores have been acknowledged once vmcnt reaches 0.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)lds;
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = old == SK - 1;
+            if (old == SK - 1) __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived: ready for the next launch
+        }
+        __syncthreads();
+        if (!*flag) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        for (int sidx = 0; sidx < SK; ++sidx)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        acc[a][b][e] += __hip_atomic_load(part + (long long)sidx * PART + ((a * TN + b) * 16 + e) * 512 + tid, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();   // the flag word is about to be overwritten by the residual tile
+    }
 
     // ------------------------------------------------------------------ epilogue (fp32 math, f16 stores)
     const int ldc = (int)p.ldc;
@@ -393,14 +443,29 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
 }
 
 template <int TW, int IMGS, int LW>
-int launch_geom(reid_ctx* ctx, const Gemm16Params& p) {
+int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
+    Gemm16Params p = p0;
     const int nmt = (p.M + 255) / 256;
     const int threads = LW ? 768 : 512;
     // few M tiles (a tracking frame): 64-wide N tiles put twice as many blocks on the chip
     if (p.N % 128 == 0 && (long long)nmt * (p.N / 128) >= 128) {
         hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW>), dim3(nmt * (p.N / 128)), dim3(threads), 0, ctx->stream, p);
     } else {
-        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64, LW>), dim3(nmt * (p.N / 64)), dim3(threads), 0, ctx->stream, p);
+        // ... and when even those leave CUs idle, split the input channels over 2 or 4 blocks per tile (the K loop is
+        // latency-bound at ~0.65 us per (chunk, tap) tile, so its length is what a small launch costs)
+        const int tiles = nmt * (p.N / 64), nchunk = p.Cin / 64;
+        int sk = 1;
+        if (ctx->f16_split_k) while (sk < 4 && tiles * sk * 2 <= 256 && nchunk % (sk * 2) == 0) sk *= 2;
+        if (sk > 1) {
+            float* ws;
+            int* cnt;
+            bool fresh = ctx->ws.find("conv16.splitk_cnt") == ctx->ws.end();
+            REID_TRY(ctx_ws(ctx, "conv16.splitk_ws", (size_t)tiles * sk * 256 * 64 * sizeof(float), (void**)&ws));
+            REID_TRY(ctx_ws(ctx, "conv16.splitk_cnt", 256 * sizeof(int), (void**)&cnt));
+            if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, 256 * sizeof(int), ctx->stream));
+            p.split_k = sk; p.splitk_ws = ws; p.splitk_cnt = cnt;
+        }
+        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64, LW>), dim3(tiles * sk), dim3(threads), 0, ctx->stream, p);
     }
     LAUNCH_CHECK();
     return REID_OK;

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void se_tail_f16_kernel(const float* __restric
                                                           const float* __restrict__ w1, const float* __restrict__ w2t,
                                                           const f16* __restrict__ y, const f16* __restrict__ sc,
                                                           int rows, f16* __restrict__ out) {
-    __shared__ float pooled[512];
+    __shared__ __attribute__((aligned(16))) float pooled[512];
     __shared__ float hid[64];
     __shared__ float gate[512];
     const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // grid (slices, images)
@@ -277,15 +277,37 @@ __global__ __launch_bounds__(256) void se_tail_f16_kernel(const float* __restric
         pooled[ch] = (float)(acc / hw);
     }
     __syncthreads();
-    for (int m = wave; m < mid; m += 4) {
-        float acc = 0.f;
-        for (int ch = lane; ch < c; ch += 64) acc += w1[m * c + ch] * pooled[ch];
-        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) hid[m] = fmaxf(acc, 0.f);
+    {   // hidden units: wave w owns m = w, w + 4, ...; every load of the wave is issued before the first reduction
+        // (one dependent load-reduce round per unit made this phase 10 us at c = 512, longer than the streaming)
+        const int c4n = c >> 2;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc[j] = 0.f;
+            const int m = wave + 4 * j;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c4 = lane + 64 * k;
+                if (m < mid && c4 < c4n) {
+                    const float4 wv = *(const float4*)(w1 + (long long)m * c + c4 * 4);
+                    const float4 pv = *(const float4*)(pooled + c4 * 4);
+                    acc[j] += wv.x * pv.x + wv.y * pv.y + wv.z * pv.z + wv.w * pv.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (wave + 4 * j < mid) {   // wave-uniform
+                float v = acc[j];
+                for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == 0) hid[wave + 4 * j] = fmaxf(v, 0.f);
+            }
+        }
     }
     __syncthreads();
     for (int ch = tid; ch < c; ch += 256) {
         float acc = 0.f;
+#pragma unroll 8
         for (int m = 0; m < mid; ++m) acc += w2t[m * c + ch] * hid[m];
         gate[ch] = 1.0f / (1.0f + expf(-acc));
     }

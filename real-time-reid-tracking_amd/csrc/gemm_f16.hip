@@ -472,7 +472,8 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
         const long long mt = (p.M + 255) / 256;
         const bool k64 = p.K % 64 == 0 && (AMODE != A16_IM2COL || p.Cin % 64 == 0);
         // (the linear-epilogue build of the 256-wide tile spills 98 VGPRs: those launches take the 128-wide one)
-        const int bn = !p.lin && p.N % 256 == 0 && mt * (p.N / 256) >= 192 ? 256 : (p.N % 128 == 0 ? 128 : 64);
+        int bn = !p.lin && p.N % 256 == 0 && mt * (p.N / 256) >= 192 ? 256 : (p.N % 128 == 0 ? 128 : 64);
+        if (bn == 128 && p.N > 128 && mt * (p.N / 128) < 128) bn = 64;   // a tracking frame: twice the blocks on a half-empty chip
         if (!k64) cfg = bn * 1000 + 320 + (bn == 256 ? 4 : 3);
         else if (bn == 128 && p.N == 128) cfg = 128323;
         // Swin's linears have short K loops (K = 96 .. 768, fc2 up to 3072): with BK = 32 and three stages a block needs 72 KB of

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <string>
 #include <map>
+#include <tuple>
 #include <vector>
 #include "../../include/reid_hip.h"
 struct reid_ctx;
@@ -106,6 +107,10 @@ struct Gemm16Params {
     int scat_h, scat_w, scat_py, scat_px;   // > 0: output row (img, j, i) -> (img, 2j+py, 2i+px) of a 2x upsampled map
     float* C32;
     const float* res32;
+    // conv3x3_f16.hip split-K (small launches): blocks per output tile, fp32 partial tiles, per-tile arrival counters
+    int split_k;
+    float* splitk_ws;
+    int* splitk_cnt;
 };
 
 struct reid_ctx;
@@ -227,6 +232,8 @@ struct reid_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // growable device workspaces, keyed by name
     std::map<std::string, std::pair<void*, size_t>> ws;
+    std::map<std::string, std::pair<void*, size_t>> pinned;   // pinned host staging buffers (ctx_pinned)
+    int bank_fast = 1;                    // d = 512 feature-bank cost on the register-tiled kernel (REID_BANK_FAST=0: generic kernel)
     Se18Weights se18;
     int last_n = 0;  // crops in the last embed chunk (for reid_debug_stage)
     int swin_last_n = 0, swin_last_tok = 0;   // images / stage-1 tokens per image of the last Swin pass (reid_debug_swin_stage)
@@ -243,7 +250,16 @@ struct reid_ctx {
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
     int swin_attn_mfma = 1;  // Swin window attention (REID_SWIN_ATTN): 1 = matrix cores in fp16-storage mode, VALU kernel in exact fp32
                              // (v_mfma_f32_32x32x2_f32 runs at the fp32 VALU rate: no gain); 2 = matrix cores in both; 0 = VALU in both
+    int f16_split_k = 1;     // LDS-halo kernel: split the input channels over 2-4 blocks per tile when a launch has < 128 tiles (REID_F16_SPLITK)
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
+    int frame_m[2] = {0, 0};                        // frame pipeline (bank.hip): detections / device embeddings per frame slot
+    float* frame_emb[2] = {nullptr, nullptr};
+    int frame_pending[2] = {0, 0}, frame_t[2] = {0, 0}, frame_has[2] = {0, 0};
+    hipEvent_t frame_ev[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;   // uploads of the frame pipeline (beside the kernels of the previous frame)
+    hipEvent_t copy_ev = nullptr;
+    int side_copy = 1;                   // REID_SIDE_COPY=0: uploads in the compute stream
+    const char* frame_out[2] = {nullptr, nullptr};
     float* stage_ptr[11] = {nullptr};
     unsigned long long* conv_diag = nullptr;   // experiments (debug.hip): stamps of the loader-wave conv kernel
 };
@@ -275,6 +291,9 @@ struct DeviceGuard {
 
 void swin_release(reid_ctx* ctx);   // frees the Swin weights held for this context (swin.hip)
 int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out);  // grow-only named workspace
+int ctx_pinned(reid_ctx* ctx, const char* name, size_t bytes, void** out);   // grow-only named pinned host buffer
+int embed_ragged_enqueue(reid_ctx* ctx, const char* tag, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
+                         float** d_emb_out, float** d_log_out, bool side_copy);   // api.hip: upload + resize + forward, no synchronisation
 void prof_begin(reid_ctx* ctx, int kind, double flops, double bytes);
 void prof_end(reid_ctx* ctx);
 

@@ -35,6 +35,10 @@ class Engine:
 
     def close(self):
         if self.h:
+            self.lib.reid_ctx_sync(self.h)
+            for p in getattr(self, "_pinned", []):
+                self.lib.reid_host_free(self.h, p)
+            self._pinned = []
             self.lib.reid_ctx_destroy(self.h)
             self.h = None
 
@@ -173,6 +177,72 @@ class Engine:
         emb, lg = self._outs(n, logits)
         check(self.lib.reid_embed_ragged_u8(self.h, _ptr(packed), _ptr(offs), _ptr(hw), n, _ptr(emb), _ptr(lg)))
         return (emb, lg) if logits else emb
+
+    # ---- frame pipeline (csrc/bank.hip): submit (asynchronous) / cost (the frame's one synchronisation) / update (asynchronous)
+    def pinned(self, nbytes):
+        """uint8 numpy array over pinned host memory (freed with the engine)."""
+        p = C.c_void_p()
+        check(self.lib.reid_host_alloc(self.h, int(nbytes), C.byref(p)))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(nbytes),))
+
+    def frame_submit(self, slot, crops):
+        """Stage 1: pack the ragged uint8 crops into the slot's pinned slab, enqueue upload + resize + forward; returns at once."""
+        n = len(crops)
+        hw = np.empty((n, 2), np.int32)
+        offs = np.empty(n, np.int64)
+        total = 0
+        for i, c in enumerate(crops):
+            if c.ndim != 3 or c.shape[2] != 3 or c.shape[0] < 1 or c.shape[1] < 1 or c.dtype != np.uint8:
+                raise ValueError("crop %d must be uint8[h,w,3], got %s %s" % (i, c.dtype, c.shape))
+            hw[i] = c.shape[:2]
+            offs[i] = total
+            total += c.size
+        slabs = self.__dict__.setdefault("_slabs", {})
+        slab = slabs.get(slot)
+        if slab is None or slab.size < total:
+            self.sync()          # the old slab may still be the source of an upload
+            slab = slabs[slot] = self.pinned(max(2 * total, 1 << 22))
+        for i, c in enumerate(crops):   # straight into pinned memory: the only host copy of the pixels
+            slab[offs[i]: offs[i] + c.size].reshape(c.shape)[...] = c
+        check(self.lib.reid_frame_submit(self.h, int(slot), _ptr(slab), _ptr(offs), _ptr(hw), n))
+        self.__dict__.setdefault("_frame_n", {})[slot] = n
+        return n
+
+    def frame_cost(self, slot, bank=None, slots=None, metric=0, max_dist=-1.0, track_boxes=None, det_boxes=None, want_emb=True):
+        """Stage 2 (asynchronous): enqueue the appearance cost / DIoU cost of the submitted frame; `frame_fetch` collects."""
+        m = self._frame_n[slot]
+        t = 0 if slots is None else len(slots)
+        tb = db = None
+        if track_boxes is not None and det_boxes is not None:
+            tb = np.ascontiguousarray(track_boxes, np.float64).reshape(-1, 4)
+            db = np.ascontiguousarray(det_boxes, np.float64).reshape(-1, 4)
+            if db.shape[0] != m:
+                raise ValueError("det_boxes has %d rows for %d submitted crops" % (db.shape[0], m))
+            if slots is not None and tb.shape[0] != t:
+                raise ValueError("track_boxes has %d rows for %d tracks" % (tb.shape[0], t))
+            t = tb.shape[0]
+        sl = None if slots is None else np.ascontiguousarray(slots, np.int32)
+        check(self.lib.reid_frame_cost(self.h, int(slot), bank if sl is not None else None, _ptr(sl), t, int(metric),
+                                       C.c_float(max_dist), _ptr(tb), _ptr(db), 1 if want_emb else 0))
+        self.__dict__.setdefault("_frame_q", {})[slot] = (m, t, want_emb, bank is not None and sl is not None and t and m,
+                                                          tb is not None and t and m)
+
+    def frame_fetch(self, slot):
+        """The frame's one wait: (emb[m,512] | None, cost[t,m] float32 | None, iou_cost[t,m] float64 | None)."""
+        m, t, want_emb, has_cost, has_iou = self._frame_q.pop(slot)
+        emb = np.empty((m, 512), np.float32) if want_emb else None
+        cost = np.empty((t, m), np.float32) if has_cost else None
+        iou = np.empty((t, m), np.float64) if has_iou else None
+        check(self.lib.reid_frame_fetch(self.h, int(slot), _ptr(emb) if m else None, _ptr(cost), _ptr(iou)))
+        return emb, cost, iou
+
+    def frame_update(self, slot, bank, rows, slots):
+        """Stage 3: partial_fit from the slot's device-resident embeddings (row rows[i] -> track slot slots[i]); asynchronous."""
+        rows = np.ascontiguousarray(rows, np.int32)
+        slots = np.ascontiguousarray(slots, np.int32)
+        check(self.lib.reid_frame_update(self.h, int(slot), bank, _ptr(rows), _ptr(slots), len(rows)))
 
     def embed_frame_u8(self, frame, boxes_xyxy, logits=False):
         """uint8[H,W,3] frame + int boxes [n,4] (x1,y1,x2,y2; crop = frame[y1:y2, x1:x2]) -> float32[n,512]."""

@@ -13,7 +13,7 @@ from .engine import get_engine
 
 
 class NearestNeighborDistanceMetric:
-    def __init__(self, metric, matching_threshold, budget=None, max_tracks=4096, device=0):
+    def __init__(self, metric, matching_threshold, budget=None, max_tracks=4096, device=0, engine=None):
         if metric == "euclidean":
             self._metric = _ffi.METRIC_L2SQR
         elif metric == "cosine":
@@ -25,7 +25,7 @@ class NearestNeighborDistanceMetric:
         # the reference keeps every sample when budget is None; the device ring needs a bound (oldest fall out past it)
         self._ring = int(budget) if budget is not None else 1024
         self._max_tracks = int(max_tracks)
-        self._eng = get_engine(device)
+        self._eng = engine if engine is not None else get_engine(device)   # engine: a camera stream's own context
         self._bank = None
         self._slot = {}            # target id -> slot
         self._free = list(range(self._max_tracks - 1, -1, -1))
@@ -93,3 +93,51 @@ class NearestNeighborDistanceMetric:
                                                C.c_float(-1.0 if max_distance is None else max_distance),
                                                out.ctypes.data_as(C.c_void_p)))
         return out.astype(np.float64)
+
+    # ------------------------------------------------------------------ frame pipeline (engine.frame_submit / _cost / _update)
+    def _slots_for(self, targets, create):
+        slots = np.empty(len(targets), np.int32)
+        for i, t in enumerate(targets):
+            if t not in self._slot:
+                if not create:
+                    raise KeyError(t)
+                if not self._free:
+                    raise RuntimeError(f"feature bank is full ({self._max_tracks} tracks); raise max_tracks")
+                self._slot[t] = self._free.pop()
+            slots[i] = self._slot[t]
+        return slots
+
+    def frame_distance_begin(self, slot, targets, max_distance=None, track_boxes=None, det_boxes=None):
+        """Enqueue `distance` (and, given tlwh boxes, iou_matching.iou_cost) for the frame submitted with
+        `engine.frame_submit(slot, crops)`, whose embeddings never leave the device in between.  Asynchronous: submit the
+        next frame, then collect with `frame_distance_end`."""
+        targets = list(targets)
+        self._ensure(512)
+        slots = self._slots_for(targets, False) if targets else None
+        self._eng.frame_cost(slot, self._bank, slots, self._metric, -1.0 if max_distance is None else max_distance,
+                             track_boxes, det_boxes)
+        self._pending_targets = len(targets)
+
+    def frame_distance_end(self, slot):
+        """(features[m,512], cost[len(targets),m], iou_cost | None) of `frame_distance_begin`: the frame's one wait."""
+        emb, cost, iou = self._eng.frame_fetch(slot)
+        if cost is None:
+            cost = np.zeros((self._pending_targets, emb.shape[0]), np.float32)
+        return emb, cost.astype(np.float64), iou
+
+    def frame_distance(self, slot, targets, max_distance=None, track_boxes=None, det_boxes=None):
+        self.frame_distance_begin(slot, targets, max_distance, track_boxes, det_boxes)
+        return self.frame_distance_end(slot)
+
+    def frame_partial_fit(self, slot, rows, targets, active_targets):
+        """`partial_fit` with features = rows `rows` of the submitted frame's embeddings (asynchronous)."""
+        targets = list(targets)
+        if len(targets):
+            self._ensure(512)
+            self._eng.frame_update(slot, self._bank, rows, self._slots_for(targets, True))
+        active = set(active_targets)
+        gone = [t for t in self._slot if t not in active]
+        if gone:
+            slots = np.asarray([self._slot.pop(t) for t in gone], np.int32)
+            check(self._eng.lib.reid_bank_clear(self._eng.h, self._bank, slots.ctypes.data_as(C.c_void_p), len(gone)))
+            self._free.extend(int(s) for s in slots)

@@ -1,0 +1,52 @@
+"""Per-frame driver of the appearance path of one camera stream.
+
+What it stands in for: `DeepSort.update` ([external] deep_sort.py, built by `build_tracker` from
+modification_deepsort/deep_sort.yaml) calls, every frame, `Extractor.__call__` on the detections' crops
+(modification_deepsort/feature_extractor.py:48-53), then `Tracker.update`, whose matching cascade asks
+`NearestNeighborDistanceMetric.distance` and `iou_matching.iou_cost` for cost matrices and finally feeds the matched
+features back with `partial_fit`.  Each of those is a blocking host call in the reference.  Here the four stages of
+csrc/bank.hip (`reid_frame_submit / _cost / _fetch / _update`) are queued on the camera's HIP stream so that the device
+embeds frame f+1 while the host still assigns frame f; the Kalman filter and the Hungarian assignment stay with the caller
+(`assign`), they are not part of this path.
+
+One `CameraStream` = one engine context (own stream, workspaces, feature bank).  A tracking frame leaves most CUs idle in
+most of its launches, so several camera streams driven from several host threads overlap on one GPU.
+"""
+import numpy as np
+
+from .engine import Engine, get_engine
+from .nn_matching import NearestNeighborDistanceMetric
+
+
+class CameraStream:
+    def __init__(self, weights_blob, manifest, precision=0, max_dist=0.15, budget=100, metric="cosine", device=0, own_context=True,
+                 max_tracks=4096):
+        self.eng = Engine(device) if own_context else get_engine(device)
+        self.eng.load_seres18(weights_blob, manifest)
+        self.eng.set_precision(precision)
+        self.max_dist = max_dist
+        self.metric = NearestNeighborDistanceMetric(metric, max_dist, budget, max_tracks=max_tracks, engine=self.eng)
+        self._frame = 0
+
+    def submit(self, crops):
+        """Queue upload + embedding of the FIRST frame's crops (returns at once); later frames ride on `step(next_crops=...)`."""
+        self.eng.frame_submit(self._frame & 1, crops)
+
+    def step(self, targets, track_boxes, det_boxes, next_crops=None):
+        """Costs of the submitted frame against the confirmed tracks `targets` (tlwh boxes for the DIoU cost), with the next
+        frame's crops submitted in between so that the device works under the host's assignment.  Returns
+        (features[m,512], appearance_cost[t,m] gated at max_dist, iou_cost[t,m] | None)."""
+        slot = self._frame & 1
+        self.metric.frame_distance_begin(slot, targets, self.max_dist, track_boxes, det_boxes)
+        if next_crops is not None:
+            self.eng.frame_submit(slot ^ 1, next_crops)
+        return self.metric.frame_distance_end(slot)
+
+    def commit(self, rows, targets, active_targets):
+        """partial_fit: detection row rows[i] of the frame just stepped becomes a sample of track targets[i]; tracks missing
+        from active_targets are forgotten.  Asynchronous.  Moves on to the next frame."""
+        self.metric.frame_partial_fit(self._frame & 1, np.ascontiguousarray(rows, np.int32), targets, active_targets)
+        self._frame += 1
+
+    def close(self):
+        self.eng.sync()

@@ -414,6 +414,61 @@ def test_nn_matching_bank_follows_oracle_over_a_stream(eng, metric):
         np.testing.assert_allclose(gated[near], want[near], rtol=1e-5, atol=tol)
 
 
+def test_frame_pipeline_matches_the_synchronous_calls_and_the_oracle(eng_w0):
+    """reid_frame_submit / _cost / _fetch / _update (one wait per frame, frame f+1 submitted before frame f is matched)
+    give what Extractor.__call__ + metric.distance + iou_cost + metric.partial_fit give call by call, and what the oracle says."""
+    from oracle import nn_matching as onm
+    from reid_amd.iou_matching import iou_cost
+    from reid_amd.nn_matching import NearestNeighborDistanceMetric
+    eng, sd = eng_w0
+    rng = np.random.default_rng(11)
+    pool = synth.ragged_crops_u8(24, seed=4)
+    pipe = NearestNeighborDistanceMetric("cosine", 0.15, 5, max_tracks=16)
+    sync = NearestNeighborDistanceMetric("cosine", 0.15, 5, max_tracks=16)
+    ref = onm.NearestNeighborDistanceMetric("cosine", 0.15, 5)
+    frames = [[pool[(3 * f + i) % 24] for i in range(n)] for f, n in enumerate([5, 7, 0, 3, 9, 6])]
+    boxes = rng.uniform(0, 300, (16, 4))
+    boxes[:, 2:] = rng.uniform(10, 90, (16, 2))
+    tracks = []
+    eng.frame_submit(0, frames[0])
+    for f, crops in enumerate(frames):
+        slot = f & 1
+        m = len(crops)
+        pipe.frame_distance_begin(slot, tracks, max_distance=0.15, track_boxes=boxes[:len(tracks)], det_boxes=boxes[:m])
+        if f + 1 < len(frames):
+            eng.frame_submit(slot ^ 1, frames[f + 1])              # next frame goes up while this one is "matched"
+        feats, cost, ic = pipe.frame_distance_end(slot)
+        want_feats = eng.embed_ragged_u8(crops)
+        np.testing.assert_array_equal(feats, want_feats)
+        assert cost.shape == (len(tracks), m)
+        if tracks and m:
+            np.testing.assert_array_equal(cost, sync.distance(want_feats, tracks, max_distance=0.15))
+            np.testing.assert_array_equal(ic, iou_cost(boxes[:len(tracks)], boxes[:m]))
+            raw = ref.distance(want_feats, tracks)
+            near = raw < 0.15 - 1e-5
+            np.testing.assert_allclose(cost[near], raw[near], atol=2e-6)
+            assert np.all(cost[raw > 0.15 + 1e-5] == np.float32(0.15) + np.float32(1e-5))
+        else:
+            assert ic is None
+        # detection i updates track i; a new track per frame, the oldest dropped when more than 6 are alive
+        k = min(m, len(tracks))
+        rows, tg = list(range(k)), tracks[:k]
+        if m > k:
+            tracks.append(100 + f)
+            rows.append(k)
+            tg = tg + [100 + f]
+        if len(tracks) > 6:
+            tracks.pop(0)
+        pipe.frame_partial_fit(slot, rows, tg, tracks)
+        sync.partial_fit(want_feats[rows], tg, tracks)
+        ref.partial_fit(list(want_feats[rows]), tg, tracks)
+        for t in tracks:
+            if t in ref.samples:
+                assert pipe.samples_count(t) == len(ref.samples[t])
+    with pytest.raises(_ffi.ReidHipError):
+        eng.frame_update(0, pipe._bank, [99], [0])                 # row beyond the submitted frame
+
+
 def test_nn_matching_edge_cases(eng):
     from reid_amd.nn_matching import NearestNeighborDistanceMetric
     m = NearestNeighborDistanceMetric("cosine", 0.15, budget=3, max_tracks=2)
