@@ -119,7 +119,9 @@ class Job:
         torch.cuda.set_stream(self.stream)
         self.eng.set_stream(self.stream.cuda_stream)
         # RCCL communicator behind the C ABI (reid_comm_init); REID_BENCH_COMM1=1: a real 1-rank communicator on one GPU
-        self.comm = parallel.RcclComm.from_env(self.eng, single_rank_communicator=os.environ.get("REID_BENCH_COMM1") == "1")
+        self.comm = parallel.comm_from_env(self.eng, single_rank_communicator=os.environ.get("REID_BENCH_COMM1") == "1",
+                                           log=lambda m: print("[bench rank %d] %s" % (self.rank, m), file=sys.stderr, flush=True))
+        self.transport = type(self.comm).__name__
 
     def barrier(self):
         self.comm.barrier()                  # RCCL all-reduce of one double + stream sync (local sync when world == 1)
@@ -253,7 +255,9 @@ def run_embed(job, args):
                    "crops_per_gpu": n, "embed_dim": d, "chunk": args.chunk,
                    "arithmetic": ("fp16 storage, fp32 accumulate (north_star tolerance 1e-3 cosine; measured below)" if f16
                                   else "exact fp32 (v_mfma_f32_32x32x2_f32), the reference's arithmetic"),
-                   "sharding": ("crops sharded by rank, one RCCL all-gather of [N,512] embeddings through the C ABI (reid_allgather_dev)"
+                   "sharding": ("crops sharded by rank, one RCCL all-gather of [N,512] embeddings "
+                                + ("through the C ABI (reid_allgather_dev)" if job.transport == "RcclComm"
+                                   else "through torch.distributed (C-ABI communicator unavailable on this node)")
                                 if world > 1 else "single GPU")},
         "f16_vs_f32_max_cosine_err": cos_err,
     }

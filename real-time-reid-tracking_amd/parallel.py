@@ -8,7 +8,8 @@ The path shards with exactly one exchange step:
     faiss.IndexShards pattern (reid/faiss_utils.py:121-135): every rank searches its shard for all queries
     and the per-shard (distance, index) lists are merged k-way.
 
-Two transports behind the same orchestration:
+Transports behind the same orchestration (plus ``TorchComm``, a stand-by with RcclComm's interface over torch.distributed's
+nccl backend that bench.py falls back to if the C-ABI communicator cannot be brought up on a node):
   * ``RcclComm`` - the product path: collectives inside the C ABI (reid_comm_* / reid_allgather_* /
     reid_knn_gallery_sharded_dev, csrc/comm.hip, librccl over xGMI).  Everything stays in HBM: the local shard is embedded from a
     device buffer into a device buffer, gathered on the device, the row block / the merged k-NN lists are computed on the
@@ -149,6 +150,92 @@ class RcclComm:
 
     def barrier(self):
         self.all_reduce([0.0], "sum")
+
+
+class _DevBytes:
+    """A raw device range as a __cuda_array_interface__ object (torch.as_tensor wraps it without a copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class TorchComm:
+    """Stand-by transport with RcclComm's collective interface: torch.distributed's nccl backend (RCCL as well) over the same
+    raw device pointers.  bench.py switches to it, on every rank together, only if the communicator behind the C ABI cannot be
+    brought up on a node; reid_knn_gallery_sharded_dev (collective inside the C ABI) is not available through it."""
+
+    def __init__(self, engine, group):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.engine, self.group = torch, dist, engine, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.dev = "cuda:%d" % engine.device
+
+    def _t(self, ptr, nbytes):
+        return self.torch.as_tensor(_DevBytes(ptr, nbytes), device=self.dev)
+
+    def close(self):
+        pass
+
+    def all_gather(self, d_send, d_recv, nbytes):
+        self.dist.all_gather_into_tensor(self._t(d_recv, nbytes * self.world), self._t(d_send, nbytes), group=self.group)
+
+    def all_gather_rows(self, d_local, n_local, row_bytes, d_out):
+        torch = self.torch
+        cnt = torch.tensor([int(n_local)], dtype=torch.int32, device=self.dev)
+        counts = torch.empty(self.world, dtype=torch.int32, device=self.dev)
+        self.dist.all_gather_into_tensor(counts, cnt, group=self.group)
+        counts = [int(c) for c in counts.cpu()]
+        width = max(counts) * int(row_bytes)
+        if width == 0:
+            return counts
+        mine = torch.zeros(width, dtype=torch.uint8, device=self.dev)
+        if n_local:
+            mine[: n_local * row_bytes] = self._t(d_local, n_local * row_bytes)
+        slab = torch.empty(width * self.world, dtype=torch.uint8, device=self.dev)
+        self.dist.all_gather_into_tensor(slab, mine, group=self.group)
+        out = self._t(d_out, sum(counts) * row_bytes)
+        at = 0
+        for r, c in enumerate(counts):
+            out[at: at + c * row_bytes] = slab[r * width: r * width + c * row_bytes]
+            at += c * row_bytes
+        return counts
+
+    def all_reduce(self, values, op="max"):
+        self.engine.sync()
+        t = self.torch.as_tensor(np.atleast_1d(np.asarray(values, np.float64)), device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX, group=self.group)
+        return t.cpu().numpy()
+
+    def barrier(self):
+        self.all_reduce([0.0], "sum")
+
+
+def comm_from_env(engine, single_rank_communicator=False, log=None):
+    """RcclComm.from_env, agreed on by all ranks; if any rank could not bring the C-ABI communicator up, all of them use
+    TorchComm instead (and say so through ``log``)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return RcclComm.from_env(engine, single_rank_communicator)
+    import torch
+    import torch.distributed as dist
+    comm, err = None, ""
+    try:
+        comm = RcclComm.from_env(engine)
+    except Exception as e:     # noqa: BLE001 - whatever the cause, the ranks must agree on the transport
+        err = repr(e)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=world)
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok[0]) == 1:
+        return comm
+    if comm is not None:
+        comm.close()
+    if log:
+        log("C-ABI RCCL communicator unavailable (%s): collectives go through torch.distributed's nccl backend" % (err or "another rank failed"))
+    return TorchComm(engine, dist.new_group(backend="nccl"))
 
 
 class HostComm:

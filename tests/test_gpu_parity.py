@@ -789,6 +789,36 @@ def test_entry_points_from_a_worker_thread(eng_w0):
 
 
 # ----------------------------------------------------------------------------- multi-GPU exchange behind the C ABI (one GPU here)
+def test_standby_transport_moves_raw_device_ranges_through_torch_distributed(eng):
+    """parallel.TorchComm (what bench.py falls back to when the C-ABI communicator cannot be made): torch.distributed's nccl
+    backend on the engine's raw device pointers, one rank."""
+    import socket
+    import torch.distributed as dist
+    from reid_amd import parallel
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        comm = parallel.TorchComm(eng, dist.new_group(backend="nccl"))
+        x = np.random.default_rng(4).normal(size=(19, 512)).astype(np.float32)
+        dx = parallel.DevArray.from_numpy(eng, x)
+        dy = parallel.DevArray(eng, x.shape)
+        comm.all_gather(dx.ptr, dy.ptr, x.nbytes)
+        torch.cuda.synchronize()
+        assert np.array_equal(dy.numpy(), x)
+        dz = parallel.DevArray(eng, x.shape)
+        assert comm.all_gather_rows(dx.ptr, 19, 2048, dz.ptr) == [19]
+        torch.cuda.synchronize()
+        assert np.array_equal(dz.numpy(), x)
+        assert comm.all_reduce([2.5, -4.0], "max").tolist() == [2.5, -4.0]
+        comm.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_rccl_single_rank_communicator_and_device_resident_sharding(eng_w0):
     """The RCCL branch of parallel.py with a REAL 1-rank communicator (ncclCommInitRank with nranks = 1): every collective goes
     through librccl, the sharded entry points stay in HBM, and the results equal the plain single-process calls."""

@@ -130,3 +130,41 @@ def test_rccl_bootstrap_hands_the_same_id_to_every_rank(tmp_path):
     want = np.asarray([(7 * i + 3) % 256 for i in range(128)], np.uint8)
     for r in range(world):
         assert np.array_equal(np.load(os.path.join(str(tmp_path), "id%d.npy" % r)), want)
+
+
+class _FailingLib(_FakeLib):
+    def reid_comm_init(self, h, rank, world, buf):
+        return 1 if rank == 1 else 0          # rank 1 cannot bring its communicator up
+
+
+def _fallback_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.RcclComm.unique_id = staticmethod(lambda: bytes(128))
+    parallel._ffi.check = lambda st: (_ for _ in ()).throw(RuntimeError("comm init failed")) if st else None
+    parallel.check = parallel._ffi.check
+    made = {}
+
+    class _Standby:                            # TorchComm needs a GPU (nccl): record that every rank reaches it with a group
+        def __init__(self, engine, group):
+            made.update(world=dist.get_world_size(group))
+
+    parallel.TorchComm = _Standby
+    new_group = dist.new_group
+    dist.new_group = lambda backend=None: new_group(backend="gloo")
+    eng = _FakeEngine({})
+    eng.lib = _FailingLib({})
+    msgs = []
+    try:
+        comm = parallel.comm_from_env(eng, log=msgs.append)
+        assert isinstance(comm, _Standby) and made["world"] == world and len(msgs) == 1
+        open(os.path.join(tmp, "ok%d" % rank), "w").write(msgs[0])
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_every_rank_takes_the_standby_transport_when_one_communicator_fails(tmp_path):
+    world = 2
+    mp.spawn(_fallback_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    texts = [open(os.path.join(str(tmp_path), "ok%d" % r)).read() for r in range(world)]
+    assert "comm init failed" in texts[1] and "another rank failed" in texts[0]
