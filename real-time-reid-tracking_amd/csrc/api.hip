@@ -40,6 +40,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F16_SPLITK")) c->f16_split_k = atoi(e);
     if (const char* e = getenv("REID_BANK_FAST")) c->bank_fast = atoi(e);
     if (const char* e = getenv("REID_SIDE_COPY")) c->side_copy = atoi(e);
+    if (const char* e = getenv("REID_F32_STEMPOOL")) c->f32_stem_pool = atoi(e);
     if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
     if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
@@ -509,13 +510,18 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
     (void)nt;
 
     // stem: conv7x7 s2 p3 + BN, no ReLU (SERes18_IBN.py:251-253), then MaxPool2d(3,2,1) (:254)
-    if (ctx->f32_conv == 1) {   // stem_f32.hip: weights resident in LDS, A operand read from an fp32 LDS image of the input rows
-        REID_TRY(launch_stem_f32(ctx, x, is_u8, n, w.stem_w, w.stem_scale, w.stem_shift, b.stem));
+    // stem_f32.hip: weights resident in LDS, A operand read from an fp32 LDS image of the input rows; the max-pool runs on its
+    // accumulators unless the conv map itself is wanted (debug stage 0) or REID_F32_STEMPOOL=0
+    const bool pool_fused = ctx->f32_conv == 1 && ctx->f32_stem_pool && !ctx->debug_keep;
+    if (pool_fused) {
+        REID_TRY(launch_stem_f32(ctx, x, is_u8, n, w.stem_w, w.stem_scale, w.stem_shift, b.pool, true));
+    } else if (ctx->f32_conv == 1) {
+        REID_TRY(launch_stem_f32(ctx, x, is_u8, n, w.stem_w, w.stem_scale, w.stem_shift, b.stem, false));
     } else {
         REID_TRY(conv_gemm(ctx, is_u8 ? A_STEM_U8 : A_STEM_F32, x, n, IMG_H, IMG_W, 3, w.stem_w, 64, 7, 7, 2, 3, 192, nullptr,
                            nullptr, 0, w.stem_scale, w.stem_shift, nullptr, 0, nullptr, b.stem));
     }
-    REID_TRY(launch_maxpool3s2(ctx, b.stem, n, 128, 64, 64, b.pool));
+    if (!pool_fused) REID_TRY(launch_maxpool3s2(ctx, b.stem, n, 128, 64, 64, b.pool));
     b.stage[0] = b.stem;
     b.stage[1] = b.pool;
 

@@ -145,7 +145,7 @@ int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int 
 int launch_ta_tail(reid_ctx* ctx, const float* y, const float* sc, int n_img, int H, int W, int C, const float* wts, float* out);
 int launch_ema_tail(reid_ctx* ctx, const float* y, const float* sc, int n_img, int H, int W, int C, const float* prm, float* out);
 int launch_stem_f32(reid_ctx* ctx, const void* x, bool is_u8, int n, const float* wgt, const float* scale, const float* shift,
-                    float* out);   // stem_f32.hip: 7x7 s2 conv + BN of the fp32 path
+                    float* out, bool pooled);   // stem_f32.hip: 7x7 s2 conv + BN (+ MaxPool(3,2,1) on the accumulators) of the fp32 path
 bool gemm_f32_dma_supported(int amode, int epi, const GemmParams& p);   // gemm_f32_dma.hip: dense GEMM with LDS-DMA staging
 int launch_gemm_f32_dma(reid_ctx* ctx, int epi, const GemmParams& p, int kind, double flops, double bytes);
 bool conv_f32_supported(const GemmParams& p);   // conv_f32.hip: pipelined implicit-GEMM convolution of the fp32 path (full tiles)
@@ -248,6 +248,7 @@ struct reid_ctx {
                              // (REID_F16_STEMPOOL=1: from the padded f16 image, 0: GEMM + pool kernels)
     int f32_conv = 1;        // fp32 path (REID_F32_CONV): 1 = conv_f32.hip LDS-DMA kernel, norms in the producer's epilogue / in_apply;
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
+    int f32_stem_pool = 1;   // fp32 path: MaxPool(3,2,1) on the stem kernel's accumulators (REID_F32_STEMPOOL=0: separate kernel)
     int swin_attn_mfma = 1;  // Swin window attention (REID_SWIN_ATTN): 1 = matrix cores in fp16-storage mode, VALU kernel in exact fp32
                              // (v_mfma_f32_32x32x2_f32 runs at the fp32 VALU rate: no gain); 2 = matrix cores in both; 0 = VALU in both
     int f16_split_k = 1;     // LDS-halo kernel: split the input channels over 2-4 blocks per tile when a launch has < 128 tiles (REID_F16_SPLITK)

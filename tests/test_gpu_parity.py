@@ -106,6 +106,19 @@ def test_seres18_embed_matches_reference_fixture(eng, golden_dir, tag, crops_fn)
     np.testing.assert_allclose(emb_c, emb, rtol=1e-6, atol=1e-6 * np.abs(emb).max())
 
 
+def test_fused_stem_pool_is_the_same_for_whole_images_and_strips(eng_w0):
+    """stem_f32.hip with the max-pool on its accumulators: 520 crops in one pass (a block walks a whole image) and in chunks of
+    40 (eight-tile strips, each recomputing the tile above it) run the same arithmetic per pixel - bit-identical embeddings."""
+    eng, _ = eng_w0
+    crops = synth.smooth_crops_u8(520, seed=8)
+    eng.set_chunk(1024)
+    whole = eng.embed_u8(crops)
+    eng.set_chunk(40)
+    strips = eng.embed_u8(crops)
+    eng.set_chunk(64)
+    assert np.array_equal(whole, strips)
+
+
 def test_embed_ragged_resize_matches_oracle(eng_w0):
     eng, sd = eng_w0
     crops = synth.ragged_crops_u8(6, seed=3) + [synth.crops_u8(1, 9)[0]]
