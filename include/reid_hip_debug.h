@@ -23,6 +23,9 @@ int reid_debug_conv_c64(reid_ctx* ctx, int n, const float* x, const float* w_krs
 /* Times one dense fp16 GEMM C[m][n] = A[m][k] . B[n][k]^T; diag_host: optional [64*8*4] per-wave cycle sums. */
 int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, int iters, float* ms_per_launch,
                         unsigned long long* diag_host);
+/* Times one Swin Linear layer [m][k] x [n][k]^T on random device data: mode bit 0 = fp16-storage GEMM (else exact fp32),
+ * bits 1-2 = epilogue (0 bias, 1 bias + erf-GELU, 2 bias + fp32 residual into the fp32 stream). */
+int reid_debug_linear(reid_ctx* ctx, int m, int n, int k, int mode, int iters, float* ms_per_launch);
 /* Switches the s_memtime stamps of the loader-wave conv kernel on / off (out_host [64*8*5] when disabling). */
 int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long long* out_host);
 /* Bare MFMA loop with fragments re-read from LDS (shape 32 = 32x32x16 f16, 16 = 16x16x32 f16). */

@@ -91,10 +91,45 @@ __device__ __forceinline__ void conv_epilogue(const GemmParams& p, f32x16 (&acc)
 // 405-412): bias, optional residual, optional parity scatter (img, j, i) -> (img, 2j+py, 2i+px); ragged M and N predicated.
 template <int BN>
 __device__ __forceinline__ void bias_epilogue(const GemmParams& p, f32x16 (&acc)[2][BN / 64], int m_blk, int n_blk, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
     constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
+    const int ldc = (int)p.ldc;
+    if (p.scat_h == 0 && 128ll * ldc * 4 < 0x7fffff00ll && p.M - m_blk >= 128) {
+        // as gemm_f32_dma.hip's linear epilogue: buffer stores with the row offset in the SGPR operand (not range-checked: full
+        // tiles only), columns past N dropped by the descriptor - per element one bias add (and one residual add)
+        const int rows = 128;
+        const int recs = (int)(((long long)(rows - 1) * ldc + p.N) * 4);
+        const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long long)m_blk * ldc), 0, recs, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((p.residual ? p.residual : p.C) + (long long)m_blk * ldc), 0, recs, 0x00020000);
+        const bool has_res = p.residual != nullptr;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n_blk + wn * WN + b * 32 + li;
+            const bool colok = col < p.N;
+            const float sh = (colok && p.col_shift) ? p.col_shift[col] : 0.f;
+            const int voff = colok ? ((wm * 64 + 4 * lh) * ldc + col) * 4 : 0x7fffff00;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                float res[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) res[e] = 0.f;
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        res[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff, (a * 32 + (e & 3) + 8 * (e >> 2)) * ldc * 4, 0));
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[a][b][e] + sh + res[e]), c_rs, voff,
+                                                          (a * 32 + (e & 3) + 8 * (e >> 2)) * ldc * 4, 0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int col = n_blk + wn * WN + b * 32 + li;
@@ -121,6 +156,7 @@ __device__ __forceinline__ void bias_epilogue(const GemmParams& p, f32x16 (&acc)
             }
         }
     }
+#endif
 }
 
 __device__ __forceinline__ unsigned long long stamp() {   // diagnostic builds only (cdna_hip_programming.md section 7, in-kernel stamps)

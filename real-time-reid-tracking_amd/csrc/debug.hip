@@ -219,3 +219,56 @@ extern "C" int reid_debug_knn_merge(reid_ctx* ctx, const float* Dall, const int3
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return REID_OK;
 }
+
+// One Swin Linear layer (swin_transformer.py:23-39, 191-232) on random device data: mode bit 0 = fp16-storage GEMM (else exact
+// fp32), bits 1-2 = epilogue: 0 bias, 1 bias + erf-GELU, 2 bias + fp32 residual into the fp32 stream.
+extern "C" int reid_debug_linear(reid_ctx* ctx, int m, int n, int k, int mode, int iters, float* ms_per_launch) {
+    ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded && m > 0 && n > 0 && k > 0);
+    CTX_GUARD(ctx);
+    typedef _Float16 f16;
+    const bool h = mode & 1;
+    const int epi = (mode >> 1) & 3;
+    const int npad = (n + 63) / 64 * 64;
+    float *a32, *b32, *bias, *res, *c32;
+    f16 *a16, *b16, *c16;
+    REID_TRY(ctx_ws(ctx, "dbg.x", (size_t)m * k * 4, (void**)&a32));
+    REID_TRY(ctx_ws(ctx, "dbg.w", (size_t)npad * k * 4, (void**)&b32));
+    REID_TRY(ctx_ws(ctx, "dbg.bias", (size_t)npad * 4, (void**)&bias));
+    REID_TRY(ctx_ws(ctx, "dbg.res", (size_t)m * n * 4, (void**)&res));
+    REID_TRY(ctx_ws(ctx, "dbg.out", (size_t)m * n * 4, (void**)&c32));
+    REID_TRY(ctx_ws(ctx, "dbg.x16", (size_t)m * k * 2, (void**)&a16));
+    REID_TRY(ctx_ws(ctx, "dbg.w16", (size_t)npad * k * 2, (void**)&b16));
+    REID_TRY(ctx_ws(ctx, "dbg.out16", (size_t)m * n * 2, (void**)&c16));
+    const size_t src_n = ctx->se18.n_floats;
+    for (size_t o = 0; o < (size_t)m * k; o += src_n) {
+        const size_t cnt = (size_t)m * k - o < src_n ? (size_t)m * k - o : src_n;
+        HIP_TRY(hipMemcpyAsync(a32 + o, ctx->se18.blob, cnt * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, cnt, a16 + o));
+    }
+    for (size_t o = 0; o < (size_t)npad * k; o += src_n) {
+        const size_t cnt = (size_t)npad * k - o < src_n ? (size_t)npad * k - o : src_n;
+        HIP_TRY(hipMemcpyAsync(b32 + o, ctx->se18.blob, cnt * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, cnt, b16 + o));
+    }
+    HIP_TRY(hipMemsetAsync(bias, 0, (size_t)npad * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(res, 0, (size_t)m * n * 4, ctx->stream));
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = a32; p.lda = k; p.B = b32; p.ldb = k; p.M = m; p.N = n; p.K = k; p.C = c32; p.ldc = n;
+    p.col_shift = bias; p.act = epi == 1; p.residual = epi == 2 ? res : nullptr;
+    Gemm16Params q;
+    memset(&q, 0, sizeof(q));
+    q.A = a16; q.lda = k; q.B = b16; q.ldb = k; q.M = m; q.N = npad; q.K = k; q.ldc = n;
+    q.C = epi == 2 ? nullptr : c16; q.C32 = epi == 2 ? c32 : nullptr; q.res32 = epi == 2 ? res : nullptr;
+    q.col_shift = bias; q.lin = 1; q.act = epi == 1; q.n_real = n;
+    q.zero_page = ctx->se18.zero_page;
+    auto run = [&]() { return h ? launch_gemm_f16(ctx, A16_DENSE, q, REID_K_CONV_GEMM, 0, 0) : launch_gemm_f32(ctx, A_DENSE, E_BIAS, p, REID_K_CONV_GEMM, 0, 0); };
+    int st = REID_OK;
+    for (int i = 0; i < 2 && st == REID_OK; ++i) st = run();
+    if (st == REID_OK) st = reid_timer_start(ctx);
+    for (int i = 0; i < iters && st == REID_OK; ++i) st = run();
+    float ms = 0.f;
+    if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
+    *ms_per_launch = ms / (iters > 0 ? iters : 1);
+    return st;
+}

@@ -34,10 +34,32 @@ namespace {
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// nn.GELU() (erf form), x * 0.5 * (1 + erf(x / sqrt 2)), for the fp16-storage mode.  erf by Abramowitz-Stegun 7.1.28,
+// 1 - (1 + a1 z + ... + a6 z^6)^-16, |error| <= 3e-7 - three orders below the f16 rounding of the value it produces.  Every
+// multiply-add is an explicit fma: ocml's erff, inlined into the 64- and the 128-wide instantiation, was contracted differently
+// in the two and an image's embedding depended on the batch it came in.  20 issue slots instead of ~35.
+__device__ __forceinline__ float gelu_f16_storage(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    float q = fmaf(0.0000430638f, z, 0.0002765672f);
+    q = fmaf(q, z, 0.0001520143f);
+    q = fmaf(q, z, 0.0092705272f);
+    q = fmaf(q, z, 0.0422820123f);
+    q = fmaf(q, z, 0.0705230784f);
+    q = fmaf(q, z, 1.0f);
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    const float erfz = 1.0f - __builtin_amdgcn_rcpf(q);
+    const float h = 0.5f * v;
+    return fmaf(h, copysignf(erfz, v), h);
+}
+
 // LIN: the linear-layer epilogue (Swin) instead of the convolution epilogue - a template parameter, not a run-time branch:
 // carrying both epilogues cost the 256-wide conv instantiations 66 more spilled VGPRs (72 -> 214 us per launch)
+// (launch bound = waves per SIMD: the linear builds up to 128 columns must stay within 128 VGPRs so that TWO blocks share a CU)
 template <int AMODE, int BN, int BK, int NST, int STAG, bool LIN = false>
-__global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) {
+__global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kernel(const Gemm16Params p) {
     constexpr int BM = 256;
     constexpr int WM = BN == 256 ? 2 : 4;         // waves along M
     constexpr int WN = 8 / WM;                    // waves along N
@@ -282,12 +304,89 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
     const int m_valid = p.M - m_blk;  // rows of this tile that exist (>= 256 except for a ragged last tile)
 
     if constexpr (LIN) {   // linear layers (Swin): bias, erf-GELU, fp32 residual stream, fp32 or f16 output, ragged M and N
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Swin's K loops are 3-24 tiles long: the epilogue decides these launches.  Its two hot forms carry no per-element
+        // address arithmetic, predicate or run-time branch; everything else takes the general loop at the end.
         const int n_real = p.n_real ? p.n_real : p.N;
         constexpr bool LIN_LDS = BM * BN * 2 <= NST * STAGE;
-        // f16 outputs that are plain row-major (no residual, no scatter) are staged through LDS and leave as whole 16-byte
-        // pieces of a row; everything else (fp32 stream, ConvTranspose scatter) stores from the MFMA layout, 128 B per row
+        // (1) f16 outputs that are plain row-major (qkv, fc1): staged through LDS, leave as whole 16-byte pieces of a row
         const bool staged = LIN_LDS && !p.C32 && !p.res32 && p.scat_h == 0 && (n_real & 7) == 0;
-        f16* tile = (f16*)lds;
+        if (staged && !(p.no_lean & 1)) {
+            f16* tile = (f16*)lds;
+            auto fill = [&](auto act_c) {
+                constexpr bool ACT = decltype(act_c)::value;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int lcol = wn * WTN + b * 32 + li;
+                    const int col = n_blk + lcol;
+                    const float bias = (p.col_shift && col < n_real) ? p.col_shift[col] : 0.f;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float v = acc[a][b][e] + bias;
+                            if constexpr (ACT) v = gelu_f16_storage(v);
+                            tile[(row0 + a * 32 + (e & 3) + 8 * (e >> 2)) * BN + lcol] = (f16)v;
+                        }
+                }
+            };
+            if (p.act == 1) fill(std::true_type{});
+            else fill(std::false_type{});
+            __syncthreads();
+            constexpr int C8 = BN / 8;
+            for (int idx = tid; idx < BM * C8; idx += 512) {
+                const int row = idx / C8, c8 = idx - row * C8;
+                if (row < m_valid && n_blk + c8 * 8 < n_real)
+                    *(half8*)(p.C + (long long)(m_blk + row) * ldc + n_blk + c8 * 8) = *(const half8*)(tile + row * BN + c8 * 8);
+            }
+            return;
+        }
+        // (2) the fp32 residual stream (proj, fc2, patch merging): buffer loads / stores from the MFMA layout, 128 B per row and
+        // instruction; per-lane byte offset fixed per column block, row offset in the SGPR operand, columns past N fall outside
+        // the descriptor and are dropped by the hardware
+        // (the SGPR offset is not part of the range check: a tile with fewer than BM rows takes the general loop)
+        if (p.C32 && p.scat_h == 0 && (long long)BM * ldc * 4 < 0x7fffff00ll && m_valid >= BM && !(p.no_lean & 2)) {
+            const int rows = BM;
+            const int recs = (int)(((long long)(rows - 1) * ldc + n_real) * 4);
+            const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C32 + (long long)m_blk * ldc), 0, recs, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)((p.res32 ? p.res32 : p.C32) + (long long)m_blk * ldc), 0, recs, 0x00020000);
+            auto stream = [&](auto act_c, auto res_c) {
+                constexpr bool ACT = decltype(act_c)::value, RES = decltype(res_c)::value;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int col = n_blk + wn * WTN + b * 32 + li;
+                    const bool col_ok = col < n_real;
+                    const float bias = (p.col_shift && col_ok) ? p.col_shift[col] : 0.f;
+                    const int voff = col_ok ? (row0 * ldc + col) * 4 : 0x7fffff00;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        float res[16];
+                        if constexpr (RES) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e)
+                                res[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff, (a * 32 + (e & 3) + 8 * (e >> 2)) * ldc * 4, 0));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float v = acc[a][b][e] + bias;
+                            if constexpr (ACT) v = gelu_f16_storage(v);
+                            if constexpr (RES) v += res[e];
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff, (a * 32 + (e & 3) + 8 * (e >> 2)) * ldc * 4, 0);
+                        }
+                    }
+                }
+            };
+            if (p.act == 1) {
+                if (p.res32) stream(std::true_type{}, std::true_type{});
+                else stream(std::true_type{}, std::false_type{});
+            } else {
+                if (p.res32) stream(std::false_type{}, std::true_type{});
+                else stream(std::false_type{}, std::false_type{});
+            }
+            return;
+        }
+        // (3) everything else (ConvTranspose parity scatter, f16 outputs with odd widths): element by element
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int lcol = wn * WTN + b * 32 + li;
@@ -300,10 +399,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
                 for (int e = 0; e < 16; ++e) {
                     const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
                     float v = acc[a][b][e] + bias;
-                    if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU() (erf form)
-                    if (staged) {
-                        tile[rl * BN + lcol] = (f16)v;
-                    } else if (rl < m_valid && col_ok) {
+                    if (p.act == 1) v = gelu_f16_storage(v);
+                    if (rl < m_valid && col_ok) {
                         long long orow = m_blk + rl;
                         if (p.scat_h > 0) {   // ConvTranspose2d(4,2,1) output parity: (img, j, i) -> (img, 2j+py, 2i+px)
                             const int hw = p.scat_h * p.scat_w;
@@ -319,15 +416,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_kernel(const Gemm16Params p) 
                     }
                 }
         }
-        if (staged) {
-            __syncthreads();
-            constexpr int C8 = BN / 8;
-            for (int idx = tid; idx < BM * C8; idx += 512) {
-                const int row = idx / C8, c8 = idx - row * C8;
-                if (row < m_valid && n_blk + c8 * 8 < n_real)
-                    *(half8*)(p.C + (long long)(m_blk + row) * ldc + n_blk + c8 * 8) = *(const half8*)(tile + row * BN + c8 * 8);
-            }
-        }
+#endif
         return;
     }
 
@@ -473,7 +562,9 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
         const bool k64 = p.K % 64 == 0 && (AMODE != A16_IM2COL || p.Cin % 64 == 0);
         // (the linear-epilogue build of the 256-wide tile spills 98 VGPRs: those launches take the 128-wide one)
         int bn = !p.lin && p.N % 256 == 0 && mt * (p.N / 256) >= 192 ? 256 : (p.N % 128 == 0 ? 128 : 64);
-        if (bn == 128 && p.N > 128 && mt * (p.N / 128) < 128) bn = 64;   // a tracking frame: twice the blocks on a half-empty chip
+        // a tracking frame: twice the blocks on a half-empty chip.  Convolutions only: the tile shape of a Swin linear must not
+        // depend on the batch (the two instantiations round their epilogues differently, an image's embedding would too)
+        if (!p.lin && bn == 128 && p.N > 128 && mt * (p.N / 128) < 128) bn = 64;
         if (!k64) cfg = bn * 1000 + 320 + (bn == 256 ? 4 : 3);
         else if (bn == 128 && p.N == 128) cfg = 128323;
         // Swin's linears have short K loops (K = 96 .. 768, fc2 up to 3072): with BK = 32 and three stages a block needs 72 KB of

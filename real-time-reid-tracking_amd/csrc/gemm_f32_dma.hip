@@ -10,6 +10,7 @@
 // XOR-swizzled 128-byte rows (conflict-free ds_read_b128), one s_waitcnt vmcnt(0) + one raw s_barrier per K-tile.
 // Requirements: K % 32 == 0, 16-byte aligned rows (lda, ldb % 4 == 0); everything else falls back to gemm_f32_kernel.
 #include "reid_internal.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -20,6 +21,15 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(uintptr_t)(p))
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+// One output tile's operand descriptors: they start at the tile's first row and end at the matrix' last row, so rows past
+// M / N read as zeros (and a row past the edge keeps an offset beyond the descriptor for every K-tile).
+template <int AJ, int BJ>
+struct TileDesc {
+    __amdgpu_buffer_rsrc_t a_rs, b_rs;
+    int a_voff[AJ], b_voff[BJ];
+    int m_blk, n_blk, rows_a;
+};
 
 template <int BN, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p) {
@@ -34,60 +44,43 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-
     const int nnt = (p.N + BN - 1) / BN;
-    int mtile, ntile;
-    {
-        const int nwg = gridDim.x;
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-        mtile = L / nnt;
-        ntile = L - mtile * nnt;
-    }
-    const int m_blk = mtile * BM, n_blk = ntile * BN;
-
-    // descriptors start at this block's first row and end at the matrix' last row: rows past M / N read as zeros
-    const int rows_a = p.M - m_blk < BM ? p.M - m_blk : BM;
-    const int rows_b = p.N - n_blk < BN ? p.N - n_blk : BN;
-    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const float*)p.A + (long long)m_blk * p.lda), 0, (int)((long long)(rows_a - 1) * p.lda * 4 + (long long)p.K * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.B + (long long)n_blk * p.ldb), 0, (int)((long long)(rows_b - 1) * p.ldb * 4 + (long long)p.K * 4), 0x00020000);
-    int a_voff[AJ], b_voff[BJ];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-        const int row = (wave * AJ + j) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        // a row past the edge must stay out of range for every K-tile: push it beyond the descriptor
-        a_voff[j] = row < rows_a ? (int)(((long long)row * p.lda + chunk * 4) * 4) : (int)0x7fffff00;
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-        const int row = (wave * BJ + j) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        b_voff[j] = row < rows_b ? (int)(((long long)row * p.ldb + chunk * 4) * 4) : (int)0x7fffff00;
-    }
     const int nk = p.K / BK;
-    int l_k = 0;
-    auto stage = [&](int slot) {
+
+    using Desc = TileDesc<AJ, BJ>;
+    auto describe = [&](int t, Desc& d) {
+        const int mtile = t / nnt, ntile = t - mtile * nnt;
+        d.m_blk = mtile * BM;
+        d.n_blk = ntile * BN;
+        d.rows_a = p.M - d.m_blk < BM ? p.M - d.m_blk : BM;
+        const int rows_b = p.N - d.n_blk < BN ? p.N - d.n_blk : BN;
+        d.a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)p.A + (long long)d.m_blk * p.lda), 0,
+                                                   (int)((long long)(d.rows_a - 1) * p.lda * 4 + (long long)p.K * 4), 0x00020000);
+        d.b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long long)d.n_blk * p.ldb), 0,
+                                                   (int)((long long)(rows_b - 1) * p.ldb * 4 + (long long)p.K * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int row = (wave * AJ + j) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            d.a_voff[j] = row < d.rows_a ? (int)(((long long)row * p.lda + chunk * 4) * 4) : (int)0x7fffff00;
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int row = (wave * BJ + j) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            d.b_voff[j] = row < rows_b ? (int)(((long long)row * p.ldb + chunk * 4) * 4) : (int)0x7fffff00;
+        }
+    };
+    auto stage = [&](const Desc& d, int kt, int slot) {
         char* As = lds + slot * STAGE;
         char* Bs = As + A_BYTES;
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(As + (wave * AJ + j) * 1024), 16, a_voff[j], l_k * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d.a_rs, LPTR(As + (wave * AJ + j) * 1024), 16, d.a_voff[j], kt * BK * 4, 0, 0);
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, LPTR(Bs + (wave * BJ + j) * 1024), 16, b_voff[j], l_k * 4, 0, 0);
-        l_k += BK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d.b_rs, LPTR(Bs + (wave * BJ + j) * 1024), 16, d.b_voff[j], kt * BK * 4, 0, 0);
     };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     const int swz = (li >> 1) & 7;
     int a_rd[4], b_rd[4];
@@ -97,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
         a_rd[kk] = (wm * 64 + li) * ROWB + pos;
         b_rd[kk] = A_BYTES + (wn * WN + li) * ROWB + pos;
     }
+    f32x16 acc[TM][TN];
     auto mfma_tile = [&](int slot) {
         const char* base = lds + slot * STAGE;
         f32x4 af[2][TM], bf[2][TN];
@@ -122,47 +116,81 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
         }
     };
 
-    stage(0);
-    for (int kt = 0; kt < nk; kt += 2) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (kt + u < nk) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                RAW_BARRIER();
-                if (kt + u + 1 < nk) stage(u ^ 1);
-                mfma_tile(u);
-            }
-        }
-    }
-
-    // ------------------------------------------------------------------ epilogue (ragged edges predicated)
+    // ------------------------------------------------------------------ epilogues (registers -> memory, no LDS)
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // Linear layers (everything but the ConvTranspose scatter): beside the other block's MFMAs every VALU instruction issues
+    // at a fraction of its rate, so output and residual go through buffer instructions - per-lane byte offset fixed per column
+    // block, row offset in the SGPR soffset, columns past N fall outside the descriptor and are dropped by the hardware
+    // (full-height tiles only).  Per element: bias add, (erf-GELU,) residual add; no address arithmetic, no predicate.
+    auto bias_lean = [&](const Desc& d, auto act_c, auto res_c) {
+        constexpr bool ACT = decltype(act_c)::value, RES = decltype(res_c)::value;
+        const int ldc = (int)p.ldc;
+        const int recs = (int)(((long long)(d.rows_a - 1) * ldc + p.N) * 4);
+        const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long long)d.m_blk * ldc), 0, recs, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((RES ? p.residual : p.C) + (long long)d.m_blk * ldc), 0, recs, 0x00020000);
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int col = n_blk + wn * WN + b * 32 + li;
-        const bool colok = col < p.N;
-        float sh = 0.f, cq = 0.f;
-        if constexpr (EPI == E_BIAS) {
-            if (colok && p.col_shift) sh = p.col_shift[col];
-        } else {
-            if (colok && p.col_sq) cq = p.col_sq[col];
-            if (p.metric == REID_METRIC_COS_HALF || p.metric == REID_METRIC_COS) cq = sqrtf(cq);
-        }
+        for (int b = 0; b < TN; ++b) {
+            const int col = d.n_blk + wn * WN + b * 32 + li;
+            const bool colok = col < p.N;
+            const float sh = (colok && p.col_shift) ? p.col_shift[col] : 0.f;
+            const int voff = colok ? ((wm * 64 + 4 * lh) * ldc + col) * 4 : 0x7fffff00;
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const int row0 = m_blk + wm * 64 + a * 32 + 4 * lh;
-            float res[16];
-            if constexpr (EPI == E_BIAS) {
-                if (p.residual && p.scat_h == 0) {   // plain residual: fetch the 16 values up front
+            for (int a = 0; a < TM; ++a) {
+                float res[16];
+                if constexpr (RES) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = row0 + (e & 3) + 8 * (e >> 2);
-                        res[e] = (colok && row < p.M) ? p.residual[(long long)row * p.ldc + col] : 0.f;
-                    }
+                    for (int e = 0; e < 16; ++e)
+                        res[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff, (a * 32 + (e & 3) + 8 * (e >> 2)) * ldc * 4, 0));
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[a][b][e] + sh;
+                    if constexpr (ACT) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU() (erf form)
+                    if constexpr (RES) v += res[e];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff, (a * 32 + (e & 3) + 8 * (e >> 2)) * ldc * 4, 0);
                 }
             }
-            float rsq[16];
-            if constexpr (EPI == E_DIST) {   // squared norms of the tile's 16 rows of this lane half: four groups of four consecutive rows
+        }
+    };
+    auto bias_general = [&](const Desc& d) {   // ConvTranspose parity scatter / huge row pitch: element by element
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = d.n_blk + wn * WN + b * 32 + li;
+            const bool colok = col < p.N;
+            const float sh = (colok && p.col_shift) ? p.col_shift[col] : 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = d.m_blk + wm * 64 + a * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+                    if (!colok || row >= p.M) continue;
+                    long long orow = row;
+                    if (p.scat_h > 0) {   // ConvTranspose2d(4,2,1) output parity: (img, j, i) -> (img, 2j+py, 2i+px)
+                        const int hw = p.scat_h * p.scat_w;
+                        const int img = row / hw, rem = row - img * hw;
+                        const int j = rem / p.scat_w, i = rem - j * p.scat_w;
+                        orow = ((long long)img * 2 * p.scat_h + 2 * j + p.scat_py) * (2 * p.scat_w) + 2 * i + p.scat_px;
+                    }
+                    const long long idx = orow * p.ldc + col;
+                    float v = acc[a][b][e] + sh;
+                    if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (p.residual) v += p.residual[idx];
+                    p.C[idx] = v;
+                }
+        }
+    };
+    auto dist_epilogue = [&](const Desc& d) {   // ragged edges predicated
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = d.n_blk + wn * WN + b * 32 + li;
+            const bool colok = col < p.N;
+            float cq = (colok && p.col_sq) ? p.col_sq[col] : 0.f;
+            if (p.metric == REID_METRIC_COS_HALF || p.metric == REID_METRIC_COS) cq = sqrtf(cq);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row0 = d.m_blk + wm * 64 + a * 32 + 4 * lh;
+                float rsq[16];   // squared norms of the tile's 16 rows of this lane half: four groups of four consecutive rows
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r4 = row0 + 8 * q;
@@ -174,26 +202,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                         for (int u = 0; u < 4; ++u) rsq[4 * q + u] = (p.row_sq && r4 + u < p.M) ? p.row_sq[r4 + u] : 0.f;
                     }
                 }
-            }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = row0 + (e & 3) + 8 * (e >> 2);
-                const bool ok = colok && row < p.M;
-                float v = acc[a][b][e];
-                if constexpr (EPI == E_BIAS) {
-                    long long orow = row;
-                    if (p.scat_h > 0) {   // ConvTranspose2d(4,2,1) output parity: (img, j, i) -> (img, 2j+py, 2i+px)
-                        const int hw = p.scat_h * p.scat_w;
-                        const int img = row / hw, rem = row - img * hw;
-                        const int j = rem / p.scat_w, i = rem - j * p.scat_w;
-                        orow = ((long long)img * 2 * p.scat_h + 2 * j + p.scat_py) * (2 * p.scat_w) + 2 * i + p.scat_px;
-                    }
-                    const long long idx = orow * p.ldc + col;
-                    v += sh;
-                    if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU() (erf form)
-                    if (p.residual) v += p.scat_h == 0 ? res[e] : (ok ? p.residual[idx] : 0.f);
-                    if (ok) p.C[idx] = v;
-                } else {
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + (e & 3) + 8 * (e >> 2);
+                    float v = acc[a][b][e];
                     const float rs = rsq[e];
                     switch (p.metric) {
                         case REID_METRIC_L2: v = sqrtf(fmaxf((rs + cq) - 2.0f * v, 1e-12f)); break;
@@ -202,10 +214,57 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                         case REID_METRIC_COS: v = 1.0f - v / (sqrtf(rs) * cq); break;
                         default: break;
                     }
-                    if (ok) p.C[(long long)row * p.ldc + col] = v;
+                    if (colok && row < p.M) p.C[(long long)row * p.ldc + col] = v;
                 }
             }
         }
+    };
+    // (the SGPR offset is not part of the descriptor's range check: a tile with fewer than BM rows takes the general loop)
+    const bool lean_ok = EPI == E_BIAS && p.scat_h == 0 && (long long)BM * p.ldc * 4 < 0x7fffff00ll;
+
+    // ------------------------------------------------------------------ one output tile per block
+    // (Persistent blocks that treat the K-tiles of successive output tiles as one stream - the next tile's first operands in
+    // flight under this tile's epilogue - were measured: stage-1 shapes unchanged, late stages slower from the static tile
+    // assignment; 21.5 vs 19.2 ms for all linears of a 256-image pass.)
+    Desc cur;
+    int t;
+    {   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD): an XCD's blocks take consecutive tiles
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    describe(t, cur);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    stage(cur, 0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {       // unrolled by the two stages: LDS offsets become instruction immediates
+            if (kt + u < nk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current K-tile have landed
+                RAW_BARRIER();                                     // ... everyone's have, and everyone is done with the other stage
+                if (kt + u + 1 < nk) stage(cur, kt + u + 1, u ^ 1);
+                mfma_tile(u);
+            }
+        }
+    }
+    if constexpr (EPI == E_BIAS) {
+        if (lean_ok && cur.rows_a == BM) {
+            if (p.act == 1) {
+                if (p.residual) bias_lean(cur, std::true_type{}, std::true_type{});
+                else bias_lean(cur, std::true_type{}, std::false_type{});
+            } else {
+                if (p.residual) bias_lean(cur, std::false_type{}, std::true_type{});
+                else bias_lean(cur, std::false_type{}, std::false_type{});
+            }
+        } else {
+            bias_general(cur);
+        }
+    } else {
+        dist_epilogue(cur);
     }
 #endif
 }
@@ -216,11 +275,9 @@ void launch_epi(reid_ctx* ctx, const GemmParams& p) {
     // 64-wide tiles waste fewer padded columns on narrow / odd outputs (288, 192) but run ~12 % below the 128-wide tile per column
     const double cost64 = ((p.N + 63) / 64) * 64 * 1.12, cost128 = ((p.N + 127) / 128) * 128;
     if (p.N <= 64 || cost64 < cost128) {
-        const int nnt = (p.N + 63) / 64;
-        hipLaunchKernelGGL((gemm_f32_dma_kernel<64, EPI>), dim3(nmt * nnt), dim3(256), 0, ctx->stream, p);
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<64, EPI>), dim3(nmt * ((p.N + 63) / 64)), dim3(256), 0, ctx->stream, p);
     } else {
-        const int nnt = (p.N + 127) / 128;
-        hipLaunchKernelGGL((gemm_f32_dma_kernel<128, EPI>), dim3(nmt * nnt), dim3(256), 0, ctx->stream, p);
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<128, EPI>), dim3(nmt * ((p.N + 127) / 128)), dim3(256), 0, ctx->stream, p);
     }
 }
 

@@ -108,6 +108,7 @@ struct Gemm16Params {
     float* C32;
     const float* res32;
     // conv3x3_f16.hip split-K (small launches): blocks per output tile, fp32 partial tiles, per-tile arrival counters
+    int no_lean;                // experiments: bit 0 skips the staged LIN epilogue, bit 1 the fp32-stream one
     int split_k;
     float* splitk_ws;
     int* splitk_cnt;
