@@ -370,8 +370,9 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const GemmParams p) {
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 template <int BN, int FLAGS>
-__global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p_in) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
+    GemmParams p = p_in;
     constexpr bool DIAG = (FLAGS & 1) != 0;
     constexpr bool GEN = (FLAGS & 4) != 0;          // general geometry: tiles may straddle images, ragged M / N, bias epilogue
     constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
@@ -391,7 +392,16 @@ __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p
     {
         const int nwg = gridDim.x;
         const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        if constexpr (GEN) {
+            if (p.par4) {   // four ConvTranspose parities in one launch: copy q of the tile grid = parity (q >> 1, q & 1)
+                const int tiles = nwg >> 2, par = L / tiles;
+                L -= par * tiles;
+                p.B += par * p.par_stride;
+                p.pad_y = 1 - (par >> 1); p.pad_x = 1 - (par & 1);
+                p.scat_py = par >> 1; p.scat_px = par & 1;
+            }
+        }
         mtile = L / nnt;
         ntile = L - mtile * nnt;
     }
@@ -591,8 +601,9 @@ int launch_conv_f32_general(reid_ctx* ctx, const GemmParams& p, int kind, double
     prof_begin(ctx, kind, flops, bytes);
     const int nmt = (p.M + BM - 1) / BM;
     const double cost64 = ((p.N + 63) / 64) * 64 * 1.12, cost128 = ((p.N + 127) / 128) * 128;
-    if (p.N <= 64 || cost64 < cost128) hipLaunchKernelGGL((conv_f32_dma_kernel<64, 4>), dim3(nmt * ((p.N + 63) / 64)), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((conv_f32_dma_kernel<128, 4>), dim3(nmt * ((p.N + 127) / 128)), dim3(256), 0, ctx->stream, p);
+    const int copies = p.par4 ? 4 : 1;   // the four ConvTranspose parities as one grid
+    if (p.N <= 64 || cost64 < cost128) hipLaunchKernelGGL((conv_f32_dma_kernel<64, 4>), dim3(nmt * ((p.N + 63) / 64) * copies), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((conv_f32_dma_kernel<128, 4>), dim3(nmt * ((p.N + 127) / 128) * copies), dim3(256), 0, ctx->stream, p);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

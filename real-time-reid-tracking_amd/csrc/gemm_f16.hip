@@ -59,7 +59,7 @@ __device__ __forceinline__ float gelu_f16_storage(float v) {
 // carrying both epilogues cost the 256-wide conv instantiations 66 more spilled VGPRs (72 -> 214 us per launch)
 // (launch bound = waves per SIMD: the linear builds up to 128 columns must stay within 128 VGPRs so that TWO blocks share a CU)
 template <int AMODE, int BN, int BK, int NST, int STAG, bool LIN = false>
-__global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kernel(const Gemm16Params p) {
+__global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kernel(const Gemm16Params p_in) {
     constexpr int BM = 256;
     constexpr int WM = BN == 256 ? 2 : 4;         // waves along M
     constexpr int WN = 8 / WM;                    // waves along N
@@ -83,12 +83,22 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
+    Gemm16Params p = p_in;
     const int nnt = p.N / BN;
     const int nwg = gridDim.x;
     int mtile, ntile;
     {   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD)
         const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        if constexpr (LIN && AMODE == A16_IM2COL) {
+            if (p.par4) {   // four ConvTranspose parities in one launch: copy q of the tile grid = parity (q >> 1, q & 1)
+                const int tiles = nwg >> 2, par = L / tiles;
+                L -= par * tiles;
+                p.B += par * p.par_stride;
+                p.pad_y = 1 - (par >> 1); p.pad_x = 1 - (par & 1);
+                p.scat_py = par >> 1; p.scat_px = par & 1;
+            }
+        }
         mtile = L / nnt;
         ntile = L - mtile * nnt;
     }
@@ -546,7 +556,8 @@ int launch_cfg(reid_ctx* ctx, const Gemm16Params& p) {
         reid_set_error("gemm_f16: K=%d / Cin=%d not a multiple of BK=%d", p.K, p.Cin, BK);
         return REID_ERR_ARG;
     }
-    hipLaunchKernelGGL((gemm_f16_kernel<AMODE, BN, BK, NST, STAG, LIN>), dim3(((p.M + 255) / 256) * (p.N / BN)), dim3(512), 0, ctx->stream, p);
+    hipLaunchKernelGGL((gemm_f16_kernel<AMODE, BN, BK, NST, STAG, LIN>), dim3(((p.M + 255) / 256) * (p.N / BN) * (p.par4 ? 4 : 1)), dim3(512), 0,
+                       ctx->stream, p);
     LAUNCH_CHECK();
     return REID_OK;
 }

@@ -73,6 +73,10 @@ struct GemmParams {
     // scat_h > 0: row m = (img, j, i) of a scat_h x scat_w grid is written to pixel (2j+scat_py, 2i+scat_px) of the
     // 2x up-sampled grid (one output parity of a ConvTranspose2d(4, 2, 1)); residual uses the same index.
     int act, scat_h, scat_w, scat_py, scat_px;
+    // par4 != 0 (conv_f32_dma general variant): the FOUR output parities of a ConvTranspose2d(4, 2, 1) in one launch - the grid
+    // is four copies of the tile grid, copy q = (py, px) uses weights B + q * par_stride, padding (1 - py, 1 - px), scatter (py, px)
+    int par4;
+    long long par_stride;
     unsigned long long* diag;   // diagnostic builds of conv_f32.hip only: per-wave cycle sums [block<64][8][5]
     const float* row_sq;   // E_DIST
     const float* col_sq;
@@ -108,6 +112,8 @@ struct Gemm16Params {
     float* C32;
     const float* res32;
     // conv3x3_f16.hip split-K (small launches): blocks per output tile, fp32 partial tiles, per-tile arrival counters
+    int par4;                   // as GemmParams.par4 (LIN im2col build): four ConvTranspose parities in one launch
+    long long par_stride;
     int no_lean;                // experiments: bit 0 skips the staged LIN epilogue, bit 1 the fp32-stream one
     int split_k;
     float* splitk_ws;

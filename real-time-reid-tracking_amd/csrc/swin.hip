@@ -705,10 +705,11 @@ int linear16(reid_ctx* ctx, const f16* x, long long m, int lda, int k, const f16
 // NHWC f16 map, weights [Cout padded to 64][R*S*Cin]; out = conv + bias (+ res32 at the output index), f16 or fp32
 int conv16(reid_ctx* ctx, const f16* zero_page, const f16* x, int n, int H, int W, int Cin, const f16* w, const float* bias,
            int Cout, int R, int S, int stride, int pad_y, int pad_x, int Ho, int Wo, const float* res32, f16* out16, float* out32,
-           int scat_h = 0, int scat_w = 0, int py = 0, int px = 0) {
+           int scat_h = 0, int scat_w = 0, int py = 0, int px = 0, long long par_stride = 0) {
     Gemm16Params p;
     memset(&p, 0, sizeof(p));
     p.A = x;
+    p.par4 = par_stride != 0; p.par_stride = par_stride;   // all four ConvTranspose parities in one launch (pads / scatter per grid copy)
     p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.S = S; p.stride = stride; p.asym = 1; p.pad_y = pad_y; p.pad_x = pad_x;
     p.Ho = Ho; p.Wo = Wo;
     p.B = w; p.ldb = (long long)R * S * Cin;
@@ -739,6 +740,33 @@ int conv_bias(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, const
     const double bytes = 4.0 * ((double)n * H * W * Cin + (double)Cout * p.K + (double)p.M * Cout);
     if (ctx->f32_conv == 1 && conv_f32_general_supported(p)) return launch_conv_f32_general(ctx, p, REID_K_CONV_GEMM, flops, bytes);
     return launch_gemm_f32(ctx, A_IM2COL, E_BIAS, p, REID_K_CONV_GEMM, flops, bytes);
+}
+
+// ConvTranspose2d(4, 2, 1) as its four output parities (2x2 stride-1 convs with one-sided padding, scattered to (2j+py, 2i+px));
+// wts: four [Cout][4 Cin] matrices.  One launch of 4 x the tile grid on the LDS-DMA kernel, else one launch per parity.
+int conv_transpose_parities(reid_ctx* ctx, const float* x, int n, int Hi, int Wi, int ci, const float* wts, const float* bias, int co,
+                            const float* residual, float* out) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = x;
+    p.H = Hi; p.W = Wi; p.Cin = ci; p.R = 2; p.S = 2; p.stride = 1; p.pad_y = 1; p.pad_x = 1;
+    p.Ho = Hi; p.Wo = Wi;
+    p.B = wts; p.ldb = 4 * ci;
+    p.M = n * Hi * Wi; p.N = co; p.K = 4 * ci;
+    p.C = out; p.ldc = co;
+    p.col_shift = bias; p.residual = residual;
+    p.scat_h = Hi; p.scat_w = Wi;
+    if (ctx->f32_conv == 1 && conv_f32_general_supported(p)) {
+        p.par4 = 1;
+        p.par_stride = (long long)co * 4 * ci;
+        return launch_conv_f32_general(ctx, p, REID_K_CONV_GEMM, 8.0 * p.M * co * p.K,
+                                       4.0 * ((double)n * Hi * Wi * ci + 4.0 * co * p.K + 4.0 * p.M * co));
+    }
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+            REID_TRY(conv_bias(ctx, x, n, Hi, Wi, ci, wts + (size_t)(py * 2 + px) * co * 4 * ci, bias, co, 2, 2, 1, 1 - py, 1 - px, Hi, Wi, residual,
+                               out, Hi, Wi, py, px));
+    return REID_OK;
 }
 
 const int kDims[4] = {96, 192, 384, 768}, kLayers[4] = {2, 2, 6, 2}, kHeads[4] = {3, 6, 12, 24};
@@ -1051,11 +1079,10 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
         for (int t = 0; t < 3; ++t) {
             const int ci = kDims[3 - t], co = kDims[2 - t];
             const size_t wstride = (size_t)((co + 63) / 64 * 64) * 4 * ci;
-            for (int py = 0; py < 2; ++py)
-                for (int px = 0; px < 2; ++px)
-                    REID_TRY(conv16(ctx, w.zero_page, maps16[t], n, Hi, Wi, ci, w.t16[t] + (size_t)(py * 2 + px) * wstride, w.t_b[t], co, 2, 2, 1,
-                                    1 - py, 1 - px, Hi, Wi, xs[2 - t], t < 2 ? maps16[t + 1] : nullptr, t < 2 ? nullptr : f1, Hi, Wi,
-                                    py, px));
+            // the four output parities of the ConvTranspose2d(4, 2, 1) as ONE launch (4 x the tile grid): a parity alone is 147-784
+            // blocks, too few for 256 CUs
+            REID_TRY(conv16(ctx, w.zero_page, maps16[t], n, Hi, Wi, ci, w.t16[t], w.t_b[t], co, 2, 2, 1, 1, 1, Hi, Wi, xs[2 - t],
+                            t < 2 ? maps16[t + 1] : nullptr, t < 2 ? nullptr : f1, Hi, Wi, 0, 0, (long long)wstride));
             Hi *= 2;
             Wi *= 2;
         }
@@ -1067,10 +1094,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
     int Hi = H4, Wi = W4;
     for (int t = 0; t < 3; ++t) {
         const int ci = kDims[3 - t], co = kDims[2 - t];
-        for (int py = 0; py < 2; ++py)
-            for (int px = 0; px < 2; ++px)
-                REID_TRY(conv_bias(ctx, fin, n, Hi, Wi, ci, w.t_w[t] + (size_t)(py * 2 + px) * co * 4 * ci, w.t_b[t], co, 2, 2, 1, 1 - py,
-                                   1 - px, Hi, Wi, xs[2 - t], fouts[t], Hi, Wi, py, px));
+        REID_TRY(conv_transpose_parities(ctx, fin, n, Hi, Wi, ci, w.t_w[t], w.t_b[t], co, xs[2 - t], fouts[t]));
         fin = fouts[t];
         Hi *= 2;
         Wi *= 2;
