@@ -141,32 +141,37 @@ __device__ __forceinline__ void bias_epilogue(const GemmParams& p, f32x16 (&acc)
         }
         return;
     }
+    // scatter (ConvTranspose parity) and ragged-M tiles: element by element, the output row of each of the lane's 32 rows computed
+    // once (divisions by multiply-high with host-made reciprocals)
+    float sh[TN];
+    int colv[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-        const int col = n_blk + wn * WN + b * 32 + li;
-        const bool colok = col < p.N;
-        const float sh = (colok && p.col_shift) ? p.col_shift[col] : 0.f;
+        colv[b] = n_blk + wn * WN + b * 32 + li;
+        sh[b] = (colv[b] < p.N && p.col_shift) ? p.col_shift[colv[b]] : 0.f;
+    }
+    const unsigned hws = (unsigned)(p.scat_h * p.scat_w);
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const int row0 = m_blk + wm * 64 + a * 32 + 4 * lh;
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = row0 + (e & 3) + 8 * (e >> 2);
-                const bool ok = colok && row < p.M;
-                long long orow = row;
-                if (p.scat_h > 0) {
-                    const int hws = p.scat_h * p.scat_w;
-                    const int im = row / hws, rem = row - im * hws;
-                    const int j = rem / p.scat_w, i = rem - j * p.scat_w;
-                    orow = ((long long)im * 2 * p.scat_h + 2 * j + p.scat_py) * (2 * p.scat_w) + 2 * i + p.scat_px;
-                }
-                const long long idx = orow * p.ldc + col;
-                float v = acc[a][b][e] + sh;
-                if (p.residual && ok) v += p.residual[idx];
-                if (ok) p.C[idx] = v;
+        for (int e = 0; e < 16; ++e) {
+            const unsigned row = (unsigned)(m_blk + wm * 64 + a * 32 + 4 * lh + (e & 3) + 8 * (e >> 2));
+            if ((int)row >= p.M) continue;
+            long long orow = row;
+            if (p.scat_h > 0) {
+                const unsigned im = __umulhi(row, p.scat_mhw), rem = row - im * hws;
+                const unsigned j = __umulhi(rem, p.scat_mw), i = rem - j * (unsigned)p.scat_w;
+                orow = ((long long)im * 2 * p.scat_h + 2 * j + p.scat_py) * (2 * p.scat_w) + 2 * i + p.scat_px;
+            }
+            const long long obase = orow * p.ldc;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                if (colv[b] >= p.N) continue;
+                float v = acc[a][b][e] + sh[b];
+                if (p.residual) v += p.residual[obase + colv[b]];
+                p.C[obase + colv[b]] = v;
             }
         }
-    }
 #endif
 }
 

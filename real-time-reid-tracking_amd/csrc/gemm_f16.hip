@@ -396,36 +396,46 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
             }
             return;
         }
-        // (3) everything else (ConvTranspose parity scatter, f16 outputs with odd widths): element by element
+        // (3) everything else (ConvTranspose parity scatter, f16 outputs with odd widths): element by element, the output row of
+        // each of the lane's 32 rows computed once (divisions by multiply-high with host-made reciprocals)
+        float bias[TN];
+        int colv[TN];
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const int lcol = wn * WTN + b * 32 + li;
-            const int col = n_blk + lcol;
-            const bool col_ok = col < n_real;
-            const float bias = (p.col_shift && col_ok) ? p.col_shift[col] : 0.f;
+            colv[b] = n_blk + wn * WTN + b * 32 + li;
+            bias[b] = (p.col_shift && colv[b] < n_real) ? p.col_shift[colv[b]] : 0.f;
+        }
+        auto general = [&](auto scat_c) {
+            constexpr bool SCAT = decltype(scat_c)::value;
+            const unsigned hw = (unsigned)(p.scat_h * p.scat_w);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
-                    float v = acc[a][b][e] + bias;
-                    if (p.act == 1) v = gelu_f16_storage(v);
-                    if (rl < m_valid && col_ok) {
-                        long long orow = m_blk + rl;
-                        if (p.scat_h > 0) {   // ConvTranspose2d(4,2,1) output parity: (img, j, i) -> (img, 2j+py, 2i+px)
-                            const int hw = p.scat_h * p.scat_w;
-                            const int row = m_blk + rl;
-                            const int img = row / hw, rem = row - img * hw;
-                            const int jj = rem / p.scat_w, ii = rem - jj * p.scat_w;
-                            orow = ((long long)img * 2 * p.scat_h + 2 * jj + p.scat_py) * (2 * p.scat_w) + 2 * ii + p.scat_px;
-                        }
-                        const long long o = orow * ldc + col;
+                    if (rl >= m_valid) continue;
+                    const unsigned row = (unsigned)(m_blk + rl);
+                    long long orow = row;
+                    if constexpr (SCAT) {   // ConvTranspose2d(4,2,1) output parity: (img, j, i) -> (img, 2j+py, 2i+px)
+                        const unsigned img = __umulhi(row, p.scat_mhw), rem = row - img * hw;
+                        const unsigned jj = __umulhi(rem, p.scat_mw), ii = rem - jj * (unsigned)p.scat_w;
+                        orow = ((long long)img * 2 * p.scat_h + 2 * jj + p.scat_py) * (2 * p.scat_w) + 2 * ii + p.scat_px;
+                    }
+                    const long long obase = orow * ldc;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        if (colv[b] >= n_real) continue;
+                        float v = acc[a][b][e] + bias[b];
+                        if (p.act == 1) v = gelu_f16_storage(v);
+                        const long long o = obase + colv[b];
                         if (p.res32) v += p.res32[o];
                         if (p.C32) p.C32[o] = v;
                         else p.C[o] = (f16)v;
                     }
                 }
-        }
+        };
+        if (p.scat_h > 0) general(std::true_type{});
+        else general(std::false_type{});
 #endif
         return;
     }

@@ -73,6 +73,7 @@ struct GemmParams {
     // scat_h > 0: row m = (img, j, i) of a scat_h x scat_w grid is written to pixel (2j+scat_py, 2i+scat_px) of the
     // 2x up-sampled grid (one output parity of a ConvTranspose2d(4, 2, 1)); residual uses the same index.
     int act, scat_h, scat_w, scat_py, scat_px;
+    unsigned scat_mhw, scat_mw;   // ceil(2^32 / (scat_h * scat_w)), ceil(2^32 / scat_w): row -> (img, j, i) by multiply-high (set_scatter)
     // par4 != 0 (conv_f32_dma general variant): the FOUR output parities of a ConvTranspose2d(4, 2, 1) in one launch - the grid
     // is four copies of the tile grid, copy q = (py, px) uses weights B + q * par_stride, padding (1 - py, 1 - px), scatter (py, px)
     int par4;
@@ -112,6 +113,7 @@ struct Gemm16Params {
     float* C32;
     const float* res32;
     // conv3x3_f16.hip split-K (small launches): blocks per output tile, fp32 partial tiles, per-tile arrival counters
+    unsigned scat_mhw, scat_mw; // as GemmParams
     int par4;                   // as GemmParams.par4 (LIN im2col build): four ConvTranspose parities in one launch
     long long par_stride;
     int no_lean;                // experiments: bit 0 skips the staged LIN epilogue, bit 1 the fp32-stream one
@@ -119,6 +121,17 @@ struct Gemm16Params {
     float* splitk_ws;
     int* splitk_cnt;
 };
+
+// reciprocals for the scatter epilogues: floor(x / d) == umulhi(x, ceil(2^32 / d)) for x < 2^32 / d (rows of one pass: < 2^20)
+template <class P>
+inline void set_scatter(P& p, int scat_h, int scat_w, int py, int px) {
+    p.scat_h = scat_h; p.scat_w = scat_w; p.scat_py = py; p.scat_px = px;
+    p.scat_mhw = p.scat_mw = 0;
+    if (scat_h > 0) {
+        p.scat_mhw = (unsigned)(((1ull << 32) + (unsigned long long)(scat_h * scat_w) - 1) / (unsigned long long)(scat_h * scat_w));
+        p.scat_mw = (unsigned)(((1ull << 32) + (unsigned long long)scat_w - 1) / (unsigned long long)scat_w);
+    }
+}
 
 struct reid_ctx;
 int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, double flops, double bytes);

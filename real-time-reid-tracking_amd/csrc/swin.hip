@@ -716,7 +716,7 @@ int conv16(reid_ctx* ctx, const f16* zero_page, const f16* x, int n, int H, int 
     p.M = n * Ho * Wo; p.N = (Cout + 63) / 64 * 64; p.K = R * S * Cin;
     p.C = out16; p.C32 = out32; p.ldc = Cout;
     p.col_shift = bias; p.lin = 1; p.n_real = Cout; p.res32 = res32;
-    p.scat_h = scat_h; p.scat_w = scat_w; p.scat_py = py; p.scat_px = px;
+    set_scatter(p, scat_h, scat_w, py, px);
     p.zero_page = zero_page;
     return launch_gemm_f16(ctx, A16_IM2COL, p, REID_K_CONV_GEMM, 2.0 * p.M * Cout * p.K,
                            2.0 * ((double)n * H * W * Cin + (double)Cout * p.K) + (out32 ? 4.0 : 2.0) * p.M * Cout);
@@ -735,7 +735,7 @@ int conv_bias(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, const
     p.M = n * Ho * Wo; p.N = Cout; p.K = R * S * Cin;
     p.C = out; p.ldc = Cout;
     p.col_shift = bias; p.residual = residual;
-    p.scat_h = scat_h; p.scat_w = scat_w; p.scat_py = py; p.scat_px = px;
+    set_scatter(p, scat_h, scat_w, py, px);
     const double flops = 2.0 * p.M * Cout * p.K;
     const double bytes = 4.0 * ((double)n * H * W * Cin + (double)Cout * p.K + (double)p.M * Cout);
     if (ctx->f32_conv == 1 && conv_f32_general_supported(p)) return launch_conv_f32_general(ctx, p, REID_K_CONV_GEMM, flops, bytes);
@@ -755,7 +755,7 @@ int conv_transpose_parities(reid_ctx* ctx, const float* x, int n, int Hi, int Wi
     p.M = n * Hi * Wi; p.N = co; p.K = 4 * ci;
     p.C = out; p.ldc = co;
     p.col_shift = bias; p.residual = residual;
-    p.scat_h = Hi; p.scat_w = Wi;
+    set_scatter(p, Hi, Wi, 0, 0);
     if (ctx->f32_conv == 1 && conv_f32_general_supported(p)) {
         p.par4 = 1;
         p.par_stride = (long long)co * 4 * ci;
