@@ -637,14 +637,32 @@ __global__ __launch_bounds__(256) void swin_tail_partial_kernel(const float* __r
     const int per = (ntok + TAIL_SLICES - 1) / TAIL_SLICES;
     const int t0 = slice * per, t1 = t0 + per < ntok ? t0 + per : ntok;
     float a0 = 0.f, a1 = 0.f;
-    for (int t = t0 + wave; t < t1; t += 4) {
-        const float* xi = x + ((long long)img * ntok + t) * 96;
-        const float v0 = xi[lane], v1 = lane < 32 ? xi[64 + lane] : 0.f;
+    // x^p: p = 3 (the initial value of the learnable exponent) is two multiplies, anything else exp2(p log2 x) on the
+    // transcendental unit (x >= 1e-6 > 0) - ocml's powf cost this kernel more than its HBM traffic
+    const bool cube = p == 3.0f;
+    auto pw = [&](float v) { return cube ? v * v * v : __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(v)); };
+    auto token = [&](float v0, float v1) {
         const float mean = wsum(v0 + v1) / 96.f;
         const float d0 = v0 - mean, d1 = lane < 32 ? v1 - mean : 0.f;
         const float rstd = 1.0f / sqrtf(wsum(d0 * d0 + d1 * d1) / 96.f + 1e-6f);
-        a0 += powf(fmaxf(d0 * rstd * g0 + b0, 1e-6f), p);
-        if (lane < 32) a1 += powf(fmaxf(d1 * rstd * g1 + b1, 1e-6f), p);
+        a0 += pw(fmaxf(d0 * rstd * g0 + b0, 1e-6f));
+        if (lane < 32) a1 += pw(fmaxf(d1 * rstd * g1 + b1, 1e-6f));
+    };
+    int t = t0 + wave;
+    for (; t + 12 < t1; t += 16) {      // four tokens per wave and trip: their loads are in flight together
+        float u0[4], u1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* xi = x + ((long long)img * ntok + t + 4 * k) * 96;
+            u0[k] = xi[lane];
+            u1[k] = lane < 32 ? xi[64 + lane] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) token(u0[k], u1[k]);
+    }
+    for (; t < t1; t += 4) {
+        const float* xi = x + ((long long)img * ntok + t) * 96;
+        token(xi[lane], lane < 32 ? xi[64 + lane] : 0.f);
     }
     part[wave][lane] = a0;
     if (lane < 32) part[wave][64 + lane] = a1;
