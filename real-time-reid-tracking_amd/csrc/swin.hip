@@ -797,11 +797,16 @@ struct SwinBlockW {
 };
 struct SwinBlockW16 {
     const f16 *qkv, *out, *post, *fc1, *fc2;   // [N padded to a multiple of 64][K], zero rows past N
+    // to_out and post_proj (swin_transformer.py:226-231: two Linear layers with nothing in between) folded into one for the
+    // fp16-storage mode: W = W_post . W_out (fp32 GEMM at load time), b = W_post . b_out + b_post
+    const f16* fold;
+    const float* fold_b;
 };
 struct SwinWeights {
     bool loaded = false;
     float* blob = nullptr;
     f16* blob16 = nullptr;        // fp16-storage mode: the block linears
+    float* fold_bias = nullptr;   // folded biases of the twelve blocks, back to back
     SwinBlockW16 blk16[12];
     const f16 *merge16[4], *img16, *t16[3];   // patch merging, 8x8 alignment conv, ConvTranspose parities (rows padded to 64)
     f16* zero_page = nullptr;
@@ -824,6 +829,7 @@ void swin_release(reid_ctx* ctx) {
     if (it != r.end()) {
         if (it->second.blob) (void)hipFree(it->second.blob);
         if (it->second.blob16) (void)hipFree(it->second.blob16);
+        if (it->second.fold_bias) (void)hipFree(it->second.fold_bias);
         if (it->second.zero_page) (void)hipFree(it->second.zero_page);
         r.erase(it);
     }
@@ -914,7 +920,7 @@ extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats,
         size_t total = 0;
         for (int s = 0; s < 4; ++s) {
             const size_t c = kDims[s];
-            total += (size_t)kLayers[s] * (pad64(3 * c) * c + 2 * pad64(c) * c + pad64(4 * c) * c + pad64(c) * 4 * c);
+            total += (size_t)kLayers[s] * (pad64(3 * c) * c + 3 * pad64(c) * c + pad64(4 * c) * c + pad64(c) * 4 * c);
             if (s > 0) total += pad64(c) * 4 * kDims[s - 1];
         }
         total += (size_t)768 * 64 * 96;
@@ -931,8 +937,17 @@ extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats,
             return dst;
         };
         int b2 = 0;
+        size_t nbias = 0;
+        for (int s = 0; s < 4; ++s) nbias += (size_t)kLayers[s] * kDims[s];
+        HIP_TRY(hipMalloc((void**)&w.fold_bias, nbias * sizeof(float)));
+        float *d_t, *d_f;
+        REID_TRY(ctx_ws(ctx, "swin.fold.t", (size_t)768 * 768 * 4, (void**)&d_t));
+        REID_TRY(ctx_ws(ctx, "swin.fold.f", (size_t)768 * 768 * 4, (void**)&d_f));
+        std::vector<float> out_t, bf;
+        size_t bias_at = 0;
         for (int s = 0; s < 4; ++s) {
             const size_t c = kDims[s];
+            const std::string st = "s" + std::to_string(s + 1);
             for (int j = 0; j < kLayers[s]; ++j, ++b2) {
                 const SwinBlockW& k = w.blk[b2];
                 SwinBlockW16& h = w.blk16[b2];
@@ -941,6 +956,34 @@ extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats,
                 h.post = conv(k.post_w, c, c);
                 h.fc1 = conv(k.fc1_w, 4 * c, c);
                 h.fc2 = conv(k.fc2_w, c, 4 * c);
+                // fold: y = (x W_out^T + b_out) W_post^T + b_post = x (W_post W_out)^T + (W_post b_out + b_post)
+                const std::string b = st + ".b" + std::to_string(j);
+                const float* h_out = blob + tab[b + ".out.w"].first;
+                const float* h_ob = blob + tab[b + ".out.b"].first;
+                const float* h_post = blob + tab[b + ".post.w"].first;
+                const float* h_pb = blob + tab[b + ".post.b"].first;
+                out_t.resize(c * c);
+                bf.resize(c);
+                for (size_t r = 0; r < c; ++r)
+                    for (size_t q = 0; q < c; ++q) out_t[q * c + r] = h_out[r * c + q];
+                for (size_t r = 0; r < c; ++r) {
+                    double acc = h_pb[r];
+                    for (size_t q = 0; q < c; ++q) acc += (double)h_post[r * c + q] * h_ob[q];
+                    bf[r] = (float)acc;
+                }
+                HIP_TRY(hipMemcpyAsync(d_t, out_t.data(), c * c * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(hipMemcpyAsync(w.fold_bias + bias_at, bf.data(), c * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));   // the host vectors are reused for the next block
+                GemmParams g;
+                memset(&g, 0, sizeof(g));
+                g.A = k.post_w; g.lda = (long long)c;
+                g.B = d_t; g.ldb = (long long)c;
+                g.M = (int)c; g.N = (int)c; g.K = (int)c;
+                g.C = d_f; g.ldc = (long long)c;
+                REID_TRY(launch_gemm_f32(ctx, A_DENSE, E_BIAS, g, REID_K_CONV_GEMM, 0, 0));
+                h.fold = conv(d_f, c, c);
+                h.fold_b = w.fold_bias + bias_at;
+                bias_at += c;
             }
         }
         for (int s = 1; s < 4; ++s) w.merge16[s] = conv(w.merge_w[s], kDims[s], 4 * (size_t)kDims[s - 1]);
@@ -1008,9 +1051,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
     for (int s = 0; s < 4; ++s) {
         const int C = kDims[s], heads = kHeads[s];
         float* xcur = xs[s];
-        if (s == 0) {
-            HIP_TRY(hipMemcpyAsync(xcur, sfe, (size_t)T1 * 96 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        } else {
+        if (s > 0) {
             // PatchMerging = conv2x2 s2 with weights repacked to (kh, kw, c) order + bias (swin_transformer.py:263-275)
             if (ctx->precision == 1) {
                 f16* x16 = (f16*)lnb;   // f16 copy of the previous stage's output (the residual stream itself stays fp32)
@@ -1027,6 +1068,9 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
         for (int j = 0; j < kLayers[s]; ++j, ++bi) {
             const SwinBlockW& k = w.blk[bi];
             const int shifted = j & 1;
+            // the first block reads the ShadowFeatureExtraction output (kept for the top-down fusion) and writes stage 1's
+            // residual stream; every later block updates that stream in place
+            const float* xin = (s == 0 && j == 0) ? sfe : xcur;
             const long long ntask = (long long)n * (Hs / 7) * (Ws / 7) * heads;
             if (ctx->precision == 1) {
                 // fp16-storage mode: the five linears of the block (95 % of its MACs) on the f16 MFMA GEMM with fp32
@@ -1038,7 +1082,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 f16* tmp16 = (f16*)tmp;                // [T][C]
                 const int ldq = (3 * C + 63) / 64 * 64;
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 6);
-                launch_layernorm<f16>(ctx, xcur, T, C, k.ln1_g, k.ln1_b, ln16);
+                launch_layernorm<f16>(ctx, xin, T, C, k.ln1_g, k.ln1_b, ln16);
                 prof_end(ctx);
                 REID_TRY(linear16(ctx, ln16, T, C, C, h.qkv, nullptr, 3 * C, 0, nullptr, big16, nullptr, ldq));
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
@@ -1050,8 +1094,12 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                                        Hs, Ws, heads, shifted, k.pos, att16);
                 prof_end(ctx);
                 LAUNCH_CHECK();
-                REID_TRY(linear16(ctx, att16, T, C, C, h.out, k.out_b, C, 0, nullptr, tmp16, nullptr, C));
-                REID_TRY(linear16(ctx, tmp16, T, C, C, h.post, k.post_b, C, 0, xcur, nullptr, xcur, C));
+                if (ctx->swin_fold) {   // to_out . post_proj as one Linear (folded at load time)
+                    REID_TRY(linear16(ctx, att16, T, C, C, h.fold, h.fold_b, C, 0, xin, nullptr, xcur, C));
+                } else {
+                    REID_TRY(linear16(ctx, att16, T, C, C, h.out, k.out_b, C, 0, nullptr, tmp16, nullptr, C));
+                    REID_TRY(linear16(ctx, tmp16, T, C, C, h.post, k.post_b, C, 0, xin, nullptr, xcur, C));
+                }
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 6);
                 launch_layernorm<f16>(ctx, xcur, T, C, k.ln2_g, k.ln2_b, ln16);
                 prof_end(ctx);
@@ -1061,7 +1109,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
             }
             // x = x + post_proj(to_out(attn(LN(x))))
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
-            launch_layernorm<float>(ctx, xcur, T, C, k.ln1_g, k.ln1_b, lnb);
+            launch_layernorm<float>(ctx, xin, T, C, k.ln1_g, k.ln1_b, lnb);
             prof_end(ctx);
             REID_TRY(linear(ctx, lnb, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big));
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 16);
@@ -1074,7 +1122,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
             prof_end(ctx);
             LAUNCH_CHECK();
             REID_TRY(linear(ctx, att, T, C, k.out_w, k.out_b, C, 0, nullptr, tmp));
-            REID_TRY(linear(ctx, tmp, T, C, k.post_w, k.post_b, C, 0, xcur, xcur));
+            REID_TRY(linear(ctx, tmp, T, C, k.post_w, k.post_b, C, 0, xin, xcur));
             // x = x + fc2(gelu(fc1(LN(x))))
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
             launch_layernorm<float>(ctx, xcur, T, C, k.ln2_g, k.ln2_b, lnb);
