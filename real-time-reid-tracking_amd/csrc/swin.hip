@@ -407,16 +407,24 @@ __device__ __forceinline__ void softmax_scores(f32x16 (&acc)[2][2], const float*
 
 // fp16-storage mode: v_mfma_f32_32x32x16_f16, 8 MFMAs for S^T and 8 for P.V per (window, head)
 __global__ __launch_bounds__(256) void window_attn_mfma_f16_kernel(const f16* __restrict__ qkv, int ldq, int n_img, int H, int W,
-                                                                   int heads, int shifted, const float* __restrict__ pos,
+                                                                   int heads, int shifted, const float* __restrict__ bias_tab,
                                                                    f16* __restrict__ out) {
     constexpr int VP = 72;   // V^T row pitch in f16 (144 B)
     constexpr int ZP = 40;   // Z row pitch in f16 (80 B, 16-byte aligned rows)
-    __shared__ float sbias[64 * 64];
+    __shared__ __attribute__((aligned(16))) float sbias[64 * 64];
     __shared__ int kflag[64];
     __shared__ __attribute__((aligned(16))) f16 wbuf[4][64 * ZP];   // per wave: V^T [32][VP] (4 608 B), later Z [64][ZP] (5 120 B)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
-    build_bias_table(pos, sbias, kflag, 256);
+    // the layer's [key][query] bias table (expanded once at load time: build_bias_table's divisions and gathers cost every
+    // block ~15 % of its time) - 16 KB, four 16-byte loads per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *(float4*)(sbias + (threadIdx.x + 256 * i) * 4) = *(const float4*)(bias_tab + (threadIdx.x + 256 * i) * 4);
+    if (threadIdx.x < 64) {
+        const int key = threadIdx.x, jy = key / 7, jx = key - jy * 7;
+        kflag[key] = key < 49 ? ((jy >= 4 ? 1 : 0) | (jx >= 4 ? 2 : 0)) : 0;
+    }
     const int nwh = H / 7, nww = W / 7;
     const long long task = blockIdx.x * 4LL + wave;
     const long long ntask = (long long)n_img * nwh * nww * heads;
@@ -801,12 +809,14 @@ struct SwinBlockW16 {
     // fp16-storage mode: W = W_post . W_out (fp32 GEMM at load time), b = W_post . b_out + b_post
     const f16* fold;
     const float* fold_b;
+    const float* bias_tab;   // relative-position bias expanded to [key 64][query 64] fp32, -inf on padded keys (window_attn_mfma_f16_kernel)
 };
 struct SwinWeights {
     bool loaded = false;
     float* blob = nullptr;
     f16* blob16 = nullptr;        // fp16-storage mode: the block linears
     float* fold_bias = nullptr;   // folded biases of the twelve blocks, back to back
+    float* bias_tabs = nullptr;   // expanded relative-position bias tables of the twelve blocks
     SwinBlockW16 blk16[12];
     const f16 *merge16[4], *img16, *t16[3];   // patch merging, 8x8 alignment conv, ConvTranspose parities (rows padded to 64)
     f16* zero_page = nullptr;
@@ -830,6 +840,7 @@ void swin_release(reid_ctx* ctx) {
         if (it->second.blob) (void)hipFree(it->second.blob);
         if (it->second.blob16) (void)hipFree(it->second.blob16);
         if (it->second.fold_bias) (void)hipFree(it->second.fold_bias);
+        if (it->second.bias_tabs) (void)hipFree(it->second.bias_tabs);
         if (it->second.zero_page) (void)hipFree(it->second.zero_page);
         r.erase(it);
     }
@@ -940,6 +951,24 @@ extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats,
         size_t nbias = 0;
         for (int s = 0; s < 4; ++s) nbias += (size_t)kLayers[s] * kDims[s];
         HIP_TRY(hipMalloc((void**)&w.fold_bias, nbias * sizeof(float)));
+        {   // [key][query] bias tables of the MFMA attention kernel (same entries as build_bias_table)
+            std::vector<float> tabs((size_t)12 * 4096);
+            int bt = 0;
+            for (int s = 0; s < 4; ++s)
+                for (int j = 0; j < kLayers[s]; ++j, ++bt) {
+                    const float* pos = blob + tab["s" + std::to_string(s + 1) + ".b" + std::to_string(j) + ".pos"].first;
+                    for (int key = 0; key < 64; ++key)
+                        for (int query = 0; query < 64; ++query) {
+                            float b = 0.f;
+                            if (key >= 49) b = -INFINITY;
+                            else if (query < 49) b = pos[(key / 7 - query / 7 + 6) * 13 + (key % 7 - query % 7 + 6)];
+                            tabs[(size_t)bt * 4096 + key * 64 + query] = b;
+                        }
+                }
+            HIP_TRY(hipMalloc((void**)&w.bias_tabs, tabs.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(w.bias_tabs, tabs.data(), tabs.size() * sizeof(float), hipMemcpyHostToDevice));
+            for (int i = 0; i < 12; ++i) w.blk16[i].bias_tab = w.bias_tabs + (size_t)i * 4096;
+        }
         float *d_t, *d_f;
         REID_TRY(ctx_ws(ctx, "swin.fold.t", (size_t)768 * 768 * 4, (void**)&d_t));
         REID_TRY(ctx_ws(ctx, "swin.fold.f", (size_t)768 * 768 * 4, (void**)&d_f));
@@ -1088,7 +1117,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
                 if (ctx->swin_attn_mfma)
                     hipLaunchKernelGGL(window_attn_mfma_f16_kernel, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big16, ldq,
-                                       n, Hs, Ws, heads, shifted, k.pos, att16);
+                                       n, Hs, Ws, heads, shifted, h.bias_tab, att16);
                 else
                     hipLaunchKernelGGL(window_attn_kernel<f16>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big16, ldq, n,
                                        Hs, Ws, heads, shifted, k.pos, att16);
