@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w1, const float* __restrict__ w2,
                                                       const float* __restrict__ y, const float* __restrict__ sc, int rows,
                                                       float* __restrict__ out) {
-    __shared__ float pooled[512];
+    __shared__ __attribute__((aligned(16))) float pooled[512];
     __shared__ float hid[64];
     __shared__ __attribute__((aligned(16))) float gate[512];
     const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -235,15 +235,36 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
         pooled[ch] = (float)(acc / hw);
     }
     __syncthreads();
-    for (int m = wave; m < mid; m += 4) {
-        float acc = 0.f;
-        for (int ch = lane; ch < c; ch += 64) acc += w1[m * c + ch] * pooled[ch];
-        acc = wave_sum(acc);
-        if (lane == 0) hid[m] = fmaxf(acc, 0.f);
+    {   // hidden units: wave w owns m = w, w + 4, ...; every load of the wave is issued before the first reduction
+        // (one dependent load-reduce round per unit made this phase ~10 us at c = 512: it is what a tracking frame waits for)
+        const int c4v = c >> 2;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc[j] = 0.f;
+            const int m = wave + 4 * j;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c4 = lane + 64 * k;
+                if (m < mid && c4 < c4v) {
+                    const f32x4 wv = *(const f32x4*)(w1 + (long long)m * c + c4 * 4);
+                    const f32x4 pv = *(const f32x4*)(pooled + c4 * 4);
+                    acc[j] += wv.x * pv.x + wv.y * pv.y + wv.z * pv.z + wv.w * pv.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (wave + 4 * j < mid) {   // wave-uniform
+                const float v = wave_sum(acc[j]);
+                if (lane == 0) hid[wave + 4 * j] = fmaxf(v, 0.f);
+            }
+        }
     }
     __syncthreads();
     for (int ch = tid; ch < c; ch += 256) {
         float acc = 0.f;
+#pragma unroll 8
         for (int m = 0; m < mid; ++m) acc += w2[m * c + ch] * hid[m];
         gate[ch] = 1.0f / (1.0f + expf(-acc));
     }
