@@ -283,18 +283,37 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
     }
 }
 
-// ---- GeM (attention_pooling.py:58-60) + BNNeck (SERes18_IBN.py:268).  One block per image, thread = channel.
+// ---- GeM (attention_pooling.py:58-60) + BNNeck (SERes18_IBN.py:268).  grid (c / 64, images); 256 threads = 16 channel quads x
+// 16 pixel groups (one block per image with a thread per channel walked the 128 pixels serially: 150 us for a tracking frame).
 __global__ __launch_bounds__(256) void gem_neck_kernel(const float* __restrict__ x, int hw, int c,
                                                        const float* __restrict__ p_ptr, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float* __restrict__ gem_out,
                                                        float* __restrict__ emb) {
-    const int img = blockIdx.x;
+    __shared__ float part[16][64 + 1];
+    const int img = blockIdx.y, c0 = blockIdx.x * 64;
+    const int quad = threadIdx.x & 15, pg = threadIdx.x >> 4;
     const float p = p_ptr[0];
-    const float* xi = x + (long long)img * hw * c;
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-        float acc = 0.f;
-        for (int px = 0; px < hw; ++px) acc += powf(fmaxf(xi[(long long)px * c + ch], 1e-6f), p);
-        const float g = powf(acc / (float)hw, 1.0f / p);
+    const bool cube = p == 3.0f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xi = x + (long long)img * hw * c + c0 + quad * 4;
+    for (int px = pg; px < hw; px += 16) {
+        const f32x4 v = *(const f32x4*)(xi + (long long)px * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f = fmaxf(v[e], 1e-6f);
+            acc[e] += cube ? f * f * f : powf(f, p);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[pg][quad * 4 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += part[g][threadIdx.x];
+        const int ch = c0 + threadIdx.x;
+        const float m = t / (float)hw;
+        const float g = cube ? cbrtf(m) : powf(m, 1.0f / p);
         if (gem_out) gem_out[(long long)img * c + ch] = g;
         emb[(long long)img * c + ch] = g * scale[ch] + shift[ch];
     }
@@ -413,8 +432,9 @@ int launch_se_tail(reid_ctx* ctx, const float* stats, int n_img, int tiles, int 
 
 int launch_gem_neck(reid_ctx* ctx, const float* x, int n_img, int hw, int c, const float* p, const float* scale,
                     const float* shift, float* gem_out, float* emb) {
+    ARG_CHECK(c % 64 == 0);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 4.0);
-    hipLaunchKernelGGL(gem_neck_kernel, dim3(n_img), dim3(256), 0, ctx->stream, x, hw, c, p, scale, shift, gem_out, emb);
+    hipLaunchKernelGGL(gem_neck_kernel, dim3(c / 64, n_img), dim3(256), 0, ctx->stream, x, hw, c, p, scale, shift, gem_out, emb);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
