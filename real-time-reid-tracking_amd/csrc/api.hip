@@ -41,6 +41,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_BANK_FAST")) c->bank_fast = atoi(e);
     if (const char* e = getenv("REID_SIDE_COPY")) c->side_copy = atoi(e);
     if (const char* e = getenv("REID_F32_STEMPOOL")) c->f32_stem_pool = atoi(e);
+    if (const char* e = getenv("REID_F32_SPLITK")) c->f32_split_k = atoi(e);
     if (const char* e = getenv("REID_SWIN_FOLD")) c->swin_fold = atoi(e);
     if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
     if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);

@@ -393,11 +393,17 @@ __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p
     const int li = lane & 31, lh = lane >> 5;
 
     const int nnt = (p.N + BN - 1) / BN;
-    int mtile, ntile;
+    int mtile, ntile, ksplit = 0;
     {
         const int nwg = gridDim.x;
         const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        if constexpr (!GEN) {
+            if (p.split_k > 1) {   // SK blocks per output tile, each summing nk / SK of the K-tiles (small launches)
+                ksplit = L % p.split_k;
+                L /= p.split_k;
+            }
+        }
         if constexpr (GEN) {
             if (p.par4) {   // four ConvTranspose parities in one launch: copy q of the tile grid = parity (q >> 1, q & 1)
                 const int tiles = nwg >> 2, par = L / tiles;
@@ -456,10 +462,18 @@ __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p
         }
     }
     const int cpt = p.Cin / BK;
-    const int nk = p.R * p.S * cpt;
+    const int SK = (!GEN && p.split_k > 1) ? p.split_k : 1;
+    const int nk = p.R * p.S * cpt / SK;         // K-tiles of this block: [ksplit * nk, (ksplit + 1) * nk)
     const int wc4 = p.W * p.Cin * 4;
 
-    int l_r = 0, l_s = 0, l_cc = 0, l_k = 0;     // uniform: the K-tile the next stage() fetches
+    int l_r, l_s, l_cc, l_k;                     // uniform: the K-tile the next stage() fetches
+    {
+        const int kt0 = ksplit * nk, tap = kt0 / cpt;
+        l_cc = kt0 - tap * cpt;
+        l_r = tap / p.S;
+        l_s = tap - l_r * p.S;
+        l_k = kt0 * BK;
+    }
     auto stage = [&](int slot) {
         char* As = lds + slot * STAGE;
         char* Bs = As + A_BYTES;
@@ -554,6 +568,48 @@ __global__ __launch_bounds__(256, 2) void conv_f32_dma_kernel(const GemmParams p
         bias_epilogue<BN>(p, acc, m_blk, n_blk, tid);
     } else {
         __syncthreads();   // the epilogue reuses the tiles' LDS for the column statistics
+        if (SK > 1) {
+            // split-K (as conv3x3_f16.hip): fp32 partial tiles as device-scope (sc1) stores, an arrival counter per output tile,
+            // the block that arrives last sums the partials in split order (deterministic) and runs the epilogue.  No L2
+            // write-back / invalidate fence: the stores are written through, the loads bypass this XCD's L2.
+            constexpr int PART = BM * BN;
+            const int tile_id = mtile * nnt + ntile;
+            float* part = p.splitk_ws + (long long)tile_id * SK * PART;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        __hip_atomic_store(part + (long long)ksplit * PART + ((a * TN + b) * 16 + e) * 256 + tid, acc[a][b][e], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = (int*)lds;
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = old == SK - 1;
+                if (old == SK - 1) __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (!*flag) return;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+            for (int sidx = 0; sidx < SK; ++sidx)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            acc[a][b][e] += __hip_atomic_load(part + (long long)sidx * PART + ((a * TN + b) * 16 + e) * 256 + tid, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();   // the flag word is about to become statistics scratch
+        }
         conv_epilogue<BN>(p, acc, (float*)lds, m_blk, n_blk, mtile, tid);
     }
 #endif
@@ -565,8 +621,26 @@ bool conv_f32_dma_supported(const GemmParams& p) {
 }
 
 template <int BN>
-void launch_bn(reid_ctx* ctx, const GemmParams& p) {
-    const int grid = (p.M / BM) * (p.N / BN);
+void launch_bn(reid_ctx* ctx, const GemmParams& p0) {
+    GemmParams p = p0;
+    int grid = (p.M / BM) * (p.N / BN);
+    // a launch that leaves CUs idle or alone (a tracking frame): 2 or 4 blocks per output tile, each with a share of the K-tiles
+    if (BN == 64 && ctx->f32_split_k && !p.a_scale && ctx->f32_conv != 2 && conv_f32_dma_supported(p) && !p.diag) {
+        const int nk = p.R * p.S * (p.Cin / BK);
+        int sk = 1;
+        while (sk < 4 && grid * sk * 2 <= 512 && nk % (sk * 2) == 0 && nk / (sk * 2) >= 8) sk *= 2;
+        if (sk > 1 && grid <= 1024) {
+            float* ws;
+            int* cnt;
+            const bool fresh = ctx->ws.find("conv32.splitk_cnt") == ctx->ws.end();
+            if (ctx_ws(ctx, "conv32.splitk_ws", (size_t)grid * sk * BM * BN * sizeof(float), (void**)&ws) == REID_OK &&
+                ctx_ws(ctx, "conv32.splitk_cnt", 1024 * sizeof(int), (void**)&cnt) == REID_OK) {
+                if (fresh) (void)hipMemsetAsync(cnt, 0, 1024 * sizeof(int), ctx->stream);
+                p.split_k = sk; p.splitk_ws = ws; p.splitk_cnt = cnt;
+                grid *= sk;
+            }
+        }
+    }
     if (!p.a_scale && ctx->f32_conv != 2 && conv_f32_dma_supported(p)) {   // REID_F32_CONV=2: register-staged kernel everywhere (A/B)
         if (p.diag) hipLaunchKernelGGL((conv_f32_dma_kernel<BN, 1>), dim3(grid), dim3(256), 0, ctx->stream, p);
         else hipLaunchKernelGGL((conv_f32_dma_kernel<BN, 0>), dim3(grid), dim3(256), 0, ctx->stream, p);

@@ -73,6 +73,9 @@ struct GemmParams {
     // scat_h > 0: row m = (img, j, i) of a scat_h x scat_w grid is written to pixel (2j+scat_py, 2i+scat_px) of the
     // 2x up-sampled grid (one output parity of a ConvTranspose2d(4, 2, 1)); residual uses the same index.
     int act, scat_h, scat_w, scat_py, scat_px;
+    int split_k;           // conv_f32_dma (small launches): blocks per output tile, fp32 partial tiles, per-tile arrival counters
+    float* splitk_ws;
+    int* splitk_cnt;
     unsigned scat_mhw, scat_mw;   // ceil(2^32 / (scat_h * scat_w)), ceil(2^32 / scat_w): row -> (img, j, i) by multiply-high (set_scatter)
     // par4 != 0 (conv_f32_dma general variant): the FOUR output parities of a ConvTranspose2d(4, 2, 1) in one launch - the grid
     // is four copies of the tile grid, copy q = (py, px) uses weights B + q * par_stride, padding (1 - py, 1 - px), scatter (py, px)
@@ -268,6 +271,7 @@ struct reid_ctx {
                              // (REID_F16_STEMPOOL=1: from the padded f16 image, 0: GEMM + pool kernels)
     int f32_conv = 1;        // fp32 path (REID_F32_CONV): 1 = conv_f32.hip LDS-DMA kernel, norms in the producer's epilogue / in_apply;
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
+    int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
     int f32_stem_pool = 1;   // fp32 path: MaxPool(3,2,1) on the stem kernel's accumulators (REID_F32_STEMPOOL=0: separate kernel)
     int swin_fold = 1;       // Swin, fp16-storage mode: to_out and post_proj folded into one Linear (REID_SWIN_FOLD=0: two launches)
     int swin_attn_mfma = 1;  // Swin window attention (REID_SWIN_ATTN): 1 = matrix cores in fp16-storage mode, VALU kernel in exact fp32

@@ -108,15 +108,20 @@ def test_seres18_embed_matches_reference_fixture(eng, golden_dir, tag, crops_fn)
 
 def test_fused_stem_pool_is_the_same_for_whole_images_and_strips(eng_w0):
     """stem_f32.hip with the max-pool on its accumulators: 520 crops in one pass (a block walks a whole image) and in chunks of
-    40 (eight-tile strips, each recomputing the tile above it) run the same arithmetic per pixel - bit-identical embeddings."""
+    260 (32-tile strips, each recomputing the tile above it) run the same arithmetic per pixel - bit-identical embeddings.
+    (Chunks small enough for the split-K convolutions - a tracking frame - sum their K-tiles in another order: fp32 noise.)"""
     eng, _ = eng_w0
     crops = synth.smooth_crops_u8(520, seed=8)
     eng.set_chunk(1024)
     whole = eng.embed_u8(crops)
-    eng.set_chunk(40)
+    eng.set_chunk(260)
     strips = eng.embed_u8(crops)
+    eng.set_chunk(40)
+    small = eng.embed_u8(crops)
     eng.set_chunk(64)
     assert np.array_equal(whole, strips)
+    cos = (whole * small).sum(1) / np.linalg.norm(whole, axis=1) / np.linalg.norm(small, axis=1)
+    assert (1 - cos).max() < 1e-6 and np.abs(whole - small).max() < 1e-5 * np.abs(whole).max()
 
 
 def test_embed_ragged_resize_matches_oracle(eng_w0):
