@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
         constexpr bool LIN_LDS = BM * BN * 2 <= NST * STAGE;
         // (1) f16 outputs that are plain row-major (qkv, fc1): staged through LDS, leave as whole 16-byte pieces of a row
         const bool staged = LIN_LDS && !p.C32 && !p.res32 && p.scat_h == 0 && (n_real & 7) == 0;
-        if (staged && !(p.no_lean & 1)) {
+        if (staged) {
             f16* tile = (f16*)lds;
             auto fill = [&](auto act_c) {
                 constexpr bool ACT = decltype(act_c)::value;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
         // instruction; per-lane byte offset fixed per column block, row offset in the SGPR operand, columns past N fall outside
         // the descriptor and are dropped by the hardware
         // (the SGPR offset is not part of the range check: a tile with fewer than BM rows takes the general loop)
-        if (p.C32 && p.scat_h == 0 && (long long)BM * ldc * 4 < 0x7fffff00ll && m_valid >= BM && !(p.no_lean & 2)) {
+        if (p.C32 && p.scat_h == 0 && (long long)BM * ldc * 4 < 0x7fffff00ll && m_valid >= BM) {
             const int rows = BM;
             const int recs = (int)(((long long)(rows - 1) * ldc + n_real) * 4);
             const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C32 + (long long)m_blk * ldc), 0, recs, 0x00020000);

@@ -119,7 +119,6 @@ struct Gemm16Params {
     unsigned scat_mhw, scat_mw; // as GemmParams
     int par4;                   // as GemmParams.par4 (LIN im2col build): four ConvTranspose parities in one launch
     long long par_stride;
-    int no_lean;                // experiments: bit 0 skips the staged LIN epilogue, bit 1 the fp32-stream one
     int split_k;
     float* splitk_ws;
     int* splitk_cnt;

@@ -723,7 +723,6 @@ int linear16(reid_ctx* ctx, const f16* x, long long m, int lda, int k, const f16
     p.M = (int)m; p.N = (n + 63) / 64 * 64; p.K = k;
     p.C = out16; p.C32 = out32; p.ldc = ldc;
     p.col_shift = bias; p.lin = 1; p.act = act; p.n_real = n; p.res32 = res32;
-    { static const int nl = getenv("REID_NO_LEAN") ? atoi(getenv("REID_NO_LEAN")) : 0; p.no_lean = nl; }
     return launch_gemm_f16(ctx, A16_DENSE, p, REID_K_CONV_GEMM, 2.0 * m * n * k, 2.0 * ((double)m * k + (double)n * k) + (out32 ? 4.0 : 2.0) * m * n);
 }
 

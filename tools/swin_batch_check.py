@@ -1,3 +1,6 @@
+"""Swin fp16-storage mode: is an image's embedding independent of the batch it comes in, and are repeated runs identical?
+(The 64- and 128-wide instantiations of a linear round their epilogues differently: the tile shape must not depend on the batch.)
+    python tools/swin_batch_check.py            REID_F16_CFG=128323 forces one tile shape"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
