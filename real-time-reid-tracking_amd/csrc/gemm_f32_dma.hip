@@ -272,9 +272,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
 template <int EPI>
 void launch_epi(reid_ctx* ctx, const GemmParams& p) {
     const int nmt = (p.M + BM - 1) / BM;
-    // 64-wide tiles waste fewer padded columns on narrow / odd outputs (288, 192) but run ~12 % below the 128-wide tile per column
+    // Linear layers: the 64-wide tile everywhere - 149 VGPRs and 48 KB of LDS put THREE blocks on a CU (the 128-wide one: 223
+    // VGPRs, two blocks), which hides more of the short K loops' load latency; measured on every Swin shape after the epilogue
+    // rework (tools/bench_linear.py): 18.5 ms per pass against 18.9 (per-shape choice) and 19.4 (128-wide everywhere).
+    // Distance matrices (long K, square-ish) keep the per-column cost model: 64-wide tiles run ~12 % below per column.
     const double cost64 = ((p.N + 63) / 64) * 64 * 1.12, cost128 = ((p.N + 127) / 128) * 128;
-    if (p.N <= 64 || cost64 < cost128) {
+    if (EPI == E_BIAS || p.N <= 64 || cost64 < cost128) {
         hipLaunchKernelGGL((gemm_f32_dma_kernel<64, EPI>), dim3(nmt * ((p.N + 63) / 64)), dim3(256), 0, ctx->stream, p);
     } else {
         hipLaunchKernelGGL((gemm_f32_dma_kernel<128, EPI>), dim3(nmt * ((p.N + 127) / 128)), dim3(256), 0, ctx->stream, p);
