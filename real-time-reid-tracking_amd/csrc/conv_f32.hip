@@ -34,12 +34,12 @@ constexpr int LDP = 36;
 template <int BN>
 __device__ __forceinline__ void conv_epilogue(const GemmParams& p, f32x16 (&acc)[2][BN / 64], float* stat_lds, int m_blk, int n_blk,
                                               int mtile, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins: device pass only
     constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const bool has_cs = p.col_scale != nullptr;
-#if defined(__HIP_DEVICE_COMPILE__)
     // Output and residual through buffer instructions: per-lane byte offset fixed per column block, the row offset is a scalar
     // (SGPR soffset) - no per-element address arithmetic beside the other block's MFMAs, where a VALU instruction costs ~19 cycles.
     // Tiles are always full here (conv_f32_supported), so the unchecked scalar offset is safe.
@@ -679,10 +679,9 @@ int launch_conv_f32_general(reid_ctx* ctx, const GemmParams& p, int kind, double
     ARG_CHECK(conv_f32_general_supported(p));
     prof_begin(ctx, kind, flops, bytes);
     const int nmt = (p.M + BM - 1) / BM;
-    const double cost64 = ((p.N + 63) / 64) * 64 * 1.12, cost128 = ((p.N + 127) / 128) * 128;
     const int copies = p.par4 ? 4 : 1;   // the four ConvTranspose parities as one grid
-    if (p.N <= 64 || cost64 < cost128) hipLaunchKernelGGL((conv_f32_dma_kernel<64, 4>), dim3(nmt * ((p.N + 63) / 64) * copies), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((conv_f32_dma_kernel<128, 4>), dim3(nmt * ((p.N + 127) / 128) * copies), dim3(256), 0, ctx->stream, p);
+    // the 64-wide tile (three blocks per CU) on every shape: Swin fp32 8.65 -> 8.86 k img/s against the per-column cost model
+    hipLaunchKernelGGL((conv_f32_dma_kernel<64, 4>), dim3(nmt * ((p.N + 63) / 64) * copies), dim3(256), 0, ctx->stream, p);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
