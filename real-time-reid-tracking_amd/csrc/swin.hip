@@ -447,19 +447,15 @@ __global__ __launch_bounds__(256) void window_attn_mfma_f16_kernel(const f16* __
     };
     f16* vt = wbuf[wave];
     // V^T of this (window, head): lane = token, 32 dims -> vt[dim][token]; padded tokens are zero rows
-    {
-        half8 v[4];
+    // all three operands are requested before the first one is consumed (the V^T transposition used to wait for V alone, the
+    // Q / K loads for the transposition)
+    half8 v[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (live && lane < 49) {
-            const f16* base = qkv + token(lane) * ldq + 2 * C + head * 32;
+    for (int c = 0; c < 4; ++c) v[c] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (live && lane < 49) {
+        const f16* base = qkv + token(lane) * ldq + 2 * C + head * 32;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = *(const half8*)(base + c * 8);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) vt[(c * 8 + j) * VP + lane] = v[c][j];
+        for (int c = 0; c < 4; ++c) v[c] = *(const half8*)(base + c * 8);
     }
     // Q / K fragments: lane (li, lh) holds dims 8*lh .. +7 (k-step 0) and 16 + 8*lh .. (k-step 1) of tokens li and 32 + li
     half8 qf[2][2], kf[2][2];
@@ -474,6 +470,10 @@ __global__ __launch_bounds__(256) void window_attn_mfma_f16_kernel(const f16* __
             kf[t2][s2] = ok ? *(const half8*)(base + C + s2 * 16) : half8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vt[(c * 8 + j) * VP + lane] = v[c][j];
     __syncthreads();   // bias table ready (the wave's own V^T writes are ordered before its reads)
     if (!live) return;
     f32x16 acc[2][2];
