@@ -366,6 +366,8 @@ __device__ __forceinline__ void build_bias_table(const float* __restrict__ pos, 
 
 // scores of one lane: acc[kt][qt][e] = S^T[key = kt*32 + (e&3) + 8*(e>>2) + 4*(lane>>5)][query = qt*32 + (lane&31)]
 // -> probabilities (scale, bias, masks, softmax over the 64 keys of each query), in place
+// FAST (fp16-storage mode): exp as one v_exp_f32 of the log2e-scaled difference instead of ocml's expf
+template <bool FAST>
 __device__ __forceinline__ void softmax_scores(f32x16 (&acc)[2][2], const float* sbias, const int* kflag, int lane, bool last_row,
                                                bool last_col) {
     const int li = lane & 31, lh = lane >> 5;
@@ -392,7 +394,7 @@ __device__ __forceinline__ void softmax_scores(f32x16 (&acc)[2][2], const float*
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = expf(acc[kt][qt][e] - mx);
+                const float p = FAST ? __builtin_amdgcn_exp2f((acc[kt][qt][e] - mx) * 1.44269504088896340736f) : expf(acc[kt][qt][e] - mx);
                 acc[kt][qt][e] = p;
                 den += p;
             }
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256) void window_attn_mfma_f16_kernel(const f16* __
             for (int s2 = 0; s2 < 2; ++s2)
                 acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s2], qf[qt][s2], acc[kt][qt], 0, 0, 0);
         }
-    softmax_scores(acc, sbias, kflag, lane, shifted && wy == nwh - 1, shifted && wx == nww - 1);
+    softmax_scores<true>(acc, sbias, kflag, lane, shifted && wy == nwh - 1, shifted && wx == nww - 1);
     // O = P . V: A = registers 8*s2 .. 8*s2+7 of the S^T tile as f16 (element j of lane half h is key
     // 16*s2 + 8*(j>>2) + 4*h + (j&3) of the tile), B = V^T[dim = li][those keys]
     f32x16 z[2];
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(128) void window_attn_mfma_f32_kernel(const float* 
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kt], qb[qt], acc[kt][qt], 0, 0, 0);
     }
-    softmax_scores(acc, sbias, kflag, lane, shifted && wy == nwh - 1, shifted && wx == nww - 1);
+    softmax_scores<false>(acc, sbias, kflag, lane, shifted && wy == nwh - 1, shifted && wx == nww - 1);
     // O = P . V: register e of an S^T tile is the A operand of one k-step (keys (e&3) + 8*(e>>2) + 4*h of the tile)
     f32x16 z[2];
 #pragma unroll
