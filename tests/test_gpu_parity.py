@@ -487,6 +487,48 @@ def test_frame_pipeline_matches_the_synchronous_calls_and_the_oracle(eng_w0):
         eng.frame_update(0, pipe._bank, [99], [0])                 # row beyond the submitted frame
 
 
+def test_camera_stream_driver_equals_the_blocking_calls():
+    """tracking.CameraStream (own context, submit / step / commit) over four frames: features, gated appearance cost and DIoU cost
+    equal the blocking Extractor-style calls on another context."""
+    from reid_amd.engine import Engine
+    from reid_amd.iou_matching import iou_cost
+    from reid_amd.nn_matching import NearestNeighborDistanceMetric
+    from reid_amd.tracking import CameraStream
+    sd = synth.seres18_state_dict(0)
+    blob, manifest, _ = weights.pack_seres18(sd)
+    cam = CameraStream(blob, manifest, precision=0, max_dist=0.2, budget=4, max_tracks=8)
+    ref_eng = Engine(0)
+    ref_eng.load_seres18(blob, manifest)
+    ref = NearestNeighborDistanceMetric("cosine", 0.2, 4, max_tracks=8, engine=ref_eng)
+    pool = synth.ragged_crops_u8(12, seed=6)
+    frames = [pool[0:4], pool[3:9], pool[8:11], pool[2:7]]
+    rng = np.random.default_rng(2)
+    boxes = rng.uniform(0, 200, (8, 4))
+    boxes[:, 2:] = rng.uniform(10, 60, (8, 2))
+    tracks = []
+    cam.submit(frames[0])
+    try:
+        for f, crops in enumerate(frames):
+            m = len(crops)
+            feats, cost, ic = cam.step(tracks, boxes[:len(tracks)], boxes[:m], frames[f + 1] if f + 1 < len(frames) else None)
+            want = ref_eng.embed_ragged_u8(crops)
+            np.testing.assert_array_equal(feats, want)
+            if tracks:
+                np.testing.assert_array_equal(cost, ref.distance(want, tracks, max_distance=0.2))
+                np.testing.assert_array_equal(ic, iou_cost(boxes[:len(tracks)], boxes[:m]))
+            k = min(m, len(tracks))
+            rows, tg = list(range(k)), tracks[:k]
+            tracks.append(50 + f)
+            rows.append(k)
+            tg = tg + [50 + f]
+            cam.commit(rows, tg, tracks)
+            ref.partial_fit(want[rows], tg, tracks)
+    finally:
+        cam.close()
+        cam.eng.close()
+        ref_eng.close()
+
+
 def test_nn_matching_edge_cases(eng):
     from reid_amd.nn_matching import NearestNeighborDistanceMetric
     m = NearestNeighborDistanceMetric("cosine", 0.15, budget=3, max_tracks=2)
