@@ -556,7 +556,7 @@ def run_market(job, args):
            "config": {"workload": "BASELINE configs[4]: 3368 x 15913 x 512, gallery rows sharded over %d rank(s): shard distance matrix + "
                                   "top-%d per shard, all-gather (fp32 distances, int32 indices), device k-way merge" % (world, k)},
            "distmat_shard_ms": round(dist_ms, 3), "rank1_top%d" % k: rank1,
-           "roofline": {"kernel": "gemm_f32_kernel<dense, distance epilogue> (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+           "roofline": {"kernel": "gemm_f32_dma_kernel<E_DIST> (dense LDS-DMA GEMM + distance epilogue, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                         "achieved": round(flops / (dist_ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flops / (dist_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                         "algorithmic_bytes_per_launch": byts, "hbm_gbs": round(byts / (dist_ms * 1e-3) / 1e9, 1)}}

@@ -182,7 +182,7 @@ int reid_smooth_tracklets_dev(reid_ctx* ctx, float* d_x, const int32_t* seqs, co
  * d-dimensional features in HBM; the caller maps track ids to slots 0..max_tracks-1. */
 typedef struct reid_bank reid_bank;
 int reid_bank_create(reid_ctx* ctx, int max_tracks, int budget, int d, reid_bank** out);
-int reid_bank_destroy(reid_bank* bank);
+int reid_bank_destroy(reid_bank* bank);   /* before reid_ctx_destroy of its context */
 /* partial_fit: row i of feats[n][d] is appended to track slots[i], in call order (oldest samples fall out of the ring) */
 int reid_bank_update(reid_ctx* ctx, reid_bank* bank, const float* feats, const int32_t* slots, int n);
 int reid_bank_update_dev(reid_ctx* ctx, reid_bank* bank, const float* d_feats, const int32_t* slots, int n);

@@ -39,9 +39,15 @@ class NearestNeighborDistanceMetric:
         elif d != self._d:
             raise ValueError(f"feature dimension changed from {self._d} to {d}")
 
+    def close(self):
+        """Free the device bank (before its engine is closed: a bank belongs to a context)."""
+        if self._bank is not None and self._eng.h:
+            self._eng.lib.reid_bank_destroy(self._bank)
+        self._bank = None
+
     def __del__(self):
         try:
-            if self._bank is not None:
+            if self._bank is not None and self._eng.h:     # a closed engine has taken its context (and device) with it
                 self._eng.lib.reid_bank_destroy(self._bank)
         except Exception:
             pass

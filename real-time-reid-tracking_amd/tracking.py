@@ -21,6 +21,7 @@ from .nn_matching import NearestNeighborDistanceMetric
 class CameraStream:
     def __init__(self, weights_blob, manifest, precision=0, max_dist=0.15, budget=100, metric="cosine", device=0, own_context=True,
                  max_tracks=4096):
+        self._own = bool(own_context)
         self.eng = Engine(device) if own_context else get_engine(device)
         self.eng.load_seres18(weights_blob, manifest)
         self.eng.set_precision(precision)
@@ -48,5 +49,10 @@ class CameraStream:
         self.metric.frame_partial_fit(self._frame & 1, np.ascontiguousarray(rows, np.int32), targets, active_targets)
         self._frame += 1
 
-    def close(self):
+    def close(self, destroy=False):
+        """Drain the stream; destroy=True also frees the bank and, for an own context, the context."""
         self.eng.sync()
+        if destroy:
+            self.metric.close()
+            if self._own:
+                self.eng.close()

@@ -193,6 +193,24 @@ def test_knn_matches_oracle(eng):
     assert (I[:, 0] == np.r_[np.arange(40), np.arange(3)]).all()
 
 
+def test_knn_when_one_thread_holds_the_whole_top_k(eng):
+    """topk_rows_kernel keeps four candidates per thread; gallery rows 7, 263, 519, ... (the elements one thread visits) are
+    made the nearest neighbours of every query, so that thread's list runs dry and the row takes the exact fallback: the answer
+    must not change.  Also k larger than the gallery (padding with inf / -1)."""
+    rng = np.random.default_rng(9)
+    xb = rng.normal(size=(3000, 32)).astype(np.float32) + 4.0
+    xq = rng.normal(size=(6, 32)).astype(np.float32) * 0.01
+    near = np.arange(7, 3000, 256)                      # 12 rows, all visited by thread 7 of a 256-thread block
+    xb[near] = 0.001 * np.arange(1, len(near) + 1, dtype=np.float32)[:, None]
+    D, I = eng.knn(xq, xb, 10)
+    Dr, Ir = matching.knn_l2sqr(xq, xb, 10)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_allclose(D, Dr, rtol=1e-4, atol=1e-5)
+    assert set(I[0].tolist()) <= set(near.tolist())
+    D2, I2 = eng.knn(xq, xb[:5], 8)
+    assert (I2[:, 5:] == -1).all() and np.isinf(D2[:, 5:]).all() and (np.sort(I2[:, :5], 1) == np.arange(5)).all()
+
+
 def test_diou_bit_exact(eng, golden_dir):
     g = np.load(os.path.join(golden_dir, "matching.npz"))
     demo = eng.diou([10, 12, 8, 9], [[9, 10, 9, 9], [8, 12, 9, 10], [10, 12, 9, 8]])
@@ -524,8 +542,8 @@ def test_camera_stream_driver_equals_the_blocking_calls():
             cam.commit(rows, tg, tracks)
             ref.partial_fit(want[rows], tg, tracks)
     finally:
-        cam.close()
-        cam.eng.close()
+        cam.close(destroy=True)
+        ref.close()
         ref_eng.close()
 
 
