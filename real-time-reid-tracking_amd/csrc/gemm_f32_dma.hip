@@ -180,13 +180,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                 }
         }
     };
-    auto dist_epilogue = [&](const Desc& d) {   // ragged edges predicated
+    // distance epilogue: metric chosen at compile time; full-height tiles store through the buffer path of the linear epilogue
+    // (row offset in the SGPR operand, columns past N dropped by the descriptor), the ragged last row of tiles element by element
+    auto dist_epilogue = [&](const Desc& d, auto metric_c) {
+        constexpr int METRIC = decltype(metric_c)::value;
+        const int ldc = (int)p.ldc;
+        const bool full = d.rows_a == BM && (long long)BM * ldc * 4 < 0x7fffff00ll;
+        const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long long)d.m_blk * ldc), 0,
+                                                                              (int)(((long long)(BM - 1) * ldc + p.N) * 4), 0x00020000);
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int col = d.n_blk + wn * WN + b * 32 + li;
             const bool colok = col < p.N;
             float cq = (colok && p.col_sq) ? p.col_sq[col] : 0.f;
-            if (p.metric == REID_METRIC_COS_HALF || p.metric == REID_METRIC_COS) cq = sqrtf(cq);
+            if (METRIC == REID_METRIC_COS_HALF || METRIC == REID_METRIC_COS) cq = sqrtf(cq);
+            const int voff = colok ? ((wm * 64 + 4 * lh) * ldc + col) * 4 : 0x7fffff00;
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 const int row0 = d.m_blk + wm * 64 + a * 32 + 4 * lh;
@@ -204,17 +212,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int row = row0 + (e & 3) + 8 * (e >> 2);
                     float v = acc[a][b][e];
                     const float rs = rsq[e];
-                    switch (p.metric) {
-                        case REID_METRIC_L2: v = sqrtf(fmaxf((rs + cq) - 2.0f * v, 1e-12f)); break;
-                        case REID_METRIC_L2SQR: v = (rs + cq) - 2.0f * v; break;
-                        case REID_METRIC_COS_HALF: v = (1.0f - v / (sqrtf(rs) * cq)) / 2.0f; break;
-                        case REID_METRIC_COS: v = 1.0f - v / (sqrtf(rs) * cq); break;
-                        default: break;
+                    if (METRIC == REID_METRIC_L2) v = sqrtf(fmaxf((rs + cq) - 2.0f * v, 1e-12f));
+                    else if (METRIC == REID_METRIC_L2SQR) v = (rs + cq) - 2.0f * v;
+                    else if (METRIC == REID_METRIC_COS_HALF) v = (1.0f - v / (sqrtf(rs) * cq)) / 2.0f;
+                    else if (METRIC == REID_METRIC_COS) v = 1.0f - v / (sqrtf(rs) * cq);
+                    if (full) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff, (a * 32 + (e & 3) + 8 * (e >> 2)) * ldc * 4, 0);
+                    } else {
+                        const int row = row0 + (e & 3) + 8 * (e >> 2);
+                        if (colok && row < p.M) p.C[(long long)row * p.ldc + col] = v;
                     }
-                    if (colok && row < p.M) p.C[(long long)row * p.ldc + col] = v;
                 }
             }
         }
@@ -264,7 +273,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
             bias_general(cur);
         }
     } else {
-        dist_epilogue(cur);
+        switch (p.metric) {
+            case REID_METRIC_L2: dist_epilogue(cur, std::integral_constant<int, REID_METRIC_L2>{}); break;
+            case REID_METRIC_L2SQR: dist_epilogue(cur, std::integral_constant<int, REID_METRIC_L2SQR>{}); break;
+            case REID_METRIC_COS_HALF: dist_epilogue(cur, std::integral_constant<int, REID_METRIC_COS_HALF>{}); break;
+            case REID_METRIC_COS: dist_epilogue(cur, std::integral_constant<int, REID_METRIC_COS>{}); break;
+            default: dist_epilogue(cur, std::integral_constant<int, -1>{}); break;   // plain dot products
+        }
     }
 #endif
 }
