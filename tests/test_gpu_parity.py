@@ -547,6 +547,53 @@ def test_camera_stream_driver_equals_the_blocking_calls():
         ref_eng.close()
 
 
+def test_two_camera_streams_on_two_threads_do_not_disturb_each_other():
+    """Two CameraStreams (own contexts) driven concurrently from two host threads give, frame by frame, what each gives alone."""
+    import threading
+    from reid_amd.tracking import CameraStream
+    sd = synth.seres18_state_dict(0)
+    blob, manifest, _ = weights.pack_seres18(sd)
+    pool = synth.ragged_crops_u8(16, seed=7)
+    boxes = np.random.default_rng(4).uniform(5, 150, (8, 4))
+
+    def drive(cam, shift, out):
+        frames = [[pool[(shift + 3 * f + i) % 16] for i in range(3 + (f + shift) % 4)] for f in range(12)]
+        tracks = []
+        cam.submit(frames[0])
+        for f, crops in enumerate(frames):
+            m = len(crops)
+            feats, cost, ic = cam.step(tracks, boxes[:len(tracks)], boxes[:m], frames[f + 1] if f + 1 < len(frames) else None)
+            out.append((feats.copy(), cost.copy()))
+            k = min(m, len(tracks))
+            rows, tg = list(range(k)), tracks[:k]
+            if len(tracks) < 6:
+                tracks.append(10 * shift + f)
+                rows.append(min(k, m - 1))
+                tg = tg + [10 * shift + f]
+            cam.commit(rows, tg, tracks)
+        cam.close()
+
+    cams = [CameraStream(blob, manifest, precision=1, max_dist=0.3, budget=3, max_tracks=8) for _ in range(4)]
+    try:
+        alone = [[], []]
+        for c in range(2):
+            drive(cams[c], c + 1, alone[c])
+        together = [[], []]
+        th = [threading.Thread(target=drive, args=(cams[2 + c], c + 1, together[c])) for c in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for c in range(2):
+            assert len(alone[c]) == len(together[c]) == 12
+            for (fa, ca), (fb, cb) in zip(alone[c], together[c]):
+                np.testing.assert_array_equal(fa, fb)
+                np.testing.assert_array_equal(ca, cb)
+    finally:
+        for cam in cams:
+            cam.close(destroy=True)
+
+
 def test_nn_matching_edge_cases(eng):
     from reid_amd.nn_matching import NearestNeighborDistanceMetric
     m = NearestNeighborDistanceMetric("cosine", 0.15, budget=3, max_tracks=2)
