@@ -402,27 +402,40 @@ def run_tracking(job, args):
         return [pool[(f * 7 + i) % 256] for i in range(int(counts[f]))]
 
     def run_pipelined(first, last, lat):
-        """One GPU: the three-stage frame pipeline (csrc/bank.hip) - frame f+1 is packed into pinned memory, uploaded and embedded
-        while frame f's costs come back and its update is enqueued; one synchronisation per frame."""
+        """The frame pipeline (csrc/bank.hip), any number of ranks: this rank's round-robin share of frame f+1 is packed into
+        pinned memory, uploaded and embedded while frame f's costs come back and its update is enqueued; the ranks' embeddings
+        meet in ONE device-side all-gather per frame (reid_frame_gather), every rank then holds the frame's features in the
+        slot and computes the full cost matrices, as DeepSORT would on every rank.  One wait per frame."""
+        def share(f):
+            return [pool[(f * 7 + int(i)) % 256] for i in parallel.round_robin(int(counts[f]), world, rank)]
+
         t_sub = {first: time.perf_counter()}
-        eng.frame_submit(first & 1, crops_of(first))
+        eng.frame_submit(first & 1, share(first))
         total = 0
         for f in range(first, last):
             slot = f & 1
             n = int(counts[f])
-            metric.frame_distance_begin(slot, tracks, 0.15, boxes[:40], boxes[:n])   # queued behind forward(f)
+            rows, per = parallel.frame_rows(n, world)          # detection i -> row of the gathered slot
+            t0 = time.perf_counter()
+            eng.frame_gather(slot, per, world)
+            dets = np.tile(np.asarray([0.0, 0.0, 1.0, 1.0]), (world * per, 1))
+            dets[rows] = boxes[:n]
+            metric.frame_distance_begin(slot, tracks, 0.15, boxes[:40], dets)   # queued behind forward(f) and the gather
             if f + 1 < last:
                 t_sub[f + 1] = time.perf_counter()
-                eng.frame_submit(slot ^ 1, crops_of(f + 1))                           # forward(f+1) runs under the host's work
-            feats, cost, icost = metric.frame_distance_end(slot)
+                eng.frame_submit(slot ^ 1, share(f + 1))                        # forward(f+1) runs under the host's work
+            feats_g, cost_g, icost_g = metric.frame_distance_end(slot)
+            if world > 1:
+                gather_us.append((time.perf_counter() - t0) * 1e6)              # gather + costs + the frame's wait
+            feats, cost, icost = feats_g[rows], cost_g[:, rows], icost_g[:, rows]
             k = min(n, 40)
-            metric.frame_partial_fit(slot, np.arange(k, dtype=np.int32), tracks[:k], tracks)
+            metric.frame_partial_fit(slot, rows[:k].astype(np.int32), tracks[:k], tracks)
             lat.append(time.perf_counter() - t_sub.pop(f))
             total += n
         eng.sync()
         return total
 
-    pipelined = world == 1 and not args.no_pipeline
+    pipelined = not args.no_pipeline
     if pipelined:
         run_pipelined(0, 3, [])
     else:
@@ -468,7 +481,7 @@ def run_tracking(job, args):
         cpu = {"value": round(fc / elc, 2), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "%d frames, %d crops (%.1f s): oracle preprocess + oracle/seres18.py + numpy bank cost + DIoU" % (fc, cc, elc)}
     multi = None
-    if pipelined and args.cameras > 1:
+    if pipelined and world == 1 and args.cameras > 1:
         # several camera streams on the one GPU: own context (HIP stream, workspaces, bank) and host thread each
         import threading
         from reid_amd.tracking import CameraStream
@@ -505,7 +518,8 @@ def run_tracking(job, args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[3] stand-in: %d frames, %d crops (Poisson(30) per frame, ragged sizes), round-robin over "
                                    "the ranks, all-gather of [n_f,512], bank cost (40 tracks x 100) + DIoU" % (frames, ncrops),
-                       "host_flow": "frame pipeline: cost f | submit f+1 | fetch f (the one wait) | update f" if pipelined else "one synchronous call per operation"},
+                       "host_flow": ("frame pipeline: " + ("device all-gather f | " if world > 1 else "") + "cost f | submit f+1 | fetch f (the one wait) | update f")
+                                    if pipelined else "one synchronous call per operation"},
             "crops_per_s": round(ncrops / elapsed, 1), "ms_per_frame_median": round(float(np.median(lat)), 3),
             "ms_per_frame_p95": round(float(np.percentile(lat, 95)), 3),
             "allgather_us_median": round(float(np.median(gather_us)), 1) if gather_us else None}

@@ -213,6 +213,11 @@ int reid_frame_submit(reid_ctx* ctx, int slot, const uint8_t* packed, const int6
 int reid_frame_cost(reid_ctx* ctx, int slot, reid_bank* bank, const int32_t* slots, int t, int metric, float max_dist,
                     const double* tracks_t4, const double* dets_m4, int want_emb);
 int reid_frame_fetch(reid_ctx* ctx, int slot, float* emb, float* cost_tm, double* iou_tm);
+/* multi-GPU frames (every rank embeds its round-robin share of the frame's crops): between submit and
+ * cost, gather the ranks' embeddings into the slot as equal blocks of per = ceil(n / world) rows - one ncclAllGather; the slot
+ * then holds world * per rows (row r * per + i = detection r + i * world; rows past a rank's share are padding) on every rank.
+ * Asynchronous; without a communicator (reid_comm_init) a no-op. */
+int reid_frame_gather(reid_ctx* ctx, int slot, int per);
 int reid_frame_update(reid_ctx* ctx, int slot, reid_bank* bank, const int32_t* rows, const int32_t* slots, int n);
 /* retrieval evaluation, reid/evaluate.py:33-105: for every query the ranks of its good gallery items among
  * non-junk items (descending similarity gf@q).  cmc_sum int32[ng] = sum over valid queries of the CMC step,

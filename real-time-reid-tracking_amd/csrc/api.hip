@@ -895,7 +895,7 @@ int embed_ragged_enqueue(reid_ctx* ctx, const char* tag, const uint8_t* packed, 
     REID_TRY(ctx_ws(ctx, (t + ".meta").c_str(), (size_t)n * 16, (void**)&d_meta));
     long long* d_off = (long long*)d_meta;
     int* d_hw = (int*)(d_meta + (size_t)n * 8);
-    REID_TRY(ctx_ws(ctx, (t + ".emb").c_str(), (size_t)n * 512 * 4, (void**)&d_emb));
+    REID_TRY(ctx_ws(ctx, (t + ".emb").c_str(), (size_t)(n + 1) * 512 * 4, (void**)&d_emb));   // + 1: the padding row of reid_frame_gather
     if (d_log_out) REID_TRY(ctx_ws(ctx, (t + ".logits").c_str(), (size_t)n * nc * 4 + 16, (void**)&d_log));
     // side_copy (frame pipeline, pinned sources): the upload runs on a copy stream beside the previous frame's kernels
     hipStream_t cs = ctx->stream;

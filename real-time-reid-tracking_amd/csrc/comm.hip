@@ -9,6 +9,7 @@
 // librccl is opened with dlopen on first use: a single-GPU user never loads it.  Without a communicator (world 1) every entry
 // point degrades to the local copy, so callers need no special case.
 #include "reid_internal.h"
+#include <string>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string.h>
@@ -200,6 +201,28 @@ extern "C" int reid_allgather_dev(reid_ctx* ctx, const void* d_send, void* d_rec
     }
     if (bytes % 4 == 0) RCCL_TRY(g_rccl.AllGather(d_send, d_recv, bytes / 4, ncclInt32, c->comm, ctx->stream));
     else RCCL_TRY(g_rccl.AllGather(d_send, d_recv, bytes, ncclInt8, c->comm, ctx->stream));
+    return REID_OK;
+}
+
+// Multi-GPU frames ("per-frame tracking uses the same all-gather"): every rank has submitted its round-robin share
+// of a frame's crops to frame slot `slot` (reid_frame_submit); this gathers the ranks' embeddings into the slot as equal blocks
+// of `per` = ceil(n / world) rows (ONE ncclAllGather of per x 512 floats per rank; a rank with fewer rows sends padding).
+// Afterwards the slot holds world * per rows - row r * per + i is detection r + i * world of the frame - and
+// reid_frame_cost / _fetch / _update work on that matrix on every rank.  Asynchronous; a no-op without a communicator.
+extern "C" int reid_frame_gather(reid_ctx* ctx, int slot, int per) {
+    ARG_CHECK(ctx && (slot == 0 || slot == 1) && per >= 0);
+    CTX_GUARD(ctx);
+    const int world = ctx->comm ? ctx->comm->world : 1;
+    ARG_CHECK(ctx->frame_m[slot] <= per && per <= ctx->frame_m[slot] + 1);   // round-robin shares differ by at most one crop
+    if (!ctx->comm || !ctx->comm->comm || per == 0) return REID_OK;   // (a 1-rank communicator still runs the collective: tests)
+    const std::string tag = slot ? "frame1" : "frame0";
+    float *d_loc = ctx->frame_emb[slot], *d_all;
+    if (!d_loc) REID_TRY(ctx_ws(ctx, (tag + ".emb").c_str(), (size_t)(per + 1) * 2048, (void**)&d_loc));   // this rank had no crop
+    REID_TRY(ctx_ws(ctx, (tag + ".all").c_str(), (size_t)world * per * 2048, (void**)&d_all));
+    REID_TRY(reid_allgather_dev(ctx, d_loc, d_all, (size_t)per * 2048));
+    ctx->frame_emb[slot] = d_all;
+    ctx->frame_m[slot] = world * per;
+    ctx->frame_pending[slot] = 1;
     return REID_OK;
 }
 

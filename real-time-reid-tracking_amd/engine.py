@@ -210,6 +210,13 @@ class Engine:
         self.__dict__.setdefault("_frame_n", {})[slot] = n
         return n
 
+    def frame_gather(self, slot, per, world):
+        """Multi-GPU frames: all-gather the ranks' embeddings of the submitted frame into the slot (equal blocks of `per` rows);
+        the slot then holds world * per rows on every rank (`parallel.frame_rows` maps detections to them)."""
+        check(self.lib.reid_frame_gather(self.h, int(slot), int(per)))
+        if per > 0:
+            self._frame_n[slot] = int(world) * int(per)
+
     def frame_cost(self, slot, bank=None, slots=None, metric=0, max_dist=-1.0, track_boxes=None, det_boxes=None, want_emb=True):
         """Stage 2 (asynchronous): enqueue the appearance cost / DIoU cost of the submitted frame; `frame_fetch` collects."""
         m = self._frame_n[slot]

@@ -38,6 +38,14 @@ def round_robin(n, world, rank):
     return np.arange(rank, n, world)
 
 
+def frame_rows(n, world):
+    """Row of detection i in a frame slot after `Engine.frame_gather` (rank i % world holds it as its (i // world)-th crop and
+    contributes a block of per = ceil(n / world) rows).  Returns (rows int64[n], per)."""
+    per = (int(n) + int(world) - 1) // int(world)
+    i = np.arange(int(n), dtype=np.int64)
+    return (i % world) * per + i // world, per
+
+
 def merge_topk(d_parts, i_parts, k):
     """k-way merge of per-shard top-k lists on the host.  d_parts/i_parts: lists of [nq, k_r] arrays with GLOBAL indices.
     Returns (D float32[nq,k] ascending, I int32[nq,k]); ties -> lowest global index (the engine's rule; the device merge

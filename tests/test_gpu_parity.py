@@ -968,6 +968,19 @@ def test_rccl_single_rank_communicator_and_device_resident_sharding(eng_w0):
         assert np.array_equal(emb_all.numpy(), want)
         block = parallel.distmat_row_block(eng, emb_all, 2, 7, _ffi.METRIC_L2)
         assert np.array_equal(block.numpy(), eng.distmat(want[2:7], want, _ffi.METRIC_L2))
+        # the frame pipeline's device-side gather (reid_frame_gather) through the 1-rank communicator: one block of per rows
+        from reid_amd.nn_matching import NearestNeighborDistanceMetric
+        fc = synth.ragged_crops_u8(5, seed=2)
+        metric = NearestNeighborDistanceMetric("cosine", 0.5, 3, max_tracks=4)
+        want_f = eng.embed_ragged_u8(fc)
+        metric.partial_fit(want_f[:2], [1, 2], [1, 2])
+        rows, per = parallel.frame_rows(5, 1)
+        eng.frame_submit(0, fc)
+        eng.frame_gather(0, per, 1)
+        feats, cost, _ = metric.frame_distance(0, [1, 2], max_distance=0.5)
+        np.testing.assert_array_equal(feats[rows], want_f)
+        np.testing.assert_array_equal(cost[:, rows], metric.distance(want_f, [1, 2], max_distance=0.5))
+        metric.close()
         xb = np.random.default_rng(6).normal(size=(301, 64)).astype(np.float32)
         xq = xb[:11] + 0.01
         D, I = parallel.knn_gallery_sharded(eng, xq, xb, 7, comm=comm)

@@ -88,6 +88,21 @@ def test_shard_bounds_and_merge():
     assert I.tolist() == [[4, 0, 1, 12]] and D.dtype == np.float32     # tie at 0.5 -> lower global index first
 
 
+def test_frame_rows_maps_detections_into_the_gathered_slot():
+    """parallel.frame_rows: after reid_frame_gather rank r contributes a block of per rows holding its round-robin share in
+    order; detection i must be found at row (i % world) * per + i // world, padding rows are never addressed."""
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 5, 8, 30, 31):
+            rows, per = parallel.frame_rows(n, world)
+            assert per == -(-n // world) and len(rows) == n and len(set(rows.tolist())) == n
+            slot = np.full(world * per, -1)
+            for r in range(world):
+                mine = parallel.round_robin(n, world, r)
+                assert len(mine) <= per <= len(mine) + 1 or n == 0
+                slot[r * per: r * per + len(mine)] = mine
+            assert (slot[rows] == np.arange(n)).all()
+
+
 # ----------------------------------------------------------------------------- RCCL bootstrap (no GPU: the C calls are recorded)
 class _FakeLib:
     """Stands in for libreid_hip.so's communicator entry points: records what each rank hands to reid_comm_init."""
