@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256, 2) void stem_f32_kernel(const void* __restrict
     __shared__ __attribute__((aligned(16))) float w_lds[64 * WP];
     __shared__ __attribute__((aligned(16))) float in_lds[2][ROWS * PITCH];
     __shared__ float edge[2][4][64];     // POOL: column 15 of every wave's vertical maxima, by tile parity
+    __shared__ float norm_lut[256];      // U8: (v / 255 - 0.5) / 0.5 of every byte value - the two IEEE divisions once per block,
+                                         // not ~25 VALU instructions per pixel value beside the MFMAs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int nseg = (OUT_H / 2) / tiles_per_block;
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(256, 2) void stem_f32_kernel(const void* __restrict
         w_lds[nrow * WP + k] = wgt[nrow * 192 + k];
     }
     for (int i = tid; i < 64 * 4; i += 256) w_lds[(i >> 2) * WP + 168 + (i & 3)] = 0.f;
+    if constexpr (U8) norm_lut[tid] = ((float)tid / 255.0f - 0.5f) / 0.5f;   // feature_extractor.py:41-46, same arithmetic
     __syncthreads();
 
     // ---- staging: 16 consecutive channel values of one input row per thread and step
@@ -88,8 +91,7 @@ __global__ __launch_bounds__(256, 2) void stem_f32_kernel(const void* __restrict
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const float v = (float)((raw[s][q] >> (8 * b)) & 0xffu);
-                        dst[q * 4 + b] = inside ? (v / 255.0f - 0.5f) / 0.5f : 0.f;   // feature_extractor.py:41-46
+                        dst[q * 4 + b] = inside ? norm_lut[(raw[s][q] >> (8 * b)) & 0xffu] : 0.f;
                     }
             } else {
                 float* dst = buf + row * PITCH + 9 + piece * 4;
