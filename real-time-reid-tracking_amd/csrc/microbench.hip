@@ -169,7 +169,8 @@ extern "C" int reid_debug_feed(reid_ctx* ctx, int mode, size_t footprint, int ro
 // Co-issue experiment for the exact-fp32 path: what does a wave that stages data (VALU / LDS writes / global loads) get to
 // issue while the OTHER wave of its SIMD runs back-to-back v_mfma_f32_32x32x2_f32?  512-thread blocks, one per CU: waves 0-3
 // run `iters` x 16 MFMAs (4 accumulators), waves 4-7 run `iters` x 64 operations of `mode` (0 v_fma_f32, 1 ds_write_b128,
-// 2 global_load_dwordx4 + wait every 8, 3 v_fma with s_setprio 3).  `roles`: bit 0 = MFMA waves active, bit 1 = other waves active.
+// 2 global_load_dwordx4 + wait every 8, 3 v_fma with s_setprio 3).  `roles`: bit 0 = MFMA waves active, bit 1 = other waves active,
+// bit 2 = the MFMA waves issue v_mfma_f32_32x32x16_f16 instead.
 // Output: median cycles per wave of each role.
 namespace {
 typedef float f32x16cb __attribute__((ext_vector_type(16)));
@@ -192,9 +193,20 @@ __global__ __launch_bounds__(512) void coissue_kernel(int iters, int roles, cons
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
             const float av = src[lane], bv = src[64 + lane];
-            for (int it = 0; it < iters; ++it) {
+            if (roles & 4) {   // the same experiment beside v_mfma_f32_32x32x16_f16 (8 passes instead of 16)
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                h8 ah, bh;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j & 3], 0, 0, 0);
+                for (int e = 0; e < 8; ++e) { ah[e] = (_Float16)av; bh[e] = (_Float16)bv; }
+                for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j & 3], 0, 0, 0);
+                }
+            } else {
+                for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j & 3], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a) keep += acc[a][0] + acc[a][7];

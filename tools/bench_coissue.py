@@ -24,3 +24,9 @@ for mode in (0, 3, 1, 2):
     nm, no = iters * 16, iters * 64
     print("%-28s MFMA wave alone %.1f cyc/MFMA | other wave alone %.1f cyc/op | together: %.1f cyc/MFMA, %.1f cyc/op"
           % (names[mode], res[1][0] / nm, res[2][1] / no, res[3][0] / nm, res[3][1] / no))
+    a, b = C.c_double(), C.c_double()
+    check(fn(eng.h, mode, iters, 5, C.byref(a), C.byref(b)))
+    a1 = a.value
+    check(fn(eng.h, mode, iters, 7, C.byref(a), C.byref(b)))
+    print("%-28s beside v_mfma_f32_32x32x16_f16: MFMA wave alone %.1f cyc/MFMA | together: %.1f cyc/MFMA, %.1f cyc/op"
+          % ("", a1 / nm, a.value / nm, b.value / no))
