@@ -50,10 +50,15 @@ __global__ __launch_bounds__(256) void bank_write_kernel(const float* __restrict
 
 // Small updates (a tracking frame: <= 128 samples) carry their metadata as kernel arguments: no upload, no synchronisation.
 struct MetaArgs { int32_t v[5 * 128]; };   // src row | slot | pos | count slot | count value
-__global__ __launch_bounds__(256) void bank_write_args_kernel(const float* __restrict__ src, const MetaArgs a, int budget, int d,
-                                                              float* __restrict__ feat, float* __restrict__ sq) {
+__global__ __launch_bounds__(256) void bank_write_args_kernel(const float* __restrict__ src, const MetaArgs a, int nw, int nc, int budget,
+                                                              int d, float* __restrict__ feat, float* __restrict__ sq,
+                                                              int32_t* __restrict__ count) {
     __shared__ float red[4];
     const int i = blockIdx.x, tid = threadIdx.x;
+    if (i == nw) {   // the block after the samples: new sample counts of the touched tracks (same launch, one fewer in a frame)
+        if (tid < nc) count[a.v[384 + tid]] = a.v[512 + tid];
+        return;
+    }
     const int slot = a.v[128 + i], pos = a.v[256 + i];
     const float* s = src + (long long)a.v[i] * d;
     float* o = feat + ((long long)slot * budget + pos) * d;
@@ -67,10 +72,6 @@ __global__ __launch_bounds__(256) void bank_write_args_kernel(const float* __res
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
     if (tid == 0) sq[(long long)slot * budget + pos] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-__global__ void bank_set_count_args_kernel(const MetaArgs a, int n, int32_t* __restrict__ count) {
-    const int i = threadIdx.x;
-    if (i < n) count[a.v[384 + i]] = a.v[512 + i];
 }
 
 __global__ void bank_set_count_kernel(const int32_t* __restrict__ slots, const int32_t* __restrict__ values, int n,
@@ -316,9 +317,8 @@ static int bank_update_impl(reid_ctx* ctx, reid_bank* b, const float* d_feats, c
         memcpy(a.v + 384, cs.data(), nc * 4);
         memcpy(a.v + 512, cv.data(), nc * 4);
         prof_begin(ctx, REID_K_SELECT, 0, 8.0 * nw * b->d);
-        hipLaunchKernelGGL(bank_write_args_kernel, dim3(nw), dim3(256), 0, ctx->stream, d_feats, a, b->budget, b->d, b->feat, b->sq);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(bank_set_count_args_kernel, dim3(1), dim3(128), 0, ctx->stream, a, nc, b->count);
+        hipLaunchKernelGGL(bank_write_args_kernel, dim3(nw + 1), dim3(256), 0, ctx->stream, d_feats, a, nw, nc, b->budget, b->d, b->feat, b->sq,
+                           b->count);
         LAUNCH_CHECK();
         prof_end(ctx);
         return REID_OK;
