@@ -435,7 +435,9 @@ def run_tracking(job, args):
         eng.sync()
         return total
 
-    pipelined = not args.no_pipeline
+    # (reid_frame_gather is a collective inside the C ABI: with the stand-by torch.distributed transport the ranks fall back to the
+    # blocking calls + comm.all_gather)
+    pipelined = not args.no_pipeline and (world == 1 or job.transport == "RcclComm")
     if pipelined:
         run_pipelined(0, 3, [])
     else:

@@ -213,6 +213,11 @@ class Engine:
     def frame_gather(self, slot, per, world):
         """Multi-GPU frames: all-gather the ranks' embeddings of the submitted frame into the slot (equal blocks of `per` rows);
         the slot then holds world * per rows on every rank (`parallel.frame_rows` maps detections to them)."""
+        if world > 1:
+            rank, w = C.c_int(), C.c_int()
+            check(self.lib.reid_comm_info(self.h, C.byref(rank), C.byref(w)))
+            if w.value != world:
+                raise RuntimeError("frame_gather over %d ranks needs the C-ABI communicator (reid_comm_init); it spans %d" % (world, w.value))
         check(self.lib.reid_frame_gather(self.h, int(slot), int(per)))
         if per > 0:
             self._frame_n[slot] = int(world) * int(per)
