@@ -117,7 +117,8 @@ class Job:
         # one explicit (non-null) HIP stream shared by torch (synchronize) and the C ABI launches + RCCL calls
         self.stream = torch.cuda.Stream()
         torch.cuda.set_stream(self.stream)
-        self.eng.set_stream(self.stream.cuda_stream)
+        if os.environ.get("REID_BENCH_OWN_STREAM") != "1":   # experiments: leave the engine on its context's own stream
+            self.eng.set_stream(self.stream.cuda_stream)
         # RCCL communicator behind the C ABI (reid_comm_init); REID_BENCH_COMM1=1: a real 1-rank communicator on one GPU
         self.comm = parallel.comm_from_env(self.eng, single_rank_communicator=os.environ.get("REID_BENCH_COMM1") == "1",
                                            log=lambda m: print("[bench rank %d] %s" % (self.rank, m), file=sys.stderr, flush=True))
@@ -342,6 +343,9 @@ def run_swin(job, args):
 
 
 # ------------------------------------------------------------------------------------------------ configs[3]: tracking stream
+TRACK_WARMUP = 60   # untimed frames: workspaces and pinned staging reach the sizes of the stream's larger frames
+
+
 def run_tracking(job, args):
     """MOT16-02 is not in the container: synthetic stand-in per SURVEY.md section 8(d) - 600 frames, detections per frame
     ~ Poisson(30) clipped to [1, 80], ragged crop sizes.  Per frame: this rank's share of the crops (round-robin) is resized
@@ -439,9 +443,9 @@ def run_tracking(job, args):
     # blocking calls + comm.all_gather)
     pipelined = not args.no_pipeline and (world == 1 or job.transport == "RcclComm")
     if pipelined:
-        run_pipelined(0, 3, [])
+        run_pipelined(0, TRACK_WARMUP, [])
     else:
-        for f in range(3):
+        for f in range(TRACK_WARMUP):
             frame(f)
     job.barrier()
     t0 = time.perf_counter()
@@ -516,7 +520,7 @@ def run_tracking(job, args):
         multi = {"cameras": args.cameras, "frames_per_s_total": round(args.cameras * frames / elm, 1),
                  "frames_per_s_per_camera": round(frames / elm, 1), "ms_per_frame_per_camera": round(elm / frames * 1e3, 3)}
     out = {"metric": "frames/sec, per-frame crop batches embedded + gathered + matched (ResNet18-SE 128x256)", "value": round(frames / elapsed, 1),
-            "unit": "frames/s", "n_gpus": world, "steps": frames, "warmup": 3, "ms_per_step": round(elapsed * 1e3 / frames, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": frames, "warmup": TRACK_WARMUP, "ms_per_step": round(elapsed * 1e3 / frames, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[3] stand-in: %d frames, %d crops (Poisson(30) per frame, ragged sizes), round-robin over "
                                    "the ranks, all-gather of [n_f,512], bank cost (40 tracks x 100) + DIoU" % (frames, ncrops),
