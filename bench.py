@@ -117,8 +117,7 @@ class Job:
         # one explicit (non-null) HIP stream shared by torch (synchronize) and the C ABI launches + RCCL calls
         self.stream = torch.cuda.Stream()
         torch.cuda.set_stream(self.stream)
-        if os.environ.get("REID_BENCH_OWN_STREAM") != "1":   # experiments: leave the engine on its context's own stream
-            self.eng.set_stream(self.stream.cuda_stream)
+        self.eng.set_stream(self.stream.cuda_stream)
         # RCCL communicator behind the C ABI (reid_comm_init); REID_BENCH_COMM1=1: a real 1-rank communicator on one GPU
         self.comm = parallel.comm_from_env(self.eng, single_rank_communicator=os.environ.get("REID_BENCH_COMM1") == "1",
                                            log=lambda m: print("[bench rank %d] %s" % (self.rank, m), file=sys.stderr, flush=True))
