@@ -303,7 +303,6 @@ extern "C" int reid_cam_debias_dev(reid_ctx* ctx, float* d_x, const int32_t* cam
             HIP_TRY(hipMemcpyAsync(&r2, alpha + 1, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             const float r = sqrtf(r2);
-            if (getenv("REID_DEBUG_CD")) fprintf(stderr, "cam %d it %d r %g\n", c, it, r);
             if (it == 0 && !(r < INFINITY)) {   // NaN / inf in the input rows: there is no previous iterate to fall back to
                 reid_set_error("reid_cam_debias: non-finite residual for camera %d (NaN or inf in its rows?)", c);
                 return REID_ERR_ARG;
