@@ -485,6 +485,27 @@ def run_tracking(job, args):
         elc = time.perf_counter() - t0c
         cpu = {"value": round(fc / elc, 2), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "%d frames, %d crops (%.1f s): oracle preprocess + oracle/seres18.py + numpy bank cost + DIoU" % (fc, cc, elc)}
+    # roofline object of the frame's convolutions: the first 100 frames again with every launch of the class bracketed by HIP
+    # events on its stream (same flow as the timed region)
+    from reid_amd import _ffi
+    eng.profile_reset()
+    eng.profile(True)
+    nprof = min(100, frames)
+    if pipelined:
+        run_pipelined(0, nprof, [])
+    else:
+        for f in range(nprof):
+            frame(f)
+    eng.sync()
+    conv = eng.profile_get(_ffi.K_CONV_GEMM)
+    eng.profile(False)
+    peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16" else PEAK_F32_MFMA_TFLOPS
+    conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+    roof = {"kernel": "convolution kernels of a frame's forward (~%d crops per rank: launches of at most one wave of blocks, latency-bound K loops)"
+                      % round(ncrops / frames / world),
+            "bound": "mfma", "achieved": round(conv_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4), "traffic": None,
+            "launches": conv["launches"], "avg_launch_us": round(conv["ms"] * 1e3 / max(1, conv["launches"]), 2),
+            "conv_ms_per_frame": round(conv["ms"] / nprof, 4)}
     multi = None
     if pipelined and world == 1 and args.cameras > 1:
         # several camera streams on the one GPU: own context (HIP stream, workspaces, bank) and host thread each
@@ -528,6 +549,7 @@ def run_tracking(job, args):
             "crops_per_s": round(ncrops / elapsed, 1), "ms_per_frame_median": round(float(np.median(lat)), 3),
             "ms_per_frame_p95": round(float(np.percentile(lat, 95)), 3),
             "allgather_us_median": round(float(np.median(gather_us)), 1) if gather_us else None}
+    out["roofline"] = roof
     if multi is not None:
         out["camera_streams"] = multi
     if cpu is not None:
