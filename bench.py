@@ -305,10 +305,20 @@ def run_swin(job, args):
         tf = g["flops"] / max(g["ms"], 1e-9) / 1e9
         return {"value": round(n * world * steps / elapsed, 1), "ms_per_step": round(elapsed * 1e3 / steps, 3),
                 "whole_net_tflops": round(SWIN_FLOP_PER_IMAGE * n * steps / elapsed / 1e12, 1),
-                "roofline": {"kernel": "Swin Linear / conv / window-attention contractions (%s)" % ("v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x2_f32"),
-                             "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                             "traffic": traffic_from_profile("swin_f16" if f16 else "swin_f32"), "launches": g["launches"],
-                             "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2)},
+                # exact fp32: the contractions are bound by the fp32 MFMA rate; fp16 storage: by HBM (PMC traffic of the class
+                # ~3.7 TB/s at its average launch duration, profiles/r02_traffic_swin_f16.json) - algorithmic bytes / duration
+                "roofline": ({"kernel": "Swin Linear / conv contractions (gemm_f16 linear builds, v_mfma_f32_32x32x16_f16)",
+                              "bound": "hbm", "achieved": round(g["bytes"] / max(g["ms"], 1e-9) / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": round(g["bytes"] / max(g["ms"], 1e-9) / 1e6 / PEAK_HBM_GBS, 4),
+                              "traffic": traffic_from_profile("swin_f16"), "launches": g["launches"],
+                              "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2),
+                              "algorithmic_bytes_per_launch": round(g["bytes"] / max(1, g["launches"]), 1),
+                              "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / peak, 4)} if f16 else
+                             {"kernel": "Swin Linear / conv contractions (gemm_f32_dma / conv_f32_dma, v_mfma_f32_32x32x2_f32)",
+                              "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                              "traffic": traffic_from_profile("swin_f32"), "launches": g["launches"],
+                              "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2),
+                              "algorithmic_bytes_per_launch": round(g["bytes"] / max(1, g["launches"]), 1)}),
                 "other_kernels": {"elementwise_attention_norm": {"ms_per_step": round(e["ms"] / steps, 3)}}}
 
     main_res = run(args.precision, args.steps, args.warmup)

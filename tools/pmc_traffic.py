@@ -17,6 +17,12 @@ MODE = sys.argv[3] if len(sys.argv) > 3 else "f16"
 if MODE == "f32":   # convolution class of the exact-fp32 path: conv_f32.hip kernels + the 7x7 stem (gemm_f32_kernel<A_STEM_*>)
     CONV = re.compile(r"conv_f32_dma_kernel|conv_f32_kernel|stem_f32_kernel|gemm_f32_kernel<[123],|gemm_f32_kernelILi[123]E")
     LABEL = "convolution kernels of the fp32 path (conv_f32_dma, conv_f32, 7x7 stem)"
+elif MODE == "swin_f32":   # Swin contractions in exact fp32: dense LDS-DMA GEMM + general conv kernel
+    CONV = re.compile(r"gemm_f32_dma_kernel|conv_f32_dma_kernel|gemm_f32_kernel")
+    LABEL = "Swin Linear / conv contractions of the fp32 path (gemm_f32_dma, conv_f32_dma general variant)"
+elif MODE == "swin_f16":
+    CONV = re.compile(r"gemm_f16_kernel")
+    LABEL = "Swin Linear / conv contractions of the fp16-storage path (gemm_f16 linear builds)"
 else:
     CONV = re.compile(r"conv3x3_f16_kernel|conv3x3_c64_f16_kernel|stem_pool_f16_kernel|gemm_f16_kernel")
     LABEL = "convolution kernels of the fp16 path (conv3x3_f16, conv3x3_c64_f16, stem_pool_f16, gemm_f16)"
@@ -49,7 +55,9 @@ fetch_kb = sum(v[1] for v in fetch.values())
 write_kb = sum(v[1] for v in write.values())
 res = {
     "kernel_class": LABEL,
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu --single --precision %s (4096 crops, chunk 1024)" % MODE,
+    "command": ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload swin --crops 512 --steps 1 --warmup 1 --no-cpu --single --precision %s" % MODE[5:]
+                if MODE.startswith("swin_") else
+                "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu --single --precision %s (4096 crops, chunk 1024)" % MODE),
     "launches": launches,
     "fetch_size_kb_raw_per_launch": fetch_kb / max(1, launches),
     "write_size_kb_per_launch": write_kb / max(1, sum(v[0] for v in write.values())),
