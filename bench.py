@@ -609,7 +609,7 @@ def run_market(job, args):
            "distmat_shard_ms": round(dist_ms, 3), "rank1_top%d" % k: rank1,
            "roofline": {"kernel": "gemm_f32_dma_kernel<E_DIST> (dense LDS-DMA GEMM + distance epilogue, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                         "achieved": round(flops / (dist_ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(flops / (dist_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "frac": round(flops / (dist_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic_from_profile("market"),
                         "algorithmic_bytes_per_launch": byts, "hbm_gbs": round(byts / (dist_ms * 1e-3) / 1e9, 1)}}
     if not args.no_cpu and world == 1:
         from oracle import matching

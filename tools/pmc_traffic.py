@@ -20,6 +20,9 @@ if MODE == "f32":   # convolution class of the exact-fp32 path: conv_f32.hip ker
 elif MODE == "swin_f32":   # Swin contractions in exact fp32: dense LDS-DMA GEMM + general conv kernel
     CONV = re.compile(r"gemm_f32_dma_kernel|conv_f32_dma_kernel|gemm_f32_kernel")
     LABEL = "Swin Linear / conv contractions of the fp32 path (gemm_f32_dma, conv_f32_dma general variant)"
+elif MODE == "market":     # distance matrix of the Market-size retrieval (bench.py --workload market)
+    CONV = re.compile(r"gemm_f32_dma_kernel")
+    LABEL = "distance-matrix GEMM of the Market-size search (gemm_f32_dma_kernel<E_DIST>)"
 elif MODE == "swin_f16":
     CONV = re.compile(r"gemm_f16_kernel")
     LABEL = "Swin Linear / conv contractions of the fp16-storage path (gemm_f16 linear builds)"
@@ -57,6 +60,8 @@ res = {
     "kernel_class": LABEL,
     "command": ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload swin --crops 512 --steps 1 --warmup 1 --no-cpu --single --precision %s" % MODE[5:]
                 if MODE.startswith("swin_") else
+                "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload market --steps 2 --warmup 1 --no-cpu"
+                if MODE == "market" else
                 "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu --single --precision %s (4096 crops, chunk 1024)" % MODE),
     "launches": launches,
     "fetch_size_kb_raw_per_launch": fetch_kb / max(1, launches),
