@@ -48,8 +48,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     const int nk = p.K / BK;
 
     using Desc = TileDesc<AJ, BJ>;
+    // Tile order: groups of GM row tiles; inside a group the row tile runs fastest, so the GM A tiles (GM x BM x K floats) stay in
+    // the XCD's L2 while the group sweeps the columns and every B tile is fetched once per group, not once per row tile (the
+    // Market-size search fetched its 33 MB gallery 27 times: PMC FETCH_SIZE 0.9 GB per launch against 40 MB of operands).
+    constexpr int GM = 8;
+    const int nmt = (p.M + BM - 1) / BM;
     auto describe = [&](int t, Desc& d) {
-        const int mtile = t / nnt, ntile = t - mtile * nnt;
+        const int group = t / (GM * nnt), first = group * GM;
+        const int gm = nmt - first < GM ? nmt - first : GM;
+        const int r = t - group * GM * nnt;
+        const int ntile = r / gm, mtile = first + (r - ntile * gm);
         d.m_blk = mtile * BM;
         d.n_blk = ntile * BN;
         d.rows_a = p.M - d.m_blk < BM ? p.M - d.m_blk : BM;
