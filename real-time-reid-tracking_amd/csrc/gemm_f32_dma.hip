@@ -48,10 +48,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     const int nk = p.K / BK;
 
     using Desc = TileDesc<AJ, BJ>;
-    // Tile order: groups of GM row tiles; inside a group the row tile runs fastest, so the GM A tiles (GM x BM x K floats) stay in
+    // Tile order: groups of GM row tiles (GM <= 8); inside a group the row tile runs fastest, so the GM A tiles (GM x BM x K floats) stay in
     // the XCD's L2 while the group sweeps the columns and every B tile is fetched once per group, not once per row tile (the
     // Market-size search fetched its 33 MB gallery 27 times: PMC FETCH_SIZE 0.9 GB per launch against 40 MB of operands).
-    constexpr int GM = 8;
+    // (GM row tiles of A must fit the L2 next to everything else: 1 MiB of them - 8 tiles at K = 96 .. 256, 4 at K = 512, the
+    // plain row-major order from K = 2048 on, where the A tile itself is the large operand of a Swin fc2)
+    const int a_tile_bytes = BM * p.K * 4;
+    const int GM = a_tile_bytes >= (1 << 20) ? 1 : ((1 << 20) / a_tile_bytes > 8 ? 8 : (1 << 20) / a_tile_bytes);
     const int nmt = (p.M + BM - 1) / BM;
     auto describe = [&](int t, Desc& d) {
         const int group = t / (GM * nnt), first = group * GM;
