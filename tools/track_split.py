@@ -1,3 +1,5 @@
+"""Host-time split of one tracking frame driven call by call (embed_ragged / bank cost / DIoU / bank update, each blocking).
+python tools/track_split.py"""
 import sys, time, numpy as np
 sys.path.insert(0, '/root/repo')
 from reid_amd import synth, weights
