@@ -505,6 +505,38 @@ def test_frame_pipeline_matches_the_synchronous_calls_and_the_oracle(eng_w0):
         eng.frame_update(0, pipe._bank, [99], [0])                 # row beyond the submitted frame
 
 
+def test_frame_pipeline_large_frame_and_euclidean_metric(eng_w0):
+    """A frame of 80 crops (more than one pass of the default 64-crop chunk), the euclidean metric, no boxes; then an empty
+    frame and a frame costed without tracks."""
+    from reid_amd.nn_matching import NearestNeighborDistanceMetric
+    eng, _ = eng_w0
+    pool = synth.ragged_crops_u8(20, seed=12)
+    crops = [pool[i % 20] for i in range(80)]
+    pipe = NearestNeighborDistanceMetric("euclidean", 50.0, 4, max_tracks=8)
+    sync = NearestNeighborDistanceMetric("euclidean", 50.0, 4, max_tracks=8)
+    want = eng.embed_ragged_u8(crops)
+    for mtr in (pipe, sync):
+        mtr.partial_fit(want[:6], [1, 1, 2, 3, 3, 3], [1, 2, 3])
+    eng.frame_submit(1, crops)
+    feats, cost, ic = pipe.frame_distance(1, [3, 1, 2], max_distance=40.0)
+    np.testing.assert_array_equal(feats, want)
+    np.testing.assert_array_equal(cost, sync.distance(want, [3, 1, 2], max_distance=40.0))
+    assert ic is None and cost.shape == (3, 80)
+    pipe.frame_partial_fit(1, [79, 0], [2, 1], [1, 2, 3])
+    sync.partial_fit(want[[79, 0]], [2, 1], [1, 2, 3])
+    eng.frame_submit(0, [])                                   # a frame without detections
+    f0, c0, _ = pipe.frame_distance(0, [1, 2, 3])
+    assert f0.shape == (0, 512) and c0.shape == (3, 0)
+    eng.frame_submit(1, crops[:3])                            # ... and one costed against no track
+    f1, c1, _ = pipe.frame_distance(1, [])
+    np.testing.assert_array_equal(f1, eng.embed_ragged_u8(crops[:3]))   # (a 3-crop pass takes the split-K convolutions: fp32 noise vs want[:3])
+    np.testing.assert_allclose(f1, want[:3], rtol=0, atol=2e-5 * np.abs(want).max())
+    assert c1.shape == (0, 3)
+    np.testing.assert_array_equal(pipe.distance(want[:5], [1, 2, 3]), sync.distance(want[:5], [1, 2, 3]))
+    pipe.close()
+    sync.close()
+
+
 def test_camera_stream_driver_equals_the_blocking_calls():
     """tracking.CameraStream (own context, submit / step / commit) over four frames: features, gated appearance cost and DIoU cost
     equal the blocking Extractor-style calls on another context."""
