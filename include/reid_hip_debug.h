@@ -1,6 +1,6 @@
 /* Experiment and correctness-harness entry points of libreid_hip_debug.so (built from csrc/debug.hip + csrc/microbench.hip,
  * linked on top of libreid_hip.so).  NOT part of the drop-in C ABI of include/reid_hip.h: nothing the reference's callers
- * would bind lives here.  Used by tools/*.py (kernel A/B timing, feed / MFMA-shape microbenchmarks) and by one parity test
+ * would bind lives here.  Used by the tools/ scripts (kernel A/B timing, feed / MFMA-shape microbenchmarks) and by one parity test
  * of the layer-1 fp16 convolution kernel.  All functions return a reid_hip.h status code. */
 #pragma once
 #include "reid_hip.h"

@@ -226,3 +226,18 @@ def test_load_state_dict_shape_mismatch_is_loud():
         warnings.simplefilter("always")
         missing, skipped = m.load_state_dict(bad, strict=False)
     assert "bnneck.weight" in skipped and any("bnneck.weight" in str(x.message) for x in w)
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/reid_hip.h (the drop-in C ABI) and include/reid_hip_debug.h compile as C99 with gcc: plain pointers and sizes, no
+    C++ in the signatures."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "reid_hip.h"\n#include "reid_hip_debug.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
