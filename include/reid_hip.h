@@ -225,6 +225,10 @@ int reid_frame_update(reid_ctx* ctx, int slot, reid_bank* bank, const int32_t* r
 int reid_rank_eval(reid_ctx* ctx, const float* qf, const int64_t* ql, const int64_t* qc, int nq,
                    const float* gf, const int64_t* gl, const int64_t* gc, int ng, int d,
                    int32_t* cmc_sum, double* ap, int32_t* valid);
+/* the same with the features already on the device (labels and results stay host arrays; synchronises) */
+int reid_rank_eval_dev(reid_ctx* ctx, const float* d_qf, const int64_t* ql, const int64_t* qc, int nq,
+                       const float* d_gf, const int64_t* gl, const int64_t* gc, int ng, int d,
+                       int32_t* cmc_sum, double* ap, int32_t* valid);
 
 /* ---- multi-GPU exchange: one process per GPU, collectives directly on librccl (RCCL over xGMI) -----
  * The path shards with ONE exchange step: crops are split contiguous-by-index, every rank embeds its shard, one all-gather of

@@ -414,6 +414,115 @@ def gen_siblings():
     np.savez_compressed(os.path.join(OUT, "siblings.npz"), **out)
 
 
+def _faiss_stub():
+    """numpy stand-in for the slice of faiss that compute_jaccard_distance(search_option=3) touches (see gen_rerank)."""
+    class _IndexFlatL2:
+        def __init__(self, d):
+            self.d, self.xb = d, np.zeros((0, d), np.float32)
+
+        def add(self, x):
+            self.xb = np.concatenate([self.xb, np.asarray(x, np.float32)], 0)
+
+        def search(self, x, k):
+            x = np.asarray(x, np.float32)
+            dist = (x * x).sum(1)[:, None] + (self.xb * self.xb).sum(1)[None, :] - 2.0 * (x @ self.xb.T)
+            idx = np.argsort(dist, axis=1, kind="stable")[:, :k]
+            return np.take_along_axis(dist, idx, 1), idx.astype(np.int64)
+
+    fs = types.ModuleType("faiss")
+    fs.get_num_gpus = lambda: 0
+    fs.METRIC_L2 = 1
+    fs.IndexFlatL2 = _IndexFlatL2
+    sys.modules["faiss"] = fs
+    return _IndexFlatL2
+
+
+def gen_e2e():
+    """The evaluation script's whole chain (reid/image_reid_inference.py:238-315) on ONE seeded problem, every link the
+    reference's own code: SERse18_IBN (eval) on cat(img, hflip img) in batches of 64 -> cat(normalize(emb), normalize(logits))
+    (:112-123) -> (plain + mirrored) / 2, normalize (:252-253, :267-268) -> cat(gallery, query) -> diminish_camera_bias (:276)
+    -> compute_jaccard_distance (:284; search_option=3 with the numpy IndexFlatL2 stand-in, faiss absent) -> clamp at 0 (:286)
+    -> sklearn DBSCAN(eps=0.5, min_samples=min(10, cams + 1), precomputed) (:299-303) -> merged_seqs * num_labels + pseudo
+    (:308) -> smooth_tracklets (:312) -> evaluate_all (:317).  The script itself cannot be imported (onnxruntime, cv2,
+    ultralytics, datasets: SURVEY.md 8c), so the glue between the links is restated here line by line; the mirrored view is a
+    plain horizontal flip (the script's strong_inference variant adds a random pad + crop), and the Market attribute
+    distance (:278-283, needs the .mat file) is left out, as for the other datasets."""
+    import io, contextlib
+    import torch.nn.functional as F
+    from sklearn.cluster import DBSCAN
+    from reid_amd import synth
+    _faiss_stub()
+    from reid.backbones.SERes18_IBN import seres18_ibn
+    from reid.inference_utils import diminish_camera_bias, smooth_tracklets
+    from reid.faiss_utils import compute_jaccard_distance
+    from reid.evaluate import evaluate_all
+
+    prob = synth.e2e_problem()
+    n_cams = 4
+    sd_np = synth.seres18_state_dict(0)
+    model = seres18_ibn(num_classes=751, loss="triplet")
+    res = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model.eval()
+
+    def inference_efficient(images):            # image_reid_inference.py:78-135, bs 64 (:144)
+        t1, t2 = [], []
+        with torch.no_grad():
+            for i in range(0, len(images), 64):
+                img1 = torch.from_numpy(images[i:i + 64])
+                img2 = torch.flip(img1, dims=[3])
+                embeddings, outputs = model(torch.cat((img1, img2), dim=0))
+                embeddings = torch.cat((F.normalize(embeddings, dim=1), F.normalize(outputs, dim=1)), dim=1)
+                t1.append(embeddings[:(len(embeddings) >> 1)])
+                t2.append(embeddings[(len(embeddings) >> 1):])
+        return torch.cat(t1, dim=0), torch.cat(t2, dim=0)
+
+    def ev(q, g):
+        with contextlib.redirect_stdout(io.StringIO()):
+            cmc, ap = evaluate_all(q, torch.from_numpy(prob["ql"]), torch.from_numpy(prob["qc"]),
+                                   g, torch.from_numpy(prob["gl"]), torch.from_numpy(prob["gc"]))
+        return cmc.numpy().astype(np.float32), np.float64(ap)
+
+    g1, g2 = inference_efficient(prob["g_img"])
+    gallery = F.normalize((g1 + g2) / 2.0, dim=1)
+    q1, q2 = inference_efficient(prob["q_img"])
+    query = F.normalize((q1 + q2) / 2.0, dim=1)
+    ng = gallery.shape[0]
+    merged = torch.cat((gallery, query), dim=0)
+    merged_cams = torch.cat((torch.from_numpy(prob["gc"]), torch.from_numpy(prob["qc"])), dim=0)
+    merged_seqs = torch.cat((torch.from_numpy(prob["gs"]), torch.from_numpy(prob["qs"])), dim=0)
+    step = 6                                    # every 6th row of the big intermediates keeps the fixture small
+    out = {"row_step": np.int64(step), "desc": merged.numpy()[::step].copy()}
+    out["cmc_tta"], out["map_tta"] = ev(merged[ng:], merged[:ng])
+    merged = diminish_camera_bias(merged, merged_cams)
+    out["debiased"] = merged.numpy()[::step].copy()
+    out["cmc_debiased"], out["map_debiased"] = ev(merged[ng:], merged[:ng])
+    dists = compute_jaccard_distance(merged, print_flag=False, search_option=3)
+    dists[dists < 0] = 0.
+    out["jaccard"] = dists.astype(np.float32)[::step].copy()
+    # --eps (default 0.5, :155) is a parameter of the script: take the value inside [0.45, 0.55] that lies in the middle of
+    # the widest gap between neighbouring distances, so that no DBSCAN neighbourhood decision sits within float noise of it
+    vals = np.unique(dists[(dists > 0.45) & (dists < 0.55)].astype(np.float64))
+    gap = int(np.argmax(np.diff(vals)))
+    eps = float((vals[gap] + vals[gap + 1]) / 2)
+    out["eps"] = np.float64(eps)
+    pseudo = DBSCAN(eps=eps, min_samples=min(10, n_cams + 1), metric="precomputed", n_jobs=-1).fit_predict(dists)
+    indices_pseudo = (pseudo != -1)
+    num_labels = max(pseudo) + 1
+    out["pseudo_labels"] = pseudo.astype(np.int32)
+    # margin of every DBSCAN decision that depends on eps: |d - eps| of the closest pair distance to the threshold
+    out["eps_margin"] = np.float64(np.abs(dists - eps).min())
+    merged_seqs = merged_seqs * num_labels + pseudo
+    merged = smooth_tracklets(merged, merged_seqs, indices_pseudo)
+    out["smoothed"] = merged.numpy()[::step].copy()
+    out["cmc"], out["map"] = ev(merged[ng:], merged[:ng])
+    np.savez_compressed(os.path.join(OUT, "e2e.npz"), **out)
+    print("e2e: %d gallery + %d query, descriptor %d-d | Rank-1/mAP  tta %.4f/%.4f  debiased %.4f/%.4f  final %.4f/%.4f | "
+          "eps %.6f: %d clusters, %d noise points, closest distance to eps %.2e"
+          % (ng, query.shape[0], merged.shape[1], out["cmc_tta"][0], out["map_tta"], out["cmc_debiased"][0], out["map_debiased"],
+             out["cmc"][0], out["map"], eps, num_labels, int((pseudo == -1).sum()), out["eps_margin"]))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -428,3 +537,4 @@ if __name__ == "__main__":
     gen_config1()
     gen_config5()
     gen_siblings()
+    gen_e2e()

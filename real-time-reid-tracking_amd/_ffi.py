@@ -83,6 +83,7 @@ _SIGS = {
     "reid_diou": (_i, [_vp, _vp, _vp, _i, _vp]),
     "reid_diou_cost": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "reid_rank_eval": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "reid_rank_eval_dev": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "reid_comm_unique_id": (_i, [_vp]),
     "reid_comm_init": (_i, [_vp, _i, _i, _vp]),
     "reid_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),

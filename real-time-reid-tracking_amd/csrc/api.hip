@@ -1152,13 +1152,12 @@ extern "C" int reid_diou_cost(reid_ctx* ctx, const double* tracks, int t, const 
     return reid_diou_cost_impl(ctx, tracks, t, dets, m, out, 1);
 }
 
-extern "C" int reid_rank_eval(reid_ctx* ctx, const float* qf, const int64_t* ql, const int64_t* qc, int nq, const float* gf,
-                              const int64_t* gl, const int64_t* gc, int ng, int d, int32_t* cmc_sum, double* ap,
-                              int32_t* valid) {
-    ARG_CHECK(ctx && qf && ql && qc && gf && gl && gc && cmc_sum && ap && valid && nq >= 1 && ng >= 1 && d >= 1);
+// features already on the device (the evaluation harness keeps them there between links); labels and results are host arrays
+extern "C" int reid_rank_eval_dev(reid_ctx* ctx, const float* d_qf, const int64_t* ql, const int64_t* qc, int nq,
+                                  const float* d_gf, const int64_t* gl, const int64_t* gc, int ng, int d, int32_t* cmc_sum,
+                                  double* ap, int32_t* valid) {
+    ARG_CHECK(ctx && d_qf && ql && qc && d_gf && gl && gc && cmc_sum && ap && valid && nq >= 1 && ng >= 1 && d >= 1);
     CTX_GUARD(ctx);
-    HostIO io{ctx};
-    REID_TRY(io.upload(qf, nq, gf, ng, d));
     long long *dql, *dqc, *dgl, *dgc;
     int32_t *dhist, *dvalid;
     double* dap;
@@ -1176,7 +1175,7 @@ extern "C" int reid_rank_eval(reid_ctx* ctx, const float* qf, const int64_t* ql,
     HIP_TRY(hipMemcpyAsync(dgl, gl, (size_t)ng * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dgc, gc, (size_t)ng * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(dhist, 0, (size_t)ng * 4, ctx->stream));
-    REID_TRY(reid_distmat_dev(ctx, io.dx, nq, io.dy, ng, d, REID_METRIC_DOT, score));
+    REID_TRY(reid_distmat_dev(ctx, d_qf, nq, d_gf, ng, d, REID_METRIC_DOT, score));
     REID_TRY(launch_rank_eval(ctx, score, nq, ng, ng, dql, dqc, dgl, dgc, dhist, dap, dvalid));
     HIP_TRY(hipMemcpyAsync(cmc_sum, dhist, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ap, dap, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1190,6 +1189,16 @@ extern "C" int reid_rank_eval(reid_ctx* ctx, const float* qf, const int64_t* ql,
     // histogram of first-good ranks -> summed CMC step functions (cmc[rows_good[0]:] = 1, evaluate.py:95)
     for (int j = 1; j < ng; ++j) cmc_sum[j] += cmc_sum[j - 1];
     return REID_OK;
+}
+
+extern "C" int reid_rank_eval(reid_ctx* ctx, const float* qf, const int64_t* ql, const int64_t* qc, int nq, const float* gf,
+                              const int64_t* gl, const int64_t* gc, int ng, int d, int32_t* cmc_sum, double* ap,
+                              int32_t* valid) {
+    ARG_CHECK(ctx && qf && gf && nq >= 1 && ng >= 1 && d >= 1);
+    CTX_GUARD(ctx);
+    HostIO io{ctx};
+    REID_TRY(io.upload(qf, nq, gf, ng, d));
+    return reid_rank_eval_dev(ctx, io.dx, ql, qc, nq, io.dy, gl, gc, ng, d, cmc_sum, ap, valid);
 }
 
 // ------------------------------------------------------------------------------------------------ single operators

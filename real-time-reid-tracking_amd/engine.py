@@ -353,6 +353,32 @@ class Engine:
         check(self.lib.reid_descriptor_f32_nchw(self.h, _ptr(x), x.shape[0], int(bool(flip_tta)), _ptr(out)))
         return out
 
+    def descriptor_dev(self, d_x, n, flip_tta, d_out):
+        check(self.lib.reid_descriptor_f32_nchw_dev(self.h, C.c_void_p(d_x), int(n), int(bool(flip_tta)), C.c_void_p(d_out)))
+
+    def cam_debias_dev(self, d_x, cams, n, d, la=0.05, iters=0):
+        cams = np.ascontiguousarray(cams, dtype=np.int32).reshape(-1)
+        if cams.shape[0] != n:
+            raise ValueError("cam_debias_dev: %d camera ids for %d rows" % (cams.shape[0], n))
+        check(self.lib.reid_cam_debias_dev(self.h, C.c_void_p(d_x), _ptr(cams), int(n), int(d), C.c_float(la), int(iters)))
+
+    def smooth_tracklets_dev(self, d_x, seqs, valid, n, d, keep=0.1):
+        seqs = np.ascontiguousarray(seqs, dtype=np.int32).reshape(-1)
+        v = None if valid is None else np.ascontiguousarray(np.asarray(valid).reshape(-1) != 0, dtype=np.uint8)
+        if seqs.shape[0] != n or (v is not None and v.shape[0] != n):
+            raise ValueError("smooth_tracklets_dev: seqs / valid must have %d entries" % n)
+        check(self.lib.reid_smooth_tracklets_dev(self.h, C.c_void_p(d_x), _ptr(seqs), _ptr(v), int(n), int(d), C.c_float(keep)))
+
+    def rank_eval_dev(self, d_qf, ql, qc, nq, d_gf, gl, gc, ng, d):
+        """Features in HBM, labels / cameras host int64 arrays -> (cmc_sum int32[ng], ap float64[nq], valid int32[nq])."""
+        ql, qc, gl, gc = (np.ascontiguousarray(a, dtype=np.int64) for a in (ql, qc, gl, gc))
+        cmc = np.empty(ng, np.int32)
+        ap = np.empty(nq, np.float64)
+        valid = np.empty(nq, np.int32)
+        check(self.lib.reid_rank_eval_dev(self.h, C.c_void_p(d_qf), _ptr(ql), _ptr(qc), int(nq), C.c_void_p(d_gf), _ptr(gl),
+                                          _ptr(gc), int(ng), int(d), _ptr(cmc), _ptr(ap), _ptr(valid)))
+        return cmc, ap, valid
+
     def cam_debias(self, x, cams, la=0.05, iters=0):
         """diminish_camera_bias (reid/inference_utils.py:5-15) on the device; returns a new float32 [n, d] array."""
         x = np.array(_f32(x), copy=True)

@@ -281,3 +281,49 @@ def images_f32(n, seed=0, h=224, w=224):
     x = 0.5 * a * yy + 0.5 * b * xx + 0.3 * np.sin(2 * np.pi * f * yy) * np.cos(2 * np.pi * f * xx)
     x = x + rng.normal(0, 0.15, (n, 3, h, w)).astype(np.float32)
     return np.clip(x, -1, 1).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ evaluation-harness problem
+def _id_pattern(rng, h, w):
+    yy = np.linspace(0, 1, h, dtype=np.float32)[None, :, None]
+    xx = np.linspace(0, 1, w, dtype=np.float32)[None, None, :]
+    a = rng.uniform(-1, 1, (3, 1, 1)).astype(np.float32)
+    b = rng.uniform(-1.5, 1.5, (3, 1, 1)).astype(np.float32)
+    c = rng.uniform(-1.5, 1.5, (3, 1, 1)).astype(np.float32)
+    f = rng.uniform(1, 5, 2)
+    ph = rng.uniform(0, 6.28, 2)
+    wave = np.sin(2 * np.pi * f[0] * yy + ph[0]) * np.cos(2 * np.pi * f[1] * xx + ph[1])
+    return (a + b * (yy - 0.5) + c * (xx - 0.5) + 0.6 * wave).astype(np.float32)
+
+
+def identity_images_f32(labels, cams, seed, noise=0.2, cam_shift=0.4, h=256, w=128):
+    """Normalised float images [n,3,h,w] with identity AND camera structure: image = gain * pattern[label] + cam_shift *
+    pattern[camera] + noise (white + one low-frequency pattern).  The identity / camera patterns come from a fixed stream, so
+    a gallery and a query set generated with different ``seed`` share them.  Stands in for a dataset the evaluation
+    script (reid/image_reid_inference.py) would load: retrieval is non-trivial and the per-camera offset is what
+    ``diminish_camera_bias`` removes."""
+    labels, cams = np.asarray(labels), np.asarray(cams)
+    brng = np.random.default_rng(7)
+    base = np.stack([_id_pattern(brng, h, w) for _ in range(max(32, int(labels.max()) + 1))])
+    camp = np.stack([_id_pattern(brng, h, w) for _ in range(max(8, int(cams.max()) + 1))])
+    rng = np.random.default_rng(seed)
+    out = np.empty((len(labels), 3, h, w), np.float32)
+    for i, (l, c) in enumerate(zip(labels, cams)):
+        g = np.float32(rng.uniform(0.8, 1.2))
+        out[i] = (g * base[l] + np.float32(cam_shift) * camp[c] + np.float32(noise) * rng.normal(0, 1, (3, h, w)).astype(np.float32)
+                  + np.float32(noise) * _id_pattern(rng, h, w))
+    return out
+
+
+def e2e_problem(seed=100, n_ids=24, n_cams=4, n_gallery=300, n_query=60, n_seqs=5):
+    """The seeded retrieval problem of the end-to-end harness test (tests/golden/e2e.npz): labels, cameras, sequence ids and
+    images of a gallery and a query set.  Label 0 of the gallery plays Market's distractors (queries draw from 1..)."""
+    rng = np.random.default_rng(seed)
+    gl = rng.integers(0, n_ids, n_gallery).astype(np.int64)
+    gc = rng.integers(0, n_cams, n_gallery).astype(np.int64)
+    ql = rng.integers(1, n_ids, n_query).astype(np.int64)
+    qc = rng.integers(0, n_cams, n_query).astype(np.int64)
+    gs = rng.integers(0, n_seqs, n_gallery).astype(np.int64)
+    qs = rng.integers(0, n_seqs, n_query).astype(np.int64)
+    return {"gl": gl, "gc": gc, "gs": gs, "ql": ql, "qc": qc, "qs": qs,
+            "g_img": identity_images_f32(gl, gc, seed + 1), "q_img": identity_images_f32(ql, qc, seed + 2)}

@@ -1190,3 +1190,34 @@ def test_sibling_backbones_match_reference_fixture(eng, golden_dir, tag, name, s
     # other batch sizes go through the same kernels: a single crop, and the crops inside a larger batch
     e1 = model(x[:1])
     assert np.abs(e1 - emb[:1]).max() <= 2e-5 * np.abs(emb).max()
+
+
+# ----------------------------------------------------------------------------- evaluation harness (SURVEY 8c harness row)
+def test_e2e_harness_matches_reference_chain(eng_w0, golden_dir):
+    """reid_amd.reid_inference.evaluate_reid - descriptor + flip-TTA -> camera de-biasing -> Jaccard re-ranking -> DBSCAN
+    (host, scikit-learn as in the reference) -> tracklet smoothing -> CMC / mAP, device-resident between the links - against
+    tests/golden/e2e.npz: the same chain run by gen_golden.gen_e2e through the reference's own classes and functions
+    (image_reid_inference.py:238-322) on the same seeded 300-image gallery + 60 queries."""
+    from reid_amd import reid_inference
+    eng, _ = eng_w0
+    g = np.load(os.path.join(golden_dir, "e2e.npz"))
+    step = int(g["row_step"])
+    prob = synth.e2e_problem()
+    taps = {}
+    cmc, mean_ap = reid_inference.evaluate_reid(prob["g_img"], prob["gl"], prob["gc"], prob["gs"], prob["q_img"], prob["ql"],
+                                                prob["qc"], prob["qs"], num_gallery_cams=4, eps=float(g["eps"]), taps=taps,
+                                                verbose=False, engine=eng)
+    np.testing.assert_allclose(taps["desc"][::step], g["desc"], atol=2e-5)          # unit rows: absolute = relative to the norm
+    np.testing.assert_allclose(taps["debiased"][::step], g["debiased"], atol=5e-5)
+    np.testing.assert_allclose(taps["jaccard"][::step], g["jaccard"], atol=2e-4)
+    # eps sits in the middle of the widest gap of the reference's distances (margin 1e-3 >> 2e-4): same neighbourhoods, same labels
+    assert (taps["pseudo_labels"] == g["pseudo_labels"]).all()
+    np.testing.assert_allclose(taps["smoothed"][::step], g["smoothed"], atol=5e-5)
+    np.testing.assert_array_equal(cmc, g["cmc"])
+    assert abs(mean_ap - float(g["map"])) < 1e-6
+    # the clustering hook: handing the reference's labels in gives the same result without scikit-learn
+    cmc2, map2 = reid_inference.evaluate_reid(prob["g_img"], prob["gl"], prob["gc"], prob["gs"], prob["q_img"], prob["ql"],
+                                              prob["qc"], prob["qs"], cluster_fn=lambda d: g["pseudo_labels"], verbose=False,
+                                              engine=eng)
+    np.testing.assert_array_equal(cmc2, cmc)
+    assert map2 == mean_ap

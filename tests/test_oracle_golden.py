@@ -224,3 +224,22 @@ def test_sibling_backbones_oracle_matches_reference(golden_dir, tag, arch, sd_fn
     for name in [b[0] for b in synth.SERES18_BLOCKS]:
         got = _sample(taps[name])
         np.testing.assert_allclose(got, g["%s_tap_%s" % (tag, name)], rtol=2e-4, atol=2e-4, err_msg=name)
+
+
+def test_e2e_chain_oracle_matches_reference(golden_dir):
+    """oracle.reid_inference (the evaluation script's chain composed from the oracle modules) against tests/golden/e2e.npz,
+    which gen_golden.gen_e2e produced with the reference's own model class, diminish_camera_bias, compute_jaccard_distance,
+    smooth_tracklets and evaluate_all on the same seeded problem."""
+    from oracle import reid_inference
+    g = np.load(os.path.join(golden_dir, "e2e.npz"))
+    step = int(g["row_step"])
+    prob = synth.e2e_problem()
+    taps = {}
+    cmc, mean_ap = reid_inference.evaluate_reid(synth.seres18_state_dict(0), prob, eps=float(g["eps"]), num_gallery_cams=4, taps=taps)
+    np.testing.assert_allclose(taps["desc"][::step], g["desc"], atol=2e-5)
+    np.testing.assert_allclose(taps["debiased"][::step], g["debiased"], atol=5e-5)
+    np.testing.assert_allclose(taps["jaccard"][::step], g["jaccard"], atol=2e-4)
+    assert (taps["pseudo_labels"] == g["pseudo_labels"]).all()
+    np.testing.assert_allclose(taps["smoothed"][::step], g["smoothed"], atol=5e-5)
+    np.testing.assert_array_equal(cmc, g["cmc"])
+    assert abs(mean_ap - float(g["map"])) < 1e-6
