@@ -110,18 +110,20 @@ class Job:
         if self.world != args.gpus:
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, self.world, args.gpus))
-        # REID_BENCH_ONE_DEVICE=1: every rank on device 0 (rehearsal of the multi-rank path on a one-GPU box, if RCCL allows it)
-        self.device = 0 if os.environ.get("REID_BENCH_ONE_DEVICE") == "1" else self.local_rank
+        self.device = self.local_rank      # one rank per device: RCCL rejects two ranks on one GPU ("Duplicate GPU detected")
         torch.cuda.set_device(self.device)
         self.eng = get_engine(self.device)
         # one explicit (non-null) HIP stream shared by torch (synchronize) and the C ABI launches + RCCL calls
         self.stream = torch.cuda.Stream()
         torch.cuda.set_stream(self.stream)
         self.eng.set_stream(self.stream.cuda_stream)
-        # RCCL communicator behind the C ABI (reid_comm_init); REID_BENCH_COMM1=1: a real 1-rank communicator on one GPU
-        self.comm = parallel.comm_from_env(self.eng, single_rank_communicator=os.environ.get("REID_BENCH_COMM1") == "1",
-                                           log=lambda m: print("[bench rank %d] %s" % (self.rank, m), file=sys.stderr, flush=True))
-        self.transport = type(self.comm).__name__
+        # RCCL communicator behind the C ABI (reid_comm_init) - the only transport: if it cannot be brought up the RCCL error is
+        # printed and the job exits non-zero.  REID_BENCH_COMM1=1: a real 1-rank communicator on one GPU
+        try:
+            self.comm = parallel.RcclComm.from_env(self.eng, single_rank_communicator=os.environ.get("REID_BENCH_COMM1") == "1")
+        except Exception as e:     # noqa: BLE001
+            print("[bench rank %d] FATAL: RCCL communicator: %s" % (self.rank, e), file=sys.stderr, flush=True)
+            raise SystemExit(3)
 
     def barrier(self):
         self.comm.barrier()                  # RCCL all-reduce of one double + stream sync (local sync when world == 1)
@@ -255,9 +257,7 @@ def run_embed(job, args):
                    "crops_per_gpu": n, "embed_dim": d, "chunk": args.chunk,
                    "arithmetic": ("fp16 storage, fp32 accumulate (north_star tolerance 1e-3 cosine; measured below)" if f16
                                   else "exact fp32 (v_mfma_f32_32x32x2_f32), the reference's arithmetic"),
-                   "sharding": ("crops sharded by rank, one RCCL all-gather of [N,512] embeddings "
-                                + ("through the C ABI (reid_allgather_dev)" if job.transport == "RcclComm"
-                                   else "through torch.distributed (C-ABI communicator unavailable on this node)")
+                   "sharding": ("crops sharded by rank, one RCCL all-gather of [N,512] embeddings through the C ABI (reid_allgather_dev)"
                                 if world > 1 else "single GPU")},
         "f16_vs_f32_max_cosine_err": cos_err,
     }
@@ -371,7 +371,9 @@ def run_tracking(job, args):
     rng = np.random.default_rng(3)
     counts = np.clip(rng.poisson(30, frames), 1, 80)
     pool = synth.ragged_crops_u8(256, seed=3)
-    metric = NearestNeighborDistanceMetric("cosine", 0.15, 100)         # MAX_DIST / NN_BUDGET, deep_sort.yaml:3,9
+    from reid_amd.tracking import ShardedCameraStream
+    stream = ShardedCameraStream(eng, comm, 0.15, 100)                   # MAX_DIST / NN_BUDGET, deep_sort.yaml:3,9
+    metric = stream.metric
     tracks = list(range(40))
     metric.partial_fit(rng.normal(size=(40 * 100, 512)).astype(np.float32), np.repeat(tracks, 100), tracks)
     boxes = rng.uniform(0, 500, (80, 4))
@@ -415,42 +417,31 @@ def run_tracking(job, args):
         return [pool[(f * 7 + i) % 256] for i in range(int(counts[f]))]
 
     def run_pipelined(first, last, lat):
-        """The frame pipeline (csrc/bank.hip), any number of ranks: this rank's round-robin share of frame f+1 is packed into
-        pinned memory, uploaded and embedded while frame f's costs come back and its update is enqueued; the ranks' embeddings
-        meet in ONE device-side all-gather per frame (reid_frame_gather), every rank then holds the frame's features in the
-        slot and computes the full cost matrices, as DeepSORT would on every rank.  One wait per frame."""
-        def share(f):
-            return [pool[(f * 7 + int(i)) % 256] for i in parallel.round_robin(int(counts[f]), world, rank)]
-
+        """The frame pipeline (csrc/bank.hip) through the library's own driver, tracking.ShardedCameraStream, for any number of
+        ranks: this rank's round-robin share of frame f+1 is packed into pinned memory, uploaded and embedded while frame f's
+        costs come back and its update is enqueued; the ranks' embeddings meet in ONE device-side all-gather per frame
+        (reid_frame_gather), every rank then holds the frame's features in the slot and computes the full cost matrices, as
+        DeepSORT would on every rank.  One wait per frame."""
+        stream.submit(crops_of(first))
         t_sub = {first: time.perf_counter()}
-        eng.frame_submit(first & 1, share(first))
         total = 0
         for f in range(first, last):
-            slot = f & 1
             n = int(counts[f])
-            rows, per = parallel.frame_rows(n, world)          # detection i -> row of the gathered slot
+            nxt = crops_of(f + 1) if f + 1 < last else None
             t0 = time.perf_counter()
-            eng.frame_gather(slot, per, world)
-            dets = np.tile(np.asarray([0.0, 0.0, 1.0, 1.0]), (world * per, 1))
-            dets[rows] = boxes[:n]
-            metric.frame_distance_begin(slot, tracks, 0.15, boxes[:40], dets)   # queued behind forward(f) and the gather
-            if f + 1 < last:
-                t_sub[f + 1] = time.perf_counter()
-                eng.frame_submit(slot ^ 1, share(f + 1))                        # forward(f+1) runs under the host's work
-            feats_g, cost_g, icost_g = metric.frame_distance_end(slot)
+            if nxt is not None:
+                t_sub[f + 1] = t0
+            feats, cost, icost = stream.step(n, tracks, boxes[:40], boxes[:n], nxt)
             if world > 1:
                 gather_us.append((time.perf_counter() - t0) * 1e6)              # gather + costs + the frame's wait
-            feats, cost, icost = feats_g[rows], cost_g[:, rows], icost_g[:, rows]
             k = min(n, 40)
-            metric.frame_partial_fit(slot, rows[:k].astype(np.int32), tracks[:k], tracks)
+            stream.commit(np.arange(k), tracks[:k], tracks)
             lat.append(time.perf_counter() - t_sub.pop(f))
             total += n
         eng.sync()
         return total
 
-    # (reid_frame_gather is a collective inside the C ABI: with the stand-by torch.distributed transport the ranks fall back to the
-    # blocking calls + comm.all_gather)
-    pipelined = not args.no_pipeline and (world == 1 or job.transport == "RcclComm")
+    pipelined = not args.no_pipeline
     if pipelined:
         run_pipelined(0, TRACK_WARMUP, [])
     else:
@@ -583,7 +574,7 @@ def run_market(job, args):
         # the shard's block of the distance matrix (the metric's "N x M distmat ms") + sharded k-NN with device merge
         if hi > lo:
             eng.distmat_dev(dq.ptr, nq, dg.ptr, hi - lo, d, _ffi.METRIC_L2, dist.ptr)
-        parallel.knn_gallery_sharded_dev(eng, dq.ptr, nq, dg.ptr, hi - lo, lo, d, k, dD.ptr, dI.ptr)
+        parallel.knn_gallery_sharded_dev(eng, dq.ptr, nq, dg.ptr, hi - lo, lo, d, k, dD.ptr, dI.ptr, world)
 
     elapsed = job.timed(step, args.steps, args.warmup)
     eng.timer_start()

@@ -36,6 +36,10 @@ int reid_debug_feed(reid_ctx* ctx, int mode, size_t footprint, int rowb, size_t 
 /* The device k-way merge of reid_knn_gallery_sharded_dev run on host lists [world][nq][kk] (tests with virtual shards). */
 int reid_debug_knn_merge(reid_ctx* ctx, const float* Dall, const int32_t* Iall, int world, int nq, int kk, int k, float* D,
                          int32_t* I);
+/* Loop-back communicator: `world` contexts of this process on one device become ranks 0..world-1 of a job, one host thread
+ * each; every collective of csrc/comm.hip then runs with world > 1 on a one-GPU box (host rendezvous + device copies, no
+ * RCCL).  reid_comm_destroy / reid_ctx_destroy detach a rank. */
+int reid_debug_comm_loopback(reid_ctx** ctxs, int world);
 /* What a wave that stages data can issue beside the other wave's back-to-back v_mfma_f32_32x32x2_f32 (microbench.hip). */
 int reid_debug_coissue(reid_ctx* ctx, int mode, int iters, int roles, double* cyc_mfma_wave, double* cyc_other_wave);
 

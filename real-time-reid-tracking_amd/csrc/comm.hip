@@ -13,11 +13,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string.h>
-
-struct reid_comm {
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-};
+#include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -150,12 +147,19 @@ extern "C" int reid_comm_init(reid_ctx* ctx, int rank, int world, const void* id
         if (rccl_load() != REID_OK) { delete c; return REID_ERR_STATE; }
         ncclUniqueId id;
         memcpy(&id, id128, sizeof(id));
-        ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+        setenv("NCCL_DEBUG", "WARN", 0);   // a failed bring-up must say why (RCCL prints the cause at WARN); never overrides the user
+        ncclComm_t nc = nullptr;
+        ncclResult_t r = g_rccl.CommInitRank(&nc, world, id, rank);
         if (r != ncclSuccess) {
-            reid_set_error("ncclCommInitRank(rank %d of %d) -> %s", rank, world, g_rccl.GetErrorString(r));
+            // fatal for the caller: there is no second transport.  The usual causes: two ranks on one device ("Duplicate GPU
+            // detected", ncclInvalidUsage), a stale / foreign id, ranks that disagree on `world`.
+            reid_set_error("ncclCommInitRank(rank %d of %d, device %d) -> %s", rank, world, ctx->device, g_rccl.GetErrorString(r));
+            fprintf(stderr, "[libreid_hip] ncclCommInitRank(rank %d of %d, device %d) failed: %s\n", rank, world, ctx->device,
+                    g_rccl.GetErrorString(r));
             delete c;
             return REID_ERR_HIP;
         }
+        c->comm = nc;
     }
     ctx->comm = c;
     return REID_OK;
@@ -173,7 +177,8 @@ extern "C" int reid_comm_destroy(reid_ctx* ctx) {
     CTX_GUARD(ctx);
     if (!ctx->comm) return REID_OK;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->comm->comm) g_rccl.CommDestroy(ctx->comm->comm);
+    if (ctx->comm->loop) ctx->comm->loop->detach(ctx->comm->rank);
+    if (ctx->comm->comm) g_rccl.CommDestroy((ncclComm_t)ctx->comm->comm);
     delete ctx->comm;
     ctx->comm = nullptr;
     return REID_OK;
@@ -181,7 +186,8 @@ extern "C" int reid_comm_destroy(reid_ctx* ctx) {
 
 void comm_release(reid_ctx* ctx) {   // reid_ctx_destroy
     if (ctx->comm) {
-        if (ctx->comm->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm->comm);
+        if (ctx->comm->loop) ctx->comm->loop->detach(ctx->comm->rank);
+        if (ctx->comm->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm->comm);
         delete ctx->comm;
         ctx->comm = nullptr;
     }
@@ -194,13 +200,15 @@ extern "C" int reid_allgather_dev(reid_ctx* ctx, const void* d_send, void* d_rec
     CTX_GUARD(ctx);
     if (bytes == 0) return REID_OK;
     reid_comm* c = ctx->comm;
+    if (c && c->loop) return c->loop->allgather(c->rank, d_send, d_recv, bytes, ctx->stream);   // test transport (debug library)
     if (!c || !c->comm) {   // world 1 without a communicator: the gather is a copy
         ARG_CHECK(!c || c->world == 1);
         if (d_recv != d_send) HIP_TRY(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         return REID_OK;
     }
-    if (bytes % 4 == 0) RCCL_TRY(g_rccl.AllGather(d_send, d_recv, bytes / 4, ncclInt32, c->comm, ctx->stream));
-    else RCCL_TRY(g_rccl.AllGather(d_send, d_recv, bytes, ncclInt8, c->comm, ctx->stream));
+    ncclComm_t nc = (ncclComm_t)c->comm;
+    if (bytes % 4 == 0) RCCL_TRY(g_rccl.AllGather(d_send, d_recv, bytes / 4, ncclInt32, nc, ctx->stream));
+    else RCCL_TRY(g_rccl.AllGather(d_send, d_recv, bytes, ncclInt8, nc, ctx->stream));
     return REID_OK;
 }
 
@@ -214,10 +222,14 @@ extern "C" int reid_frame_gather(reid_ctx* ctx, int slot, int per) {
     CTX_GUARD(ctx);
     const int world = ctx->comm ? ctx->comm->world : 1;
     ARG_CHECK(ctx->frame_m[slot] <= per && per <= ctx->frame_m[slot] + 1);   // round-robin shares differ by at most one crop
-    if (!ctx->comm || !ctx->comm->comm || per == 0) return REID_OK;   // (a 1-rank communicator still runs the collective: tests)
+    if (!ctx->comm || (!ctx->comm->comm && !ctx->comm->loop) || per == 0) return REID_OK;   // (a 1-rank communicator still runs the collective: tests)
     const std::string tag = slot ? "frame1" : "frame0";
+    const int mine = ctx->frame_m[slot];
     float *d_loc = ctx->frame_emb[slot], *d_all;
-    if (!d_loc) REID_TRY(ctx_ws(ctx, (tag + ".emb").c_str(), (size_t)(per + 1) * 2048, (void**)&d_loc));   // this rank had no crop
+    if (!d_loc || mine == 0) REID_TRY(ctx_ws(ctx, (tag + ".emb").c_str(), (size_t)(per + 1) * 2048, (void**)&d_loc));   // this rank had no crop
+    // a rank with one crop fewer than `per` sends a padding row: zeros, not whatever an earlier frame left there (nobody may
+    // address it - parallel.frame_rows never does - but a cost matrix over the whole slot must not meet NaNs)
+    if (mine < per) HIP_TRY(hipMemsetAsync(d_loc + (size_t)mine * 512, 0, (size_t)(per - mine) * 2048, ctx->stream));
     REID_TRY(ctx_ws(ctx, (tag + ".all").c_str(), (size_t)world * per * 2048, (void**)&d_all));
     REID_TRY(reid_allgather_dev(ctx, d_loc, d_all, (size_t)per * 2048));
     ctx->frame_emb[slot] = d_all;
@@ -279,6 +291,10 @@ extern "C" int reid_allreduce_f64(reid_ctx* ctx, double* inout, int count, int o
     ARG_CHECK(ctx && inout && count >= 1 && count <= 64 && (op == 0 || op == 1));
     CTX_GUARD(ctx);
     reid_comm* c = ctx->comm;
+    if (c && c->loop) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return c->loop->allreduce(c->rank, inout, count, op);
+    }
     if (!c || !c->comm) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return REID_OK;
@@ -286,7 +302,7 @@ extern "C" int reid_allreduce_f64(reid_ctx* ctx, double* inout, int count, int o
     double* d;
     REID_TRY(ctx_ws(ctx, "comm.red", 64 * 8, (void**)&d));
     HIP_TRY(hipMemcpyAsync(d, inout, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
-    RCCL_TRY(g_rccl.AllReduce(d, d, count, ncclFloat64, op == 0 ? ncclSum : ncclMax, c->comm, ctx->stream));
+    RCCL_TRY(g_rccl.AllReduce(d, d, count, ncclFloat64, op == 0 ? ncclSum : ncclMax, (ncclComm_t)c->comm, ctx->stream));
     HIP_TRY(hipMemcpyAsync(inout, d, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return REID_OK;
@@ -302,6 +318,13 @@ extern "C" int reid_knn_gallery_sharded_dev(reid_ctx* ctx, const float* d_xq, in
     CTX_GUARD(ctx);
     if (nq == 0) return REID_OK;
     const int world = ctx->comm ? ctx->comm->world : 1;
+    if (world == 1 && index_base > 0) {
+        // a shard that does not start at row 0 belongs to a job of several ranks: without a communicator the "merged" result
+        // would silently be this shard's alone
+        reid_set_error("reid_knn_gallery_sharded_dev: index_base %d > 0 but this context has no communicator of several ranks "
+                       "(reid_comm_init): the other shards would be missing from the result", index_base);
+        return REID_ERR_STATE;
+    }
     float* Dl;
     int32_t* Il;
     const size_t cnt = (size_t)nq * k;

@@ -272,3 +272,88 @@ extern "C" int reid_debug_linear(reid_ctx* ctx, int m, int n, int k, int mode, i
     *ms_per_launch = ms / (iters > 0 ? iters : 1);
     return st;
 }
+
+// ------------------------------------------------------------------------------------------------ loop-back communicator (tests)
+// Several contexts of THIS process on ONE device act as the ranks of a job: every collective of csrc/comm.hip
+// (reid_allgather_dev and what is built on it - ragged row gathers, reid_frame_gather, reid_knn_gallery_sharded_dev -
+// reid_allreduce_f64) then runs with world > 1 on a one-GPU box, driven by one host thread per rank.  The exchange itself is
+// a host rendezvous + device-to-device copies; RCCL is not involved (the product's only transport, reid_comm_init, is).
+#include <condition_variable>
+#include <chrono>
+#include <mutex>
+
+namespace {
+struct LoopComm : reid_comm_loop {
+    int world, attached;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long gen = 0;
+    std::vector<const void*> send;
+    std::vector<double> red;
+    explicit LoopComm(int w) : world(w), attached(w), send(w, nullptr), red((size_t)w * 64, 0.0) {}
+
+    // reusable barrier; gives up after 60 s (a rank that failed never arrives: the others must not hang the box)
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const long g = gen;
+        if (++arrived == world) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+            return true;
+        }
+        return cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g; });
+    }
+    int allgather(int rank, const void* d_send, void* d_recv, size_t bytes, hipStream_t st) override {
+        HIP_TRY(hipStreamSynchronize(st));            // this rank's payload is complete
+        send[rank] = d_send;
+        if (!barrier()) { reid_set_error("loop-back all-gather: rank %d waited 60 s for the others", rank); return REID_ERR_STATE; }
+        for (int r = 0; r < world; ++r)
+            HIP_TRY(hipMemcpyAsync((char*)d_recv + (size_t)r * bytes, send[r], bytes, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!barrier()) { reid_set_error("loop-back all-gather: rank %d waited 60 s for the others", rank); return REID_ERR_STATE; }
+        return REID_OK;
+    }
+    int allreduce(int rank, double* inout, int count, int op) override {
+        for (int i = 0; i < count; ++i) red[(size_t)rank * 64 + i] = inout[i];
+        if (!barrier()) { reid_set_error("loop-back all-reduce: rank %d waited 60 s for the others", rank); return REID_ERR_STATE; }
+        for (int i = 0; i < count; ++i) {
+            double v = red[i];
+            for (int r = 1; r < world; ++r) v = op == 0 ? v + red[(size_t)r * 64 + i] : (red[(size_t)r * 64 + i] > v ? red[(size_t)r * 64 + i] : v);
+            inout[i] = v;
+        }
+        if (!barrier()) { reid_set_error("loop-back all-reduce: rank %d waited 60 s for the others", rank); return REID_ERR_STATE; }
+        return REID_OK;
+    }
+    void detach(int) override {
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            last = --attached == 0;
+        }
+        if (last) delete this;
+    }
+};
+}  // namespace
+
+extern "C" int reid_debug_comm_loopback(reid_ctx** ctxs, int world) {
+    ARG_CHECK(ctxs && world >= 1 && world <= 64);
+    for (int r = 0; r < world; ++r) {
+        ARG_CHECK(ctxs[r] && ctxs[r]->device == ctxs[0]->device);
+        for (int q = 0; q < r; ++q) ARG_CHECK(ctxs[q] != ctxs[r]);
+        if (ctxs[r]->comm) {
+            reid_set_error("reid_debug_comm_loopback: context %d already has a communicator", r);
+            return REID_ERR_STATE;
+        }
+    }
+    LoopComm* lc = new LoopComm(world);
+    for (int r = 0; r < world; ++r) {
+        reid_comm* c = new reid_comm();
+        c->rank = r;
+        c->world = world;
+        c->loop = lc;
+        ctxs[r]->comm = c;
+    }
+    return REID_OK;
+}

@@ -234,7 +234,20 @@ struct Se18Weights {
     const _Float16* h(const float* p) const { return blob16 + (p - blob); }
 };
 
-struct reid_comm;   // comm.hip: the RCCL communicator of this rank
+// comm.hip: the RCCL communicator of this rank.  `loop` is a TEST transport (libreid_hip_debug.so, reid_debug_comm_loopback):
+// several contexts of ONE process on ONE device act as the ranks, so that the multi-rank C code (ragged gathers, index_base,
+// padding rows, the merge) runs with world > 1 on a one-GPU box.  The product never sets it: reid_comm_init is RCCL only.
+struct reid_comm_loop {
+    virtual int allgather(int rank, const void* d_send, void* d_recv, size_t bytes, hipStream_t st) = 0;
+    virtual int allreduce(int rank, double* inout, int count, int op) = 0;
+    virtual void detach(int rank) = 0;
+    virtual ~reid_comm_loop() {}
+};
+struct reid_comm {
+    void* comm = nullptr;   // ncclComm_t
+    int rank = 0, world = 1;
+    reid_comm_loop* loop = nullptr;
+};
 void comm_release(reid_ctx* ctx);
 // k-way merge of per-shard top-k lists [world][nq][kk] (global indices, -1 = padding) -> [nq][k] (comm.hip)
 int launch_knn_merge(reid_ctx* ctx, const float* Dall, const int32_t* Iall, int world, int nq, int kk, int k, float* D, int32_t* I);

@@ -8,9 +8,9 @@ The path shards with exactly one exchange step:
     faiss.IndexShards pattern (reid/faiss_utils.py:121-135): every rank searches its shard for all queries
     and the per-shard (distance, index) lists are merged k-way.
 
-Transports behind the same orchestration (plus ``TorchComm``, a stand-by with RcclComm's interface over torch.distributed's
-nccl backend that bench.py falls back to if the C-ABI communicator cannot be brought up on a node):
-  * ``RcclComm`` - the product path: collectives inside the C ABI (reid_comm_* / reid_allgather_* /
+Transports behind the same orchestration:
+  * ``RcclComm`` - the product path and the ONLY device transport (a communicator that cannot be brought up is fatal: the
+    RCCL error is printed and the caller exits non-zero - there is no stand-by): collectives inside the C ABI (reid_comm_* / reid_allgather_* /
     reid_knn_gallery_sharded_dev, csrc/comm.hip, librccl over xGMI).  Everything stays in HBM: the local shard is embedded from a
     device buffer into a device buffer, gathered on the device, the row block / the merged k-NN lists are computed on the
     device.  torch.distributed is used only to hand the 128-byte communicator id from rank 0 to the others.
@@ -118,7 +118,10 @@ class RcclComm:
     def from_env(cls, engine, single_rank_communicator=False):
         """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them.  With world 1 no communicator is
         made (every collective is a local copy) unless ``single_rank_communicator`` asks for a real 1-rank RCCL communicator
-        (exercises the RCCL calls on a single GPU)."""
+        (exercises the RCCL calls on a single GPU).  Any failure is fatal and raises on every rank that can still be told: rank 0
+        sends [ok byte | 128-byte id] in ONE broadcast, so a rank 0 that could not make the id does not leave its peers waiting
+        in a collective it never joins; a failed ncclCommInitRank raises ReidHipError with RCCL's message (NCCL_DEBUG=WARN is
+        set by reid_comm_init, so the cause is on stderr) - the launcher then takes the job down."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         if world == 1:
@@ -128,11 +131,28 @@ class RcclComm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dist.is_initialized():
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        t = torch.zeros(_ffi.COMM_ID_BYTES, dtype=torch.uint8)
+        t = torch.zeros(1 + _ffi.COMM_ID_BYTES, dtype=torch.uint8)
+        err = None
         if rank == 0:
-            t = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8).clone()
+            try:
+                t[1:] = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8)
+                t[0] = 1
+            except Exception as e:     # noqa: BLE001 - reported to every rank through the broadcast below, then raised
+                err = e
         dist.broadcast(t, src=0)
-        return cls(engine, rank, world, bytes(t.numpy().tobytes()))
+        if int(t[0]) != 1:
+            raise RuntimeError("RcclComm: rank 0 could not create the communicator id (ncclGetUniqueId)%s"
+                               % (": %r" % (err,) if err is not None else ""))
+        return cls(engine, rank, world, bytes(t[1:].numpy().tobytes()))
+
+    @classmethod
+    def attach(cls, engine):
+        """Wraps the communicator the engine's context already has (reid_comm_info): the loop-back ranks of the tests."""
+        self = object.__new__(cls)
+        rank, world = C.c_int(), C.c_int()
+        check(engine.lib.reid_comm_info(engine.h, C.byref(rank), C.byref(world)))
+        self.engine, self.rank, self.world = engine, rank.value, world.value
+        return self
 
     def close(self):
         check(self.engine.lib.reid_comm_destroy(self.engine.h))
@@ -158,92 +178,6 @@ class RcclComm:
 
     def barrier(self):
         self.all_reduce([0.0], "sum")
-
-
-class _DevBytes:
-    """A raw device range as a __cuda_array_interface__ object (torch.as_tensor wraps it without a copy)."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-
-
-class TorchComm:
-    """Stand-by transport with RcclComm's collective interface: torch.distributed's nccl backend (RCCL as well) over the same
-    raw device pointers.  bench.py switches to it, on every rank together, only if the communicator behind the C ABI cannot be
-    brought up on a node; reid_knn_gallery_sharded_dev (collective inside the C ABI) is not available through it."""
-
-    def __init__(self, engine, group):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist, self.engine, self.group = torch, dist, engine, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.dev = "cuda:%d" % engine.device
-
-    def _t(self, ptr, nbytes):
-        return self.torch.as_tensor(_DevBytes(ptr, nbytes), device=self.dev)
-
-    def close(self):
-        pass
-
-    def all_gather(self, d_send, d_recv, nbytes):
-        self.dist.all_gather_into_tensor(self._t(d_recv, nbytes * self.world), self._t(d_send, nbytes), group=self.group)
-
-    def all_gather_rows(self, d_local, n_local, row_bytes, d_out):
-        torch = self.torch
-        cnt = torch.tensor([int(n_local)], dtype=torch.int32, device=self.dev)
-        counts = torch.empty(self.world, dtype=torch.int32, device=self.dev)
-        self.dist.all_gather_into_tensor(counts, cnt, group=self.group)
-        counts = [int(c) for c in counts.cpu()]
-        width = max(counts) * int(row_bytes)
-        if width == 0:
-            return counts
-        mine = torch.zeros(width, dtype=torch.uint8, device=self.dev)
-        if n_local:
-            mine[: n_local * row_bytes] = self._t(d_local, n_local * row_bytes)
-        slab = torch.empty(width * self.world, dtype=torch.uint8, device=self.dev)
-        self.dist.all_gather_into_tensor(slab, mine, group=self.group)
-        out = self._t(d_out, sum(counts) * row_bytes)
-        at = 0
-        for r, c in enumerate(counts):
-            out[at: at + c * row_bytes] = slab[r * width: r * width + c * row_bytes]
-            at += c * row_bytes
-        return counts
-
-    def all_reduce(self, values, op="max"):
-        self.engine.sync()
-        t = self.torch.as_tensor(np.atleast_1d(np.asarray(values, np.float64)), device=self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX, group=self.group)
-        return t.cpu().numpy()
-
-    def barrier(self):
-        self.all_reduce([0.0], "sum")
-
-
-def comm_from_env(engine, single_rank_communicator=False, log=None):
-    """RcclComm.from_env, agreed on by all ranks; if any rank could not bring the C-ABI communicator up, all of them use
-    TorchComm instead (and say so through ``log``)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
-        return RcclComm.from_env(engine, single_rank_communicator)
-    import torch
-    import torch.distributed as dist
-    comm, err = None, ""
-    try:
-        comm = RcclComm.from_env(engine)
-    except Exception as e:     # noqa: BLE001 - whatever the cause, the ranks must agree on the transport
-        err = repr(e)
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=world)
-    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok[0]) == 1:
-        return comm
-    if comm is not None:
-        comm.close()
-    if log:
-        log("C-ABI RCCL communicator unavailable (%s): collectives go through torch.distributed's nccl backend" % (err or "another rank failed"))
-    return TorchComm(engine, dist.new_group(backend="nccl"))
 
 
 class HostComm:
@@ -357,7 +291,7 @@ def knn_gallery_sharded(engine, xq, xb, k, comm=None, group=None):
         db = DevArray.from_numpy(engine, np.ascontiguousarray(xb[lo:hi], np.float32))
         dD, dI = DevArray(engine, (nq, k), np.float32), DevArray(engine, (nq, k), np.int32)
         try:
-            knn_gallery_sharded_dev(engine, dq.ptr, nq, db.ptr, hi - lo, lo, d, k, dD.ptr, dI.ptr)
+            knn_gallery_sharded_dev(engine, dq.ptr, nq, db.ptr, hi - lo, lo, d, k, dD.ptr, dI.ptr, comm.world)
             return dD.numpy(), dI.numpy()
         finally:
             for a in (dq, db, dD, dI):
@@ -379,6 +313,14 @@ def knn_gallery_sharded(engine, xq, xb, k, comm=None, group=None):
     return merge_topk(list(d_all), list(i_all), k)
 
 
-def knn_gallery_sharded_dev(engine, d_xq, nq, d_xb_local, nb_local, index_base, d, k, d_D, d_I):
+def knn_gallery_sharded_dev(engine, d_xq, nq, d_xb_local, nb_local, index_base, d, k, d_D, d_I, world=None):
+    """reid_knn_gallery_sharded_dev; ``world`` (the job's rank count as the caller sees it) must be what the context's
+    communicator spans - a context without one would search its own shard only."""
+    if world is not None:
+        w = C.c_int()
+        check(engine.lib.reid_comm_info(engine.h, None, C.byref(w)))
+        if w.value != int(world):
+            raise RuntimeError("knn_gallery_sharded_dev: the job has %d ranks but this context's communicator spans %d "
+                               "(reid_comm_init missing?)" % (world, w.value))
     check(engine.lib.reid_knn_gallery_sharded_dev(engine.h, C.c_void_p(d_xq), int(nq), C.c_void_p(d_xb_local or 0), int(nb_local),
                                                   int(index_base), int(d), int(k), C.c_void_p(d_D), C.c_void_p(d_I)))

@@ -56,3 +56,60 @@ class CameraStream:
             self.metric.close()
             if self._own:
                 self.eng.close()
+
+
+class ShardedCameraStream:
+    """One camera stream whose frames are dealt over the ranks of a multi-GPU job (BASELINE configs[3]):
+    every rank embeds its round-robin share of a frame's crops (`parallel.round_robin`), ONE device-side all-gather per frame
+    (`reid_frame_gather`: equal blocks of ceil(n / world) rows, zero padding rows) puts the frame's features into the frame
+    slot on EVERY rank, and every rank then computes the full cost matrices and keeps its own copy of the feature bank up to
+    date - as DeepSORT would on every rank.  Same call order as `CameraStream` (submit, then per frame step + commit); all
+    arguments and results are in DETECTION order, the mapping to rows of the gathered slot (`parallel.frame_rows`) stays inside.
+    `engine` carries the rank's communicator (`RcclComm`); with world 1 this is `CameraStream` on an existing engine."""
+
+    def __init__(self, engine, comm, max_dist=0.15, budget=100, metric="cosine", max_tracks=4096):
+        self.eng, self.rank, self.world = engine, int(comm.rank), int(comm.world)
+        self.max_dist = max_dist
+        self.metric = NearestNeighborDistanceMetric(metric, max_dist, budget, max_tracks=max_tracks, engine=engine)
+        self._frame = 0
+        self._rows = None
+
+    def share(self, crops):
+        """This rank's crops of a frame: detections rank, rank + world, ..."""
+        from .parallel import round_robin
+        return [crops[int(i)] for i in round_robin(len(crops), self.world, self.rank)]
+
+    def submit(self, crops):
+        """Queue upload + embedding of this rank's share of the FIRST frame; later frames ride on `step(next_crops=...)`.
+        ``crops``: the whole frame's crops, identical on every rank."""
+        self.eng.frame_submit(self._frame & 1, self.share(crops))
+
+    def step(self, n, targets, track_boxes=None, det_boxes=None, next_crops=None):
+        """Frame of ``n`` detections (its crops were submitted before): gather, costs against `targets`, the next frame's share
+        submitted in between.  Returns (features[n,512], appearance_cost[t,n], iou_cost[t,n] | None) in detection order."""
+        from .parallel import frame_rows
+        slot = self._frame & 1
+        rows, per = frame_rows(n, self.world)
+        self.eng.frame_gather(slot, per, self.world)
+        dets = None
+        if track_boxes is not None and det_boxes is not None:
+            # the slot holds world * per rows; padding rows get a unit box (their cost columns are dropped below)
+            dets = np.tile(np.asarray([0.0, 0.0, 1.0, 1.0]), (self.world * per, 1))
+            dets[rows] = np.asarray(det_boxes, np.float64).reshape(-1, 4)[:n]
+        self.metric.frame_distance_begin(slot, targets, self.max_dist, track_boxes if dets is not None else None, dets)
+        if next_crops is not None:
+            self.eng.frame_submit(slot ^ 1, self.share(next_crops))
+        feats, cost, icost = self.metric.frame_distance_end(slot)
+        self._rows = rows
+        return feats[rows], cost[:, rows], None if icost is None else icost[:, rows]
+
+    def commit(self, dets, targets, active_targets):
+        """partial_fit: detection dets[i] of the frame just stepped becomes a sample of track targets[i] (on every rank's bank)."""
+        rows = self._rows[np.asarray(dets, np.int64)] if len(dets) else np.empty(0, np.int64)
+        self.metric.frame_partial_fit(self._frame & 1, rows.astype(np.int32), targets, active_targets)
+        self._frame += 1
+
+    def close(self, destroy=False):
+        self.eng.sync()
+        if destroy:
+            self.metric.close()

@@ -946,34 +946,174 @@ def test_entry_points_from_a_worker_thread(eng_w0):
 
 
 # ----------------------------------------------------------------------------- multi-GPU exchange behind the C ABI (one GPU here)
-def test_standby_transport_moves_raw_device_ranges_through_torch_distributed(eng):
-    """parallel.TorchComm (what bench.py falls back to when the C-ABI communicator cannot be made): torch.distributed's nccl
-    backend on the engine's raw device pointers, one rank."""
-    import socket
-    import torch.distributed as dist
+def _loopback_engines(world, sd=None):
+    """`world` engine contexts on device 0 joined by the loop-back communicator of libreid_hip_debug.so (one host thread per
+    rank drives them): the multi-rank code of csrc/comm.hip with world > 1 on one GPU."""
+    import ctypes as C
+    from reid_amd.engine import Engine
+    engs = [Engine(0) for _ in range(world)]
+    if sd is not None:
+        blob, manifest, _ = weights.pack_seres18(sd)
+        for e in engs:
+            e.load_seres18(blob, manifest)
+    arr = (C.c_void_p * world)(*[e.h for e in engs])
+    _ffi.check(_ffi.debug_lib().reid_debug_comm_loopback(arr, world))
+    return engs
+
+
+def _run_ranks(world, fn):
+    """fn(rank) on one thread per rank (ctypes releases the GIL inside the C calls, so the ranks meet in the collectives)."""
+    import threading
+    res, err = [None] * world, [None] * world
+
+    def work(r):
+        try:
+            res[r] = fn(r)
+        except BaseException as e:     # noqa: BLE001 - reported below, on the main thread
+            err[r] = e
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    for r, e in enumerate(err):
+        if e is not None:
+            raise AssertionError("rank %d: %r" % (r, e))
+    return res
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_loopback_ranks_crops_sharded_and_gallery_sharded(eng_w0, world):
+    """The device-resident multi-GPU entry points with SEVERAL ranks on one GPU (loop-back communicator, see _loopback_engines):
+    embed_sharded_dev with equal, ragged and fewer-crops-than-ranks shards (reid_allgather_dev / reid_allgather_rows_dev: counts,
+    padded payload, compaction), each rank's row block of the distance matrix, and reid_knn_gallery_sharded_dev with
+    index_base > 0, empty shards, k larger than a shard and ties across shards - every rank must hold exactly what a
+    single-context run produces."""
     from reid_amd import parallel
-    if dist.is_initialized():
-        pytest.skip("a process group already exists in this process")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    eng, sd = eng_w0
+    engs = _loopback_engines(world, sd)
     try:
-        comm = parallel.TorchComm(eng, dist.new_group(backend="nccl"))
-        x = np.random.default_rng(4).normal(size=(19, 512)).astype(np.float32)
-        dx = parallel.DevArray.from_numpy(eng, x)
-        dy = parallel.DevArray(eng, x.shape)
-        comm.all_gather(dx.ptr, dy.ptr, x.nbytes)
-        torch.cuda.synchronize()
-        assert np.array_equal(dy.numpy(), x)
-        dz = parallel.DevArray(eng, x.shape)
-        assert comm.all_gather_rows(dx.ptr, 19, 2048, dz.ptr) == [19]
-        torch.cuda.synchronize()
-        assert np.array_equal(dz.numpy(), x)
-        assert comm.all_reduce([2.5, -4.0], "max").tolist() == [2.5, -4.0]
-        comm.barrier()
+        rng = np.random.default_rng(11)
+        xb = rng.normal(size=(203, 64)).astype(np.float32)
+        xb[150] = xb[7]                                                   # the same row in two shards: lowest global index first
+        xq = np.concatenate([xb[:20] + 0.01 * rng.normal(size=(20, 64)).astype(np.float32), xb[7:8]], 0)
+        want_knn = eng.knn(xq, xb, 9)
+        want_small = eng.knn(xq, xb[:3], 3)
+        crop_sets = {n: synth.smooth_crops_u8(n, 30 + n) for n in (world * 3, world * 3 + 1, max(1, world - 1))}
+        want_emb = {n: eng.embed_u8(c) for n, c in crop_sets.items()}
+
+        def rank_fn(r):
+            e = engs[r]
+            comm = parallel.RcclComm.attach(e)
+            assert (comm.rank, comm.world) == (r, world)
+            out = {}
+            for n, crops in crop_sets.items():
+                emb_all, (lo, hi) = parallel.embed_sharded(e, crops, comm)
+                out["emb%d" % n] = emb_all.numpy()
+                out["blk%d" % n] = parallel.distmat_row_block(e, emb_all, lo, hi, _ffi.METRIC_L2).numpy()
+                out["lohi%d" % n] = (lo, hi)
+            out["knn"] = parallel.knn_gallery_sharded(e, xq, xb, 9, comm)
+            out["knn_small"] = parallel.knn_gallery_sharded(e, xq, xb[:3], 5, comm)      # most shards empty, k > gallery
+            assert comm.all_reduce([float(r), 1.0], "sum").tolist() == [world * (world - 1) / 2.0, float(world)]
+            assert comm.all_reduce([float(r)], "max").tolist() == [world - 1.0]
+            return out
+
+        res = _run_ranks(world, rank_fn)
+        for r, out in enumerate(res):
+            for n in crop_sets:
+                assert np.array_equal(out["emb%d" % n], want_emb[n]), (r, n)          # gather order = crop order, bit-equal
+                lo, hi = out["lohi%d" % n]
+                assert (lo, hi) == parallel.shard_bounds(n, world, r)
+                if hi > lo:
+                    assert np.array_equal(out["blk%d" % n], eng.distmat(want_emb[n][lo:hi], want_emb[n], _ffi.METRIC_L2))
+            D, I = out["knn"]
+            assert np.array_equal(I, want_knn[1]) and np.array_equal(D, want_knn[0])
+            assert I[20, 0] == 7 and I[20, 1] == 150                                  # the cross-shard tie
+            Ds, Is = out["knn_small"]
+            assert np.array_equal(Is[:, :3], want_small[1]) and np.array_equal(Ds[:, :3], want_small[0])
+            assert (Is[:, 3:] == -1).all() and np.isinf(Ds[:, 3:]).all()
     finally:
-        dist.destroy_process_group()
+        for e in engs:
+            e.close()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 8])
+def test_loopback_ranks_tracking_frames(eng_w0, world):
+    """tracking.ShardedCameraStream with several ranks on one GPU: round-robin shares, reid_frame_gather (equal blocks, zeroed
+    padding rows), costs over the gathered slot, bank updates from gathered rows - against the single-context CameraStream
+    flow on the same frames (frames of 0, 1, world - 1, world + 1 ... detections)."""
+    from reid_amd import parallel
+    from reid_amd.nn_matching import NearestNeighborDistanceMetric
+    from reid_amd.tracking import ShardedCameraStream
+    eng, sd = eng_w0
+    engs = _loopback_engines(world, sd)
+    try:
+        rng = np.random.default_rng(12)
+        counts = [5, 0, 1, world - 1, world + 1, 13, 2 * world, 3]
+        pool = synth.ragged_crops_u8(24, seed=9)
+        frames = [[pool[(7 * f + i) % 24] for i in range(n)] for f, n in enumerate(counts)]
+        tracks = [3, 5, 8, 9]
+        boxes = rng.uniform(0, 400, (2 * world + 14, 4))
+        boxes[:, 2:] = rng.uniform(15, 100, (len(boxes), 2))
+        seed_feats = rng.normal(size=(8, 512)).astype(np.float32)
+        seed_feats /= np.linalg.norm(seed_feats, axis=1, keepdims=True)
+
+        def drive(stream, step):
+            stream.metric.partial_fit(seed_feats, np.repeat(tracks, 2), tracks)
+            out = []
+            stream.submit(frames[0])
+            for f, cr in enumerate(frames):
+                n = len(cr)
+                feats, cost, icost = step(stream, n, frames[f + 1] if f + 1 < len(frames) else None)
+                out.append((feats, cost, icost))
+                k = min(n, len(tracks))
+                stream.commit(np.arange(k)[::-1], tracks[:k], tracks)
+            stream.close()
+            return out
+
+        import types
+        one = ShardedCameraStream(eng, types.SimpleNamespace(rank=0, world=1), 0.4, budget=3, max_tracks=16)   # no communicator
+        try:
+            want = drive(one, lambda st, n, nxt: st.step(n, tracks, boxes[:4], boxes[:n], nxt))
+        finally:
+            one.metric.close()
+
+        def rank_fn(r):
+            st = ShardedCameraStream(engs[r], parallel.RcclComm.attach(engs[r]), 0.4, budget=3, max_tracks=16)
+            try:
+                return drive(st, lambda s, n, nxt: s.step(n, tracks, boxes[:4], boxes[:n], nxt))
+            finally:
+                st.metric.close()
+
+        res = _run_ranks(world, rank_fn)
+        for r, got in enumerate(res):
+            for f, ((gf, gc, gi), (wf, wc, wi)) in enumerate(zip(got, want)):
+                assert gf.shape == wf.shape and gc.shape == wc.shape, (r, f)
+                assert np.isfinite(gc).all()
+                assert np.array_equal(gf, wf), (r, f)                    # same kernels on the same crops: bit-equal features
+                np.testing.assert_allclose(gc, wc, rtol=0, atol=1e-6, err_msg="rank %d frame %d" % (r, f))
+                if wi is not None:
+                    assert np.array_equal(gi, wi), (r, f)
+    finally:
+        for e in engs:
+            e.close()
+
+
+def test_sharded_search_without_a_communicator_is_refused(eng):
+    """a context without a communicator that is handed a shard starting at row > 0 must not answer with that
+    shard alone."""
+    from reid_amd import parallel
+    x = np.random.default_rng(1).normal(size=(12, 16)).astype(np.float32)
+    dq, db = parallel.DevArray.from_numpy(eng, x[:3]), parallel.DevArray.from_numpy(eng, x)
+    dD, dI = parallel.DevArray(eng, (3, 2)), parallel.DevArray(eng, (3, 2), np.int32)
+    with pytest.raises(_ffi.ReidHipError, match="index_base"):
+        parallel.knn_gallery_sharded_dev(eng, dq.ptr, 3, db.ptr, 12, 6, 16, 2, dD.ptr, dI.ptr)
+    with pytest.raises(RuntimeError, match="spans 1"):
+        parallel.knn_gallery_sharded_dev(eng, dq.ptr, 3, db.ptr, 12, 0, 16, 2, dD.ptr, dI.ptr, world=2)
+    parallel.knn_gallery_sharded_dev(eng, dq.ptr, 3, db.ptr, 12, 0, 16, 2, dD.ptr, dI.ptr, world=1)
+    assert np.array_equal(dI.numpy(), eng.knn(x[:3], x, 2)[1])
 
 
 def test_rccl_single_rank_communicator_and_device_resident_sharding(eng_w0):
