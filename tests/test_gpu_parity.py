@@ -1022,11 +1022,15 @@ def test_loopback_ranks_crops_sharded_and_gallery_sharded(eng_w0, world):
         res = _run_ranks(world, rank_fn)
         for r, out in enumerate(res):
             for n in crop_sets:
-                assert np.array_equal(out["emb%d" % n], want_emb[n]), (r, n)          # gather order = crop order, bit-equal
+                # gather order = crop order; a shard is a smaller batch than the whole set, and small launches split K differently:
+                # equal up to fp32 summation order (the same bound as the rebatching check of the embed test), identical on all ranks
+                np.testing.assert_allclose(out["emb%d" % n], want_emb[n], rtol=1e-6, atol=1e-6 * np.abs(want_emb[n]).max(), err_msg=str((r, n)))
+                assert np.array_equal(out["emb%d" % n], res[0]["emb%d" % n]), (r, n)
                 lo, hi = out["lohi%d" % n]
                 assert (lo, hi) == parallel.shard_bounds(n, world, r)
                 if hi > lo:
-                    assert np.array_equal(out["blk%d" % n], eng.distmat(want_emb[n][lo:hi], want_emb[n], _ffi.METRIC_L2))
+                    mine = out["emb%d" % n]
+                    assert np.array_equal(out["blk%d" % n], eng.distmat(mine[lo:hi], mine, _ffi.METRIC_L2))
             D, I = out["knn"]
             assert np.array_equal(I, want_knn[1]) and np.array_equal(D, want_knn[0])
             assert I[20, 0] == 7 and I[20, 1] == 150                                  # the cross-shard tie
@@ -1092,8 +1096,10 @@ def test_loopback_ranks_tracking_frames(eng_w0, world):
             for f, ((gf, gc, gi), (wf, wc, wi)) in enumerate(zip(got, want)):
                 assert gf.shape == wf.shape and gc.shape == wc.shape, (r, f)
                 assert np.isfinite(gc).all()
-                assert np.array_equal(gf, wf), (r, f)                    # same kernels on the same crops: bit-equal features
-                np.testing.assert_allclose(gc, wc, rtol=0, atol=1e-6, err_msg="rank %d frame %d" % (r, f))
+                if gf.size:                                              # a share is a smaller batch: equal up to fp32 summation order
+                    np.testing.assert_allclose(gf, wf, rtol=1e-6, atol=1e-6 * np.abs(wf).max(), err_msg="rank %d frame %d" % (r, f))
+                    assert np.array_equal(gf, res[0][f][0]), (r, f)      # and the same bits on every rank
+                np.testing.assert_allclose(gc, wc, rtol=0, atol=2e-6, err_msg="rank %d frame %d" % (r, f))
                 if wi is not None:
                     assert np.array_equal(gi, wi), (r, f)
     finally:
