@@ -523,6 +523,26 @@ def gen_e2e():
              out["cmc"][0], out["map"], eps, num_labels, int((pseudo == -1).sum()), out["eps_margin"]))
 
 
+def gen_renorm():
+    """`--renorm` checkpoints (reid/image_reid_inference.py:154,180-181): the reference's seres18_ibn(renorm=True), whose BatchNorm2d
+    layers are BatchRenormalization2D (batchrenorm.py:26-40, eval math :93-95), loaded strict=True from
+    synth.renorm_state_dict(synth.seres18_state_dict(2)) - which pins that key layout - and run in eval mode on 4 seeded crops."""
+    from reid_amd import synth
+    from reid.backbones.SERes18_IBN import seres18_ibn
+    sd_np = synth.renorm_state_dict(synth.seres18_state_dict(2))
+    model = seres18_ibn(num_classes=751, loss="triplet", renorm=True)
+    res = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model.eval()
+    crops = synth.smooth_crops_u8(4, 8)
+    x = torch.from_numpy(crops).float().div(255.0).sub(0.5).div(0.5).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        emb, logits = model(x)
+    np.savez_compressed(os.path.join(OUT, "renorm.npz"), emb=emb.numpy(), logits=logits.numpy())
+    print("renorm: emb", tuple(emb.shape), "|emb| row0", float(emb[0].norm()), "renorm keys",
+          sum(1 for k in sd_np if k.endswith(".gamma")))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -538,3 +558,4 @@ if __name__ == "__main__":
     gen_config5()
     gen_siblings()
     gen_e2e()
+    gen_renorm()

@@ -58,6 +58,9 @@ def _t(sd, k):
 
 
 def _bn(sd, prefix, x):
+    if prefix + ".gamma" in sd:      # --renorm checkpoint: BatchRenormalization2D, eval branch (batchrenorm.py:93-95)
+        mean, var = _t(sd, prefix + ".running_avg_mean"), _t(sd, prefix + ".running_avg_var")
+        return _t(sd, prefix + ".gamma") * ((x - mean) / torch.sqrt(var + BN_EPS)) + _t(sd, prefix + ".beta")
     return F.batch_norm(x, _t(sd, prefix + ".running_mean"), _t(sd, prefix + ".running_var"),
                         _t(sd, prefix + ".weight"), _t(sd, prefix + ".bias"), False, 0.0, BN_EPS)
 

@@ -327,3 +327,45 @@ def e2e_problem(seed=100, n_ids=24, n_cams=4, n_gallery=300, n_query=60, n_seqs=
     qs = rng.integers(0, n_seqs, n_query).astype(np.int64)
     return {"gl": gl, "gc": gc, "gs": gs, "ql": ql, "qc": qc, "qs": qs,
             "g_img": identity_images_f32(gl, gc, seed + 1), "q_img": identity_images_f32(ql, qc, seed + 2)}
+
+
+def renorm_state_dict(sd):
+    """The ``state_dict`` layout of ``seres18_ibn(renorm=True)`` (checkpoints trained with ``--renorm``,
+    reid/image_reid_inference.py:154,180-181) from a plain one: every BatchNorm2d the constructor swaps for
+    ``BatchRenormalization2D`` (SERes18_IBN.py:102-113,203-204: bn0, each block's bn1 - or the BN half of its IBN -, bn2 and
+    the shortcut's bn) carries ``gamma / beta / running_avg_mean / running_avg_var`` shaped [1,C,1,1] plus the scalars
+    ``num_tracked_batch, r_max, d_max`` (batchrenorm.py:26-40); the unused SE norm of layers 1-3 becomes a
+    ``BatchRenormalization1D`` ([1,C]).  bnneck and layer 4's SE norm stay BatchNorm1d."""
+    out = OrderedDict()
+    ren = {"weight": "gamma", "bias": "beta", "running_mean": "running_avg_mean", "running_var": "running_avg_var"}
+    for k, v in sd.items():
+        prefix, _, leaf = k.rpartition(".")
+        is_bn = (prefix + ".running_mean") in sd
+        plain = prefix == "bnneck" or (prefix.endswith("seblock.bn") and is_bn)     # BatchNorm1d in both layouts
+        if not is_bn or plain:
+            out[k] = v
+            continue
+        shape = (1, -1) if prefix.endswith("seblock.bn.BN") else (1, -1, 1, 1)
+        if leaf in ren:
+            out[prefix + "." + ren[leaf]] = np.asarray(v, np.float32).reshape(shape)
+        elif leaf == "num_batches_tracked":
+            out[prefix + ".num_tracked_batch"] = np.asarray(0, dtype=np.int64)
+            out[prefix + ".r_max"] = np.asarray(1.0, dtype=np.float32)
+            out[prefix + ".d_max"] = np.asarray(0.0, dtype=np.float32)
+    return out
+
+
+def tracking_stream(frames=600, seed=3, pool_size=256, max_dets=80):
+    """Stand-in for the MOT16-02 detection dump of BASELINE configs[3] (not in the container):
+    ``frames`` frames, detections per frame ~ Poisson(30) clipped to [1, max_dets] (MOT16-02: 17 833 boxes over 600 frames),
+    crops drawn from a pool of ragged crops (h log-uniform in [40, 400], w = h * U(0.3, 0.5)), tlwh boxes.
+    Returns (counts int[frames], pool list of uint8[h,w,3], boxes float64[max_dets,4], crops_of(f) -> the frame's crop list)."""
+    rng = np.random.default_rng(seed)
+    counts = np.clip(rng.poisson(30, frames), 1, max_dets)
+    pool = ragged_crops_u8(pool_size, seed=seed)
+    boxes = rng.uniform(0, 500, (max_dets, 4))
+    boxes[:, 2:] = rng.uniform(20, 120, (max_dets, 2))
+
+    def crops_of(f):
+        return [pool[(f * 7 + i) % pool_size] for i in range(int(counts[f]))]
+    return counts, pool, boxes, crops_of

@@ -44,6 +44,27 @@ def normalize_state_dict(state_dict):
         if k.startswith("basicBlock"):
             k = synth.sibling_key(k, to_reference=False)
         out[k] = _np(v)
+    return _renorm_to_plain(out)
+
+
+_RENORM_KEYS = {"gamma": "weight", "beta": "bias", "running_avg_mean": "running_mean", "running_avg_var": "running_var",
+                "num_tracked_batch": "num_batches_tracked"}
+
+
+def _renorm_to_plain(sd):
+    """`--renorm` checkpoints (seres18_ibn(renorm=True), SERes18_IBN.py:102-113,203-204): BatchRenormalization layers hold
+    gamma / beta / running_avg_mean / running_avg_var shaped [1,C,1,1] (or [1,C]) plus num_tracked_batch, r_max, d_max
+    (batchrenorm.py:26-40).  In eval mode they ARE BatchNorm (batchrenorm.py:93-95), so the keys are renamed to BatchNorm's and
+    flattened; r_max / d_max only steer training and are dropped."""
+    if not any(k.endswith(".running_avg_mean") for k in sd):
+        return sd
+    out = OrderedDict()
+    for k, v in sd.items():
+        prefix, _, leaf = k.rpartition(".")
+        if (prefix + ".running_avg_mean") not in sd:
+            out[k] = v
+        elif leaf in _RENORM_KEYS:
+            out[prefix + "." + _RENORM_KEYS[leaf]] = v.reshape(-1) if leaf != "num_tracked_batch" else v
     return out
 
 

@@ -1367,3 +1367,115 @@ def test_e2e_harness_matches_reference_chain(eng_w0, golden_dir):
                                               engine=eng)
     np.testing.assert_array_equal(cmc2, cmc)
     assert map2 == mean_ap
+
+
+# ----------------------------------------------------------------------------- --renorm checkpoints
+def test_renorm_checkpoint_matches_reference_fixture(eng, golden_dir):
+    """A checkpoint in the --renorm layout (every BatchNorm2d a BatchRenormalization2D: gamma / beta / running_avg_* [1,C,1,1],
+    SERes18_IBN.py:102-113,203-204, batchrenorm.py:26-40) through weights.pack_seres18 and through the model object, against
+    the reference's own seres18_ibn(renorm=True) in eval mode (tests/golden/renorm.npz)."""
+    from reid_amd import models
+    g = np.load(os.path.join(golden_dir, "renorm.npz"))
+    rsd = synth.renorm_state_dict(synth.seres18_state_dict(2))
+    crops = synth.smooth_crops_u8(4, 8)
+    blob, manifest, _ = weights.pack_seres18({"module." + k: v for k, v in rsd.items()})     # as the trainer saves it
+    eng.load_seres18(blob, manifest)
+    emb, logits = eng.embed_u8(crops, logits=True)
+    for mine, ref in ((emb, g["emb"]), (logits, g["logits"])):
+        assert np.abs(mine - ref).max() / np.abs(ref).max() < 5e-5
+    cos = (emb * g["emb"]).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(g["emb"], axis=1)
+    assert (1 - cos).max() < 1e-5
+    m = models.build_model("seres18_ibn", num_classes=751, loss="triplet", pretrained=False).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rsd.items()}, strict=True)
+    out = m(seres18.preprocess_u8(crops))
+    assert np.abs(out.numpy() - g["emb"]).max() / np.abs(g["emb"]).max() < 5e-5
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[2] at its stated size
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", [0, 1])
+def test_full_size_config2_swin_properties(eng, precision):
+    """Swin-T v1 on 4096 images of 224 x 224 (BASELINE configs[2]) through size-independent properties - 256 distinct images, each
+    16 times, shuffled.  Images are independent in eval mode (LayerNorm per token, window attention per image, MixedNorm's
+    InstanceNorm per image), so (a) copies of an image get bit-identical embeddings wherever they sit in the batch, (b) the
+    96-d distance matrix has a ~0 diagonal and the 16 nearest neighbours of every row are exactly its 16 copies, (c) six rows
+    equal the oracle (torch-CPU restatement, pinned by swin_seed0.npz) within the mode's tolerance."""
+    from oracle import swin
+    sd = synth.swin_state_dict(0)
+    eng.load_swin(*weights.pack_swin(sd)[:2])
+    rng = np.random.default_rng(12)
+    base = synth.images_f32(256, 2)
+    ids = np.repeat(np.arange(256), 16)
+    rng.shuffle(ids)
+    x = base[ids]                                                        # 2.4 GB of host memory
+    eng.set_precision(precision)
+    try:
+        eng.set_chunk(256)
+        emb = eng.swin_embed_f32_nchw(x)
+        del x
+        first = np.asarray([np.flatnonzero(ids == c)[0] for c in range(256)])
+        assert emb.shape == (4096, 96) and np.isfinite(emb).all()
+        assert np.array_equal(emb, emb[first][ids])                     # (a) position invariance, bit-exact
+        dist = eng.distmat(emb, emb, _ffi.METRIC_L2)
+        scale = float(np.median(dist))
+        same = ids[:, None] == ids[None, :]
+        assert dist[same].max() <= 1e-2 * scale
+        assert dist[~same].min() > 5 * dist[same].max()
+        _, knn = eng.knn(emb, emb, 16)
+        assert np.array_equal(np.sort(ids[knn], axis=1), np.repeat(ids[:, None], 16, 1))   # (b)
+        sample = first[:6]
+        want = swin.embed(sd, base[ids[sample]])                         # (c)
+        cos = (emb[sample] * want).sum(1) / np.linalg.norm(emb[sample], axis=1) / np.linalg.norm(want, axis=1)
+        assert (1 - cos).max() < (1e-4 if precision else 1e-5)
+        assert np.abs(emb[sample] - want).max() / np.abs(want).max() < (1e-2 if precision else 2e-4)
+    finally:
+        eng.set_chunk(128)
+        eng.set_precision(0)
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[3] stand-in at its stated size
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", [0, 1])
+def test_full_size_config3_tracking_stream(eng_w0, precision):
+    """The 600-frame stream of SURVEY.md 8(d) config 4 (detections ~ Poisson(30) in [1, 80], ragged crops; synth.tracking_stream -
+    the generator bench.py times) through the frame pipeline as the bench drives it (tracking.ShardedCameraStream, one rank):
+    submit f+1 under the costs of f, 40 tracks x 100-sample ring that wraps during the stream.  Every 50th frame is checked
+    against the oracle: features vs oracle preprocess + forward (cosine), the gated appearance cost vs oracle/nn_matching.py over a
+    host bank that was fed the same features frame by frame, the DIoU cost bit-exact."""
+    import types
+    from oracle import nn_matching as onn
+    from reid_amd.tracking import ShardedCameraStream
+    eng, sd = eng_w0
+    counts, pool, boxes, crops_of = synth.tracking_stream(600, 3)
+    tracks = list(range(40))
+    rng = np.random.default_rng(30)
+    seed_feats = rng.normal(size=(40 * 100, 512)).astype(np.float32)
+    eng.set_precision(precision)
+    stream = ShardedCameraStream(eng, types.SimpleNamespace(rank=0, world=1), 0.15, 100)
+    host = onn.NearestNeighborDistanceMetric("cosine", 0.15, budget=100)
+    try:
+        stream.metric.partial_fit(seed_feats, np.repeat(tracks, 100), tracks)
+        host.partial_fit(list(seed_feats), np.repeat(tracks, 100), tracks)
+        stream.submit(crops_of(0))
+        checked = 0
+        for f in range(600):
+            n = int(counts[f])
+            feats, cost, icost = stream.step(n, tracks, boxes[:40], boxes[:n], crops_of(f + 1) if f + 1 < 600 else None)
+            assert feats.shape == (n, 512) and cost.shape == (40, n) and icost.shape == (40, n)
+            if f % 50 == 0 or f == 599:
+                want = seres18.forward(sd, torch.from_numpy(matching.preprocess(crops_of(f))))[0].numpy()
+                cos = (feats * want).sum(1) / np.linalg.norm(feats, axis=1) / np.linalg.norm(want, axis=1)
+                assert (1 - cos).max() < (1e-4 if precision else 1e-5), (f, (1 - cos).max())
+                np.testing.assert_allclose(cost, onn.gate(host.distance(feats, tracks), 0.15), rtol=0, atol=2e-6, err_msg="frame %d" % f)
+                assert np.array_equal(icost, matching.diou_cost(boxes[:40], boxes[:n])), f
+                assert (cost <= 0.15 + 1e-5 + 1e-7).all()
+                checked += 1
+            k = min(n, 40)
+            stream.commit(np.arange(k), tracks[:k], tracks)
+            host.partial_fit(list(feats[:k]), tracks[:k], tracks)
+        assert checked == 13
+        assert stream.metric.samples_count(0) == 100                     # the ring has wrapped (600 samples into 100 slots)
+    finally:
+        stream.close()
+        stream.metric.close()
+        eng.set_precision(0)

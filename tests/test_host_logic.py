@@ -89,6 +89,17 @@ def test_pack_accepts_dataparallel_and_renorm_checkpoints():
         rn["bn0." + new] = rn.pop("bn0." + suffix).reshape(1, 64, 1, 1)
     b3, _, _ = weights.pack_seres18(rn)
     np.testing.assert_array_equal(base, b3)
+    # the whole --renorm layout (every BatchNorm2d a BatchRenormalization2D; pinned strict=True against the reference's
+    # seres18_ibn(renorm=True) in oracle/gen_golden.py::gen_renorm), also with the DataParallel prefix, and through the model object
+    full = synth.renorm_state_dict(sd)
+    assert "bn0.gamma" in full and full["basicBlock11.block_pre.bn1.BN.gamma"].shape == (1, 32, 1, 1) and "bnneck.weight" in full
+    b4, _, _ = weights.pack_seres18({"module." + k: v for k, v in full.items()})
+    np.testing.assert_array_equal(base, b4)
+    from reid_amd.backbone import SERes18IBN
+    m = SERes18IBN(num_classes=751)
+    missing, unexpected = m.load_state_dict(full, strict=True)
+    assert not missing and not unexpected
+    np.testing.assert_array_equal(weights.pack_seres18(m.state_dict())[0], base)
     with pytest.raises(KeyError):
         weights.pack_seres18({"foo": np.zeros(3)})
 

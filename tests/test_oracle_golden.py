@@ -243,3 +243,14 @@ def test_e2e_chain_oracle_matches_reference(golden_dir):
     np.testing.assert_allclose(taps["smoothed"][::step], g["smoothed"], atol=5e-5)
     np.testing.assert_array_equal(cmc, g["cmc"])
     assert abs(mean_ap - float(g["map"])) < 1e-6
+
+
+def test_renorm_checkpoint_oracle_matches_reference(golden_dir):
+    """tests/golden/renorm.npz: the reference's seres18_ibn(renorm=True) (BatchRenormalization2D layers, eval branch
+    batchrenorm.py:93-95) on a state_dict in the --renorm layout (synth.renorm_state_dict, loaded strict=True there)."""
+    g = np.load(os.path.join(golden_dir, "renorm.npz"))
+    rsd = synth.renorm_state_dict(synth.seres18_state_dict(2))
+    crops = synth.smooth_crops_u8(4, 8)
+    emb, logits = seres18.forward(rsd, seres18.preprocess_u8(crops))
+    np.testing.assert_allclose(emb.numpy(), g["emb"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=2e-4, atol=2e-3)
