@@ -43,6 +43,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F32_STEMPOOL")) c->f32_stem_pool = atoi(e);
     if (const char* e = getenv("REID_F32_SPLITK")) c->f32_split_k = atoi(e);
     if (const char* e = getenv("REID_SWIN_FOLD")) c->swin_fold = atoi(e);
+    if (const char* e = getenv("REID_SWIN_STOP")) c->swin_stop = atoi(e);
     if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
     if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;

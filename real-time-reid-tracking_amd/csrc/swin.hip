@@ -1081,6 +1081,11 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
     for (int s = 0; s < 4; ++s) {
         const int C = kDims[s], heads = kHeads[s];
         float* xcur = xs[s];
+        if (ctx->swin_stop >= 0 && bi * 10 > ctx->swin_stop) {   // diagnostics: leave the scratch buffers as they are
+            ctx->swin_last_n = n;
+            ctx->swin_last_tok = H1 * W1;
+            return REID_OK;
+        }
         if (s > 0) {
             // PatchMerging = conv2x2 s2 with weights repacked to (kh, kw, c) order + bias (swin_transformer.py:263-275)
             if (ctx->precision == 1) {
@@ -1098,6 +1103,8 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
         for (int j = 0; j < kLayers[s]; ++j, ++bi) {
             const SwinBlockW& k = w.blk[bi];
             const int shifted = j & 1;
+            const int stop = ctx->swin_stop;   // diagnostics: the stage tap then shows the stream right after that point
+            if (stop >= 0 && bi * 10 > stop) continue;
             // the first block reads the ShadowFeatureExtraction output (kept for the top-down fusion) and writes stage 1's
             // residual stream; every later block updates that stream in place
             const float* xin = (s == 0 && j == 0) ? sfe : xcur;
@@ -1130,10 +1137,13 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                     REID_TRY(linear16(ctx, att16, T, C, C, h.out, k.out_b, C, 0, nullptr, tmp16, nullptr, C));
                     REID_TRY(linear16(ctx, tmp16, T, C, C, h.post, k.post_b, C, 0, xin, nullptr, xcur, C));
                 }
+                if (stop == bi * 10) continue;
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 6);
                 launch_layernorm<f16>(ctx, xcur, T, C, k.ln2_g, k.ln2_b, ln16);
                 prof_end(ctx);
+                if (stop == bi * 10 + 2) continue;
                 REID_TRY(linear16(ctx, ln16, T, C, C, h.fc1, k.fc1_b, 4 * C, 1, nullptr, big16, nullptr, 4 * C));
+                if (stop == bi * 10 + 3) continue;
                 REID_TRY(linear16(ctx, big16, T, 4 * C, 4 * C, h.fc2, k.fc2_b, C, 0, xcur, nullptr, xcur, C));
                 continue;
             }
@@ -1221,15 +1231,17 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
 // [n][56][56][96], 1..4 = outputs of the four stages (NHWC fp32 residual streams), 5 = GeM_1D output [n][96].  Valid when the
 // call ran as ONE pass (n <= min(chunk, 256)); the buffers are the forward's own workspaces.
 extern "C" int reid_debug_swin_stage(reid_ctx* ctx, int stage, float* out, size_t max_floats, size_t* count) {
-    ARG_CHECK(ctx && out && stage >= 0 && stage <= 5);
+    ARG_CHECK(ctx && out && stage >= 0 && stage <= 7);
     CTX_GUARD(ctx);
-    static const char* names[6] = {"swin.sfe", "swin.x0", "swin.x1", "swin.x2", "swin.x3", "swin.gem"};
+    static const char* names[8] = {"swin.sfe", "swin.x0", "swin.x1", "swin.x2", "swin.x3", "swin.gem", "swin.ln", "swin.big"};
     auto it = ctx->ws.find(names[stage]);
     if (it == ctx->ws.end() || ctx->swin_last_n <= 0) {
         reid_set_error("reid_debug_swin_stage: no Swin forward has run on this context");
         return REID_ERR_STATE;
     }
-    const size_t per = stage == 5 ? 96 : ((size_t)ctx->swin_last_tok * 96) >> (stage <= 1 ? 0 : stage - 1);
+    // 6 / 7: the raw LayerNorm-output and qkv / MLP-hidden scratch buffers (diagnostics with REID_SWIN_STOP)
+    const size_t per = stage == 5 ? 96 : stage == 6 ? (size_t)ctx->swin_last_tok * 96 : stage == 7 ? (size_t)ctx->swin_last_tok * 384
+                                   : ((size_t)ctx->swin_last_tok * 96) >> (stage <= 1 ? 0 : stage - 1);
     const size_t total = per * ctx->swin_last_n;
     if (count) *count = total;
     const size_t ncopy = total < max_floats ? total : max_floats;
