@@ -44,6 +44,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F32_SPLITK")) c->f32_split_k = atoi(e);
     if (const char* e = getenv("REID_SWIN_FOLD")) c->swin_fold = atoi(e);
     if (const char* e = getenv("REID_SWIN_STOP")) c->swin_stop = atoi(e);
+    if (const char* e = getenv("REID_SELECT_TWO_PASS")) c->select_two_pass = atoi(e);
     if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
     if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
@@ -1066,11 +1067,74 @@ extern "C" int reid_distmat(reid_ctx* ctx, const float* x, int m, const float* y
     return REID_OK;
 }
 
+// zero-padded copy with rows of a multiple of `mult` floats (mult = 4: 16-byte rows; 32: whole K-tiles of the LDS-DMA loops)
+static int pad_rows_to(reid_ctx* ctx, const char* name, const float* d_x, int m, int d, int mult, const float** out, int* ld) {
+    if (d % mult == 0 && ((uintptr_t)d_x % 16) == 0) {
+        *out = d_x;
+        *ld = d;
+        return REID_OK;
+    }
+    const int dp = (d + mult - 1) / mult * mult;
+    float* buf;
+    REID_TRY(ctx_ws(ctx, name, (size_t)m * dp * 4, (void**)&buf));
+    HIP_TRY(hipMemsetAsync(buf, 0, (size_t)m * dp * 4, ctx->stream));
+    HIP_TRY(hipMemcpy2DAsync(buf, (size_t)dp * 4, d_x, (size_t)d * 4, (size_t)d * 4, m, hipMemcpyDeviceToDevice, ctx->stream));
+    *out = buf;
+    *ld = dp;
+    return REID_OK;
+}
+
+// The k smallest distances of every row of x to the rows of y with the selection fused into the distance GEMM
+// (dist_select.hip): no m x n matrix.  Returns 1 when the shape is outside the fused kernel's range (k > 64, huge row pitch):
+// the caller then takes the two-pass path.
+static int select_fused_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric, int k, float* d_D,
+                            int32_t* d_I) {
+    if (k > SEL_KMAX) return 1;
+    const float *xp, *yp;
+    int ldx, ldy;
+    REID_TRY(pad_rows_to(ctx, "sel.xpad", d_x, m, d, 32, &xp, &ldx));
+    REID_TRY(pad_rows_to(ctx, "sel.ypad", d_y, n, d, 32, &yp, &ldy));
+    SelectParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = xp; p.lda = ldx;
+    p.B = yp; p.ldb = ldy;
+    p.M = m; p.N = n; p.K = ldx;
+    p.metric = metric; p.k = k;
+    if (!dist_select_supported(p)) return 1;
+    if (metric != REID_METRIC_DOT) {
+        float *xx, *yy;
+        REID_TRY(ctx_ws(ctx, "dist.xx", (size_t)m * 4, (void**)&xx));
+        REID_TRY(ctx_ws(ctx, "dist.yy", (size_t)n * 4, (void**)&yy));
+        REID_TRY(launch_row_sqnorm(ctx, xp, m, ldx, ldx, xx));
+        REID_TRY(launch_row_sqnorm(ctx, yp, n, ldy, ldy, yy));
+        p.row_sq = xx; p.col_sq = yy;
+    }
+    p.S = select_segments(m, n);
+    REID_TRY(ctx_ws(ctx, "sel.lists", (size_t)m * p.S * SEL_CAP * 8, (void**)&p.lists));
+    REID_TRY(ctx_ws(ctx, "sel.counts", (size_t)m * p.S * 4, (void**)&p.counts));
+    // a per-row bound from a SAMPLE of y (its first 256 rows; they are part of y, so the k-th smallest of the sample bounds the
+    // k-th smallest of all): with it the sweep appends a few per cent of a block's first tiles instead of all of them
+    const int sample = 256;
+    if (n >= 8 * sample && k <= sample) {
+        float* thr0;
+        REID_TRY(ctx_ws(ctx, "sel.thr0", (size_t)m * 4, (void**)&thr0));
+        SelectParams ps = p;
+        ps.N = sample;
+        ps.S = select_segments(m, sample);
+        REID_TRY(launch_dist_select(ctx, ps, nullptr, nullptr, thr0));
+        p.thr0 = thr0;
+    }
+    return launch_dist_select(ctx, p, d_D, d_I, nullptr);
+}
+
 extern "C" int reid_argmin_rows_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric,
                                     int32_t* d_idx, float* d_val) {
-    ARG_CHECK(ctx && d_idx && m >= 0 && n >= 1);
+    ARG_CHECK(ctx && d_x && d_y && d_idx && m >= 0 && n >= 1 && d >= 1);
     CTX_GUARD(ctx);
+    ARG_CHECK(metric >= REID_METRIC_L2 && metric <= REID_METRIC_DOT);
     if (m == 0) return REID_OK;
+    const int st = ctx->select_two_pass ? 1 : select_fused_dev(ctx, d_x, m, d_y, n, d, metric, 1, d_val, d_idx);
+    if (st != 1) return st;
     float* dist;
     REID_TRY(ctx_ws(ctx, "sel.dist", (size_t)m * n * 4, (void**)&dist));
     REID_TRY(reid_distmat_dev(ctx, d_x, m, d_y, n, d, metric, dist));
@@ -1100,7 +1164,11 @@ extern "C" int reid_knn_dev(reid_ctx* ctx, const float* d_xq, int nq, const floa
     ARG_CHECK(ctx && d_D && d_I && nq >= 0 && nb >= 1 && k >= 1);
     CTX_GUARD(ctx);
     if (nq == 0) return REID_OK;
-    // query tiles bound the scratch matrix to ~1 GiB
+    if (!ctx->select_two_pass) {   // fused distance + selection: the nq x nb matrix is never written
+        const int st = select_fused_dev(ctx, d_xq, nq, d_xb, nb, d, REID_METRIC_L2SQR, k, d_D, d_I);
+        if (st != 1) return st;
+    }
+    // two-pass form (k > 64, or REID_SELECT_TWO_PASS=1 for A/B): query tiles bound the scratch matrix to ~1 GiB
     const int rows_per = (int)((size_t(1) << 28) / (size_t)nb) > 0 ? (int)((size_t(1) << 28) / (size_t)nb) : 1;
     float* dist;
     const int tile = nq < rows_per ? nq : rows_per;

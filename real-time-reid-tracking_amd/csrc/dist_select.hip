@@ -1,0 +1,332 @@
+// Distance GEMM with the SELECTION fused into its epilogue: per row of x the k smallest distances to the rows of y (k = 1: the
+// row arg-min) WITHOUT writing the m x n matrix.
+//   reid/evaluate.py:58-63        score = gf @ q, argsort, [0]            -> reid_argmin_rows(_dev)
+//   reid/faiss_utils.py:97-111    faiss brute-force k-NN (bfKnn)           -> reid_knn(_dev), reid_knn_gallery_sharded_dev
+// The two-pass form (gemm_f32_dma_kernel<E_DIST> + topk_rows_kernel) writes and re-reads 4 m n bytes (214 MB for the
+// Market-size search, whose operands are 39.5 MB); here a distance leaves the registers only if it can still belong to its
+// row's k smallest.
+//
+// Work split: a block owns 128 rows of x and ONE of S contiguous segments of y's 128-row tiles and sweeps them; the K loop is
+// the LDS-DMA loop of gemm_f32_dma.hip (v_mfma_f32_32x32x2_f32, exact fp32 - the distances are bit-identical to the matrix
+// kernel's).  Per row the block keeps, in LDS, a threshold thr (the value of the k-th smallest key seen so far in this
+// segment; initially the caller's bound, +inf if none) and a counter; an element with v <= thr is appended to the row's
+// candidate list in global memory (L2-resident, written by this block only).  Lists hold CAP = 128 keys; a tile is filtered in
+// two halves of 64 columns, and a row whose list holds more than 64 keys after a half is compacted to its k smallest (rank by
+// counting, one wave per row, in the then idle LDS stage buffers), which also tightens thr - so a list never overflows and
+// nothing is lost: the row's true k smallest of the segment are always in its list.  Keys are (order-preserving float bits
+// << 32 | column), so "smallest key" = smallest distance, ties -> lowest column, the engine's rule everywhere.
+// A second, tiny kernel merges the S sorted lists of a row (select_merge_kernel).
+//
+// The caller (api.hip) first runs the same kernel over a SAMPLE of y (its first 256 rows) to get a per-row bound
+// thr0 = k-th smallest of the sample: with it a block's first tiles append ~8 % of their elements instead of all of them.
+#include "reid_internal.h"
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int ROWB = BK * 4;
+constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+constexpr int AJ = BM / 8 / 4, BJ = BN / 8 / 4;
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(uintptr_t)(p))
+#define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+__device__ __forceinline__ unsigned long long pack_key(float v, int idx) {
+    unsigned int u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned int)idx;
+}
+__device__ __forceinline__ float unpack_val(unsigned long long k) {
+    unsigned int u = (unsigned int)(k >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+template <int METRIC>
+__device__ __forceinline__ float dist_of(float dot, float rs, float cq) {   // the arithmetic of gemm_f32_dma.hip's dist_epilogue
+    if (METRIC == REID_METRIC_L2) return sqrtf(fmaxf((rs + cq) - 2.0f * dot, 1e-12f));
+    if (METRIC == REID_METRIC_L2SQR) return (rs + cq) - 2.0f * dot;
+    if (METRIC == REID_METRIC_COS_HALF) return (1.0f - dot / (sqrtf(rs) * cq)) / 2.0f;
+    if (METRIC == REID_METRIC_COS) return 1.0f - dot / (sqrtf(rs) * cq);
+    return dot;
+}
+
+// one wave: the k smallest of list[0..n) (n <= CAP) to list[0..min(n,k)) in ascending order; returns the new count and, through
+// *thr_out, the k-th smallest value when n >= k.  sc: 128 keys of wave-private LDS.
+__device__ __forceinline__ int compact_row(unsigned long long* list, int n, int k, unsigned long long* sc, float* thr_out, int lane) {
+    const unsigned long long k0 = lane < n ? list[lane] : ~0ull;
+    const unsigned long long k1 = lane + 64 < n ? list[lane + 64] : ~0ull;
+    sc[lane] = k0;
+    sc[lane + 64] = k1;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int r0 = 0, r1 = 0;
+    for (int j = 0; j < n; ++j) {
+        const unsigned long long kj = sc[j];
+        r0 += kj < k0 ? 1 : 0;
+        r1 += kj < k1 ? 1 : 0;
+    }
+    if (lane < n && r0 < k) list[r0] = k0;
+    if (lane + 64 < n && r1 < k) list[r1] = k1;
+    if (n >= k) {
+        if (lane < n && r0 == k - 1) *thr_out = unpack_val(k0);
+        if (lane + 64 < n && r1 == k - 1) *thr_out = unpack_val(k1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return n < k ? n : k;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float thr[BM];
+    __shared__ __attribute__((aligned(16))) float rsq_s[BM];   // |x_i|^2 of the block's rows
+    __shared__ int cnt[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nk = p.K / BK;
+    const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
+    const int per = (nnt + p.S - 1) / p.S;
+
+    int t;
+    {   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD): an XCD's blocks take consecutive (segment, row tile)
+        // pairs, row tile fastest - they sweep the same segment of y, which stays in that XCD's L2
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int seg = t / nmt, mtile = t - seg * nmt;
+    const int m_blk = mtile * BM;
+    const int rows_a = p.M - m_blk < BM ? p.M - m_blk : BM;
+    const int nt0 = seg * per, nt1 = nt0 + per < nnt ? nt0 + per : nnt;
+
+    if (tid < BM) {
+        thr[tid] = (p.thr0 && tid < rows_a) ? p.thr0[m_blk + tid] : INFINITY;
+        rsq_s[tid] = (p.row_sq && tid < rows_a) ? p.row_sq[m_blk + tid] : 0.f;
+        cnt[tid] = 0;
+    }
+    unsigned long long* lists = p.lists + ((long long)m_blk * p.S + seg) * SEL_CAP;   // row r of the tile: + r * S * CAP
+    const long long row_stride = (long long)p.S * SEL_CAP;
+
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.A + (long long)m_blk * p.lda), 0, (int)((long long)(rows_a - 1) * p.lda * 4 + (long long)p.K * 4), 0x00020000);
+    int a_voff[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int row = (wave * AJ + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        a_voff[j] = row < rows_a ? (int)(((long long)row * p.lda + chunk * 4) * 4) : (int)0x7fffff00;
+    }
+    const int swz = (li >> 1) & 7;
+    int a_rd[4], b_rd[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int pos = ((kk * 2 + lh) ^ swz) * 16;
+        a_rd[kk] = (wm * 64 + li) * ROWB + pos;
+        b_rd[kk] = A_BYTES + (wn * 64 + li) * ROWB + pos;
+    }
+    __syncthreads();
+
+    for (int nt = nt0; nt < nt1; ++nt) {
+        const int n_blk = nt * BN;
+        const int rows_b = p.N - n_blk < BN ? p.N - n_blk : BN;
+        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.B + (long long)n_blk * p.ldb), 0, (int)((long long)(rows_b - 1) * p.ldb * 4 + (long long)p.K * 4), 0x00020000);
+        int b_voff[BJ];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int row = (wave * BJ + j) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            b_voff[j] = row < rows_b ? (int)(((long long)row * p.ldb + chunk * 4) * 4) : (int)0x7fffff00;
+        }
+        auto stage = [&](int kt, int slot) {
+            char* As = lds + slot * STAGE;
+            char* Bs = As + A_BYTES;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(As + (wave * AJ + j) * 1024), 16, a_voff[j], kt * BK * 4, 0, 0);
+#pragma unroll
+            for (int j = 0; j < BJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, LPTR(Bs + (wave * BJ + j) * 1024), 16, b_voff[j], kt * BK * 4, 0, 0);
+        };
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        auto mfma_tile = [&](int slot) {
+            const char* base = lds + slot * STAGE;
+            f32x4 af[2][2], bf[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[0][a] = *(const f32x4*)(base + a_rd[0] + a * 32 * ROWB);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[0][b] = *(const f32x4*)(base + b_rd[0] + b * 32 * ROWB);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk < 3) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) af[(kk + 1) & 1][a] = *(const f32x4*)(base + a_rd[kk + 1] + a * 32 * ROWB);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) bf[(kk + 1) & 1][b] = *(const f32x4*)(base + b_rd[kk + 1] + b * 32 * ROWB);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][a][e], bf[kk & 1][b][e], acc[a][b], 0, 0, 0);
+            }
+        };
+        stage(0, 0);
+        for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (kt + u < nk) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    RAW_BARRIER();
+                    if (kt + u + 1 < nk) stage(kt + u + 1, u ^ 1);
+                    mfma_tile(u);
+                }
+            }
+        }
+        __syncthreads();   // every wave has left the K loop: the stage buffers are free (compaction scratch, next tile's DMA)
+
+        // ---- filter: two halves of 64 columns (b = MFMA column block of each of the two wave columns)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n_blk + wn * 64 + b * 32 + li;
+            const bool colok = col < p.N;
+            float cq = (colok && p.col_sq) ? p.col_sq[col] : 0.f;
+            if (METRIC == REID_METRIC_COS_HALF || METRIC == REID_METRIC_COS) cq = sqrtf(cq);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int rbase = wm * 64 + a * 32 + 4 * lh;
+                float th[16], rs[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t4 = *(const f32x4*)(thr + rbase + 8 * q);
+                    const f32x4 r4 = *(const f32x4*)(rsq_s + rbase + 8 * q);
+                    th[4 * q] = t4.x; th[4 * q + 1] = t4.y; th[4 * q + 2] = t4.z; th[4 * q + 3] = t4.w;
+                    rs[4 * q] = r4.x; rs[4 * q + 1] = r4.y; rs[4 * q + 2] = r4.z; rs[4 * q + 3] = r4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = dist_of<METRIC>(acc[a][b][e], rs[e], cq);
+                    const int row = rbase + (e & 3) + 8 * (e >> 2);
+                    if (colok && row < rows_a && v <= th[e]) {
+                        const int slot = atomicAdd(&cnt[row], 1);
+                        lists[row * row_stride + slot] = pack_key(v, col + p.index_base);
+                    }
+                }
+            }
+            __syncthreads();   // the half's appends are done (and visible: workgroup-scope fence)
+            // ---- compaction of the rows whose list passed 64 keys: wave w looks after rows w*32 .. w*32+31
+            unsigned long long* sc = (unsigned long long*)lds + wave * SEL_CAP;
+            for (int r = wave * 32; r < wave * 32 + 32; ++r) {
+                const int n = cnt[r];
+                if (n > 64) {
+                    const int m2 = compact_row(lists + r * row_stride, n, p.k, sc, &thr[r], lane);
+                    if (lane == 0) cnt[r] = m2;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- every row's list down to its <= k smallest, ascending; the count goes out for the merge
+    {
+        unsigned long long* sc = (unsigned long long*)lds + wave * SEL_CAP;
+        for (int r = wave * 32; r < wave * 32 + 32; ++r) {
+            if (r >= rows_a) break;
+            const int n = cnt[r];
+            const int m2 = compact_row(lists + r * row_stride, n, p.k, sc, &thr[r], lane);
+            if (lane == 0) p.counts[(long long)(m_blk + r) * p.S + seg] = m2;
+        }
+    }
+#endif
+}
+
+// One wave per row: merge of the row's S ascending lists (counts[row][s] keys each) -> D[row][k], I[row][k] ascending, padded with
+// (+inf, -1).  k rounds of "smallest key above the last one"; ties cannot occur (keys carry the column).
+__global__ __launch_bounds__(64) void select_merge_kernel(const unsigned long long* __restrict__ lists, const int* __restrict__ counts,
+                                                          int S, int k, float* __restrict__ D, int32_t* __restrict__ I,
+                                                          float* __restrict__ kth) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const unsigned long long* L = lists + (long long)row * S * SEL_CAP;
+    const int* cn = counts + (long long)row * S;
+    unsigned long long last = 0;
+    bool first = true;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = ~0ull;
+        for (int c = lane; c < S * k; c += 64) {
+            const int s = c / k, j = c - s * k;
+            if (j >= cn[s]) continue;
+            const unsigned long long key = L[(long long)s * SEL_CAP + j];
+            if ((first || key > last) && key < best) best = key;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o);
+            best = other < best ? other : best;
+        }
+        if (lane == 0) {
+            if (D) D[(long long)row * k + r] = best == ~0ull ? INFINITY : unpack_val(best);
+            if (I) I[(long long)row * k + r] = best == ~0ull ? -1 : (int32_t)(best & 0xffffffffu);
+            if (kth && r == k - 1) kth[row] = best == ~0ull ? INFINITY : unpack_val(best);
+        }
+        last = best;
+        first = false;
+    }
+}
+
+template <int METRIC>
+void launch_metric(reid_ctx* ctx, const SelectParams& p, int blocks) {
+    hipLaunchKernelGGL((dist_select_kernel<METRIC>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+}
+
+}  // namespace
+
+int select_segments(int m, int n) {
+    // >= two blocks per CU (256 CUs): S segments of y's column tiles per row tile; never more segments than column tiles
+    const int nmt = (m + BM - 1) / BM, nnt = (n + BN - 1) / BN;
+    int S = (512 + nmt - 1) / nmt;
+    if (S > nnt) S = nnt;
+    if (S < 1) S = 1;
+    const int per = (nnt + S - 1) / S;
+    return (nnt + per - 1) / per;   // no empty segments
+}
+
+bool dist_select_supported(const SelectParams& p) {
+    return p.k >= 1 && p.k <= SEL_KMAX && p.K % BK == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
+           (long long)BM * p.lda * 4 < 0x7fff0000ll && (long long)BN * p.ldb * 4 < 0x7fff0000ll && ((uintptr_t)p.A % 16) == 0 &&
+           ((uintptr_t)p.B % 16) == 0;
+}
+
+// lists: [M][S][SEL_CAP] u64, counts: [M][S] int - scratch of the caller.  d_D / d_I / d_kth may be null.
+int launch_dist_select(reid_ctx* ctx, const SelectParams& p, float* d_D, int32_t* d_I, float* d_kth) {
+    const int nmt = (p.M + BM - 1) / BM;
+    const int blocks = nmt * p.S;
+    prof_begin(ctx, REID_K_DIST_GEMM, 2.0 * p.M * p.N * p.K, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + 2.0 * p.M * p.k));
+    switch (p.metric) {
+        case REID_METRIC_L2: launch_metric<REID_METRIC_L2>(ctx, p, blocks); break;
+        case REID_METRIC_L2SQR: launch_metric<REID_METRIC_L2SQR>(ctx, p, blocks); break;
+        case REID_METRIC_COS_HALF: launch_metric<REID_METRIC_COS_HALF>(ctx, p, blocks); break;
+        case REID_METRIC_COS: launch_metric<REID_METRIC_COS>(ctx, p, blocks); break;
+        default: launch_metric<REID_METRIC_DOT>(ctx, p, blocks); break;
+    }
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    prof_begin(ctx, REID_K_SELECT, 0, (double)p.M * p.S * p.k * 8.0);
+    hipLaunchKernelGGL(select_merge_kernel, dim3(p.M), dim3(64), 0, ctx->stream, p.lists, p.counts, p.S, p.k, d_D, d_I, d_kth);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}

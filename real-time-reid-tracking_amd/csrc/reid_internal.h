@@ -87,6 +87,24 @@ struct GemmParams {
     int metric;
 };
 
+// ---- distance GEMM with fused selection (dist_select.hip): the k smallest per row, no m x n matrix
+constexpr int SEL_CAP = 128;    // keys per (row, segment) candidate list
+constexpr int SEL_KMAX = 64;    // largest k of the fused path (a list is compacted to k once it passes 64 keys)
+struct SelectParams {
+    const float* A;             // x [M][lda]
+    const float* B;             // y [N][ldb]
+    int lda, ldb, M, N, K;      // K % 32 == 0 (zero-padded rows)
+    const float* row_sq;        // |x_i|^2, |y_j|^2 (null for REID_METRIC_DOT)
+    const float* col_sq;
+    const float* thr0;          // optional per-row upper bound of the k-th smallest distance (null: +inf)
+    int metric, k, S, index_base;
+    unsigned long long* lists;  // scratch [M][S][SEL_CAP]
+    int* counts;                // scratch [M][S]
+};
+int select_segments(int m, int n);
+bool dist_select_supported(const SelectParams& p);
+int launch_dist_select(reid_ctx* ctx, const SelectParams& p, float* d_D, int32_t* d_I, float* d_kth);
+
 // ---- fp16-input / fp32-accumulate GEMM (gemm_f16.hip)
 enum A16Mode {
     A16_DENSE = 0,   // A[M][lda] f16
@@ -285,6 +303,7 @@ struct reid_ctx {
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
     int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
     int f32_stem_pool = 1;   // fp32 path: MaxPool(3,2,1) on the stem kernel's accumulators (REID_F32_STEMPOOL=0: separate kernel)
+    int select_two_pass = 0; // REID_SELECT_TWO_PASS=1: arg-min / k-NN through the full distance matrix (A/B against dist_select.hip)
     int swin_stop = -1;      // diagnostics (REID_SWIN_STOP = block * 10 + phase): skip the rest of the Swin blocks after that point
     int swin_fold = 1;       // Swin, fp16-storage mode: to_out and post_proj folded into one Linear (REID_SWIN_FOLD=0: two launches)
     int swin_attn_mfma = 1;  // Swin window attention (REID_SWIN_ATTN): 1 = matrix cores in fp16-storage mode, VALU kernel in exact fp32

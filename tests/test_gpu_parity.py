@@ -1489,3 +1489,69 @@ def test_full_size_config3_tracking_stream(eng_w0, precision):
         stream.close()
         stream.metric.close()
         eng.set_precision(0)
+
+
+# ----------------------------------------------------------------------------- fused distance + selection (dist_select.hip)
+def _knn_oracle(xq, xb, k):
+    """Brute force in float64 with the engine's tie rule (ascending distance, then lowest index)."""
+    d = (xq.astype(np.float64) ** 2).sum(1)[:, None] + (xb.astype(np.float64) ** 2).sum(1)[None, :] - 2.0 * xq.astype(np.float64) @ xb.astype(np.float64).T
+    idx = np.argsort(d, axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(d, idx, 1), idx
+
+
+@pytest.mark.parametrize("m,n,d,k", [(1, 1, 32, 1), (3, 129, 33, 5), (130, 257, 96, 20), (257, 1000, 512, 64), (64, 5000, 1263, 20),
+                                     (300, 3000, 40, 1), (5, 700, 512, 65)])
+def test_fused_select_matches_two_pass_and_oracle(eng, m, n, d, k):
+    """reid_knn / reid_argmin_rows through the fused kernel (no m x n matrix; k = 65 takes the two-pass path) against the
+    distance matrix of the same library (the fused distances must be the matrix kernel's, bit for bit) and a float64 oracle:
+    ragged tiles, K padded to whole K-tiles (d = 33, 40, 1263), k up to the list's compaction size, k > gallery."""
+    rng = np.random.default_rng(m * 7 + n)
+    xq = rng.normal(size=(m, d)).astype(np.float32)
+    xb = rng.normal(size=(n, d)).astype(np.float32)
+    if n > 40:
+        xb[n // 2] = xb[3]                                  # a duplicate gallery row: the tie goes to the lower index
+        xq[0] = xb[3]
+    kk = min(k, n)
+    D, I = eng.knn(xq, xb, k)
+    full = eng.distmat(xq, xb, _ffi.METRIC_L2SQR)
+    order = np.lexsort((np.broadcast_to(np.arange(n), full.shape), full), axis=1)[:, :kk]
+    assert np.array_equal(I[:, :kk], order)                 # exactly the selection a full sort of the library's own matrix gives
+    assert np.array_equal(D[:, :kk], np.take_along_axis(full, order, 1))
+    if k > n:
+        assert (I[:, n:] == -1).all() and np.isinf(D[:, n:]).all()
+    Dr, Ir = _knn_oracle(xq, xb, kk)
+    gap_ok = np.abs(D[:, :kk] - Dr) <= 1e-3 * (1 + np.abs(Dr))
+    assert gap_ok.all()
+    if n > 40:
+        assert I[0, 0] == 3 and I[0, 1] == n // 2
+    for metric in (_ffi.METRIC_L2, _ffi.METRIC_COS, _ffi.METRIC_COS_HALF, _ffi.METRIC_DOT):
+        idx, val = eng.argmin_rows(xq, xb, metric)
+        fm = eng.distmat(xq, xb, metric)
+        assert np.array_equal(idx, fm.argmin(1)) and np.array_equal(val, fm.min(1)), metric
+
+
+@pytest.mark.parametrize("order", ["random", "ascending", "descending"])
+def test_fused_select_long_sweeps_and_adversarial_order(eng, order):
+    """20 000 gallery rows (the sample bound, many column tiles per block, list compactions): the gallery sorted by distance to
+    every query in DESCENDING order makes every element a candidate (each one beats the running threshold), ascending order
+    none after the first tile - the result must be the full sort's either way."""
+    rng = np.random.default_rng(17)
+    n, d, k = 20000, 64, 20
+    base = rng.normal(size=d).astype(np.float32)
+    dirs = rng.normal(size=(n, d)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    radius = np.sort(rng.uniform(0.5, 30.0, n)).astype(np.float32)
+    if order == "descending":
+        radius = radius[::-1].copy()
+    elif order == "random":
+        rng.shuffle(radius)
+    xb = base + dirs * radius[:, None]
+    xq = (base + 0.01 * rng.normal(size=(150, d))).astype(np.float32)    # every query sits at the centre: distance ~ radius
+    D, I = eng.knn(xq, xb, k)
+    full = eng.distmat(xq, xb, _ffi.METRIC_L2SQR)
+    want = np.lexsort((np.broadcast_to(np.arange(n), full.shape), full), axis=1)[:, :k]
+    assert np.array_equal(I, want)
+    assert np.array_equal(D, np.take_along_axis(full, want, 1))
+    idx, val = eng.argmin_rows(xq, xb, _ffi.METRIC_L2)
+    fl2 = eng.distmat(xq, xb, _ffi.METRIC_L2)
+    assert np.array_equal(idx, fl2.argmin(1)) and np.array_equal(val, fl2.min(1))
