@@ -1089,7 +1089,10 @@ static int pad_rows_to(reid_ctx* ctx, const char* name, const float* d_x, int m,
 // the caller then takes the two-pass path.
 static int select_fused_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric, int k, float* d_D,
                             int32_t* d_I) {
-    if (k > SEL_KMAX) return 1;
+    // small problems keep the two-pass form: their matrix is a few MB, and without a sample bound the sweep's first tile would
+    // append every element
+    constexpr int sample = 1024;
+    if (k > SEL_KMAX || n < 2 * sample || (long long)m * n < (1ll << 18)) return 1;
     const float *xp, *yp;
     int ldx, ldy;
     REID_TRY(pad_rows_to(ctx, "sel.xpad", d_x, m, d, 32, &xp, &ldx));
@@ -1112,19 +1115,13 @@ static int select_fused_dev(reid_ctx* ctx, const float* d_x, int m, const float*
     p.S = select_segments(m, n);
     REID_TRY(ctx_ws(ctx, "sel.lists", (size_t)m * p.S * SEL_CAP * 8, (void**)&p.lists));
     REID_TRY(ctx_ws(ctx, "sel.counts", (size_t)m * p.S * 4, (void**)&p.counts));
-    // a per-row bound from a SAMPLE of y (its first 256 rows; they are part of y, so the k-th smallest of the sample bounds the
-    // k-th smallest of all): with it the sweep appends a few per cent of a block's first tiles instead of all of them
-    const int sample = 256;
-    if (n >= 8 * sample && k <= sample) {
-        float* thr0;
-        REID_TRY(ctx_ws(ctx, "sel.thr0", (size_t)m * 4, (void**)&thr0));
-        SelectParams ps = p;
-        ps.N = sample;
-        ps.S = select_segments(m, sample);
-        REID_TRY(launch_dist_select(ctx, ps, nullptr, nullptr, thr0));
-        p.thr0 = thr0;
-    }
-    return launch_dist_select(ctx, p, d_D, d_I, nullptr);
+    // per-row bound from a SAMPLE of y (its first 1024 rows - part of y, so a bound of the sample's k-th smallest holds for all of y)
+    REID_TRY(ctx_ws(ctx, "sel.gmin", (size_t)m * k * 4, (void**)&p.gmin));
+    HIP_TRY(hipMemsetAsync(p.gmin, 0xff, (size_t)m * k * 4, ctx->stream));
+    SelectParams ps = p;
+    ps.N = sample;
+    REID_TRY(launch_dist_bound(ctx, ps));
+    return launch_dist_select(ctx, p, d_D, d_I);
 }
 
 extern "C" int reid_argmin_rows_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric,

@@ -17,8 +17,10 @@
 // << 32 | column), so "smallest key" = smallest distance, ties -> lowest column, the engine's rule everywhere.
 // A second, tiny kernel merges the S sorted lists of a row (select_merge_kernel).
 //
-// The caller (api.hip) first runs the same kernel over a SAMPLE of y (its first 256 rows) to get a per-row bound
-// thr0 = k-th smallest of the sample: with it a block's first tiles append ~8 % of their elements instead of all of them.
+// The caller (api.hip) first runs the kernel's BOUND form over a SAMPLE of y (its first 1024 rows): per row the minimum of each
+// of k disjoint column groups; the largest of those k minima bounds the row's k-th smallest distance, and a sweep that starts
+// from it appends a few per cent of its elements instead of all of them (measured before: a first tile that appends
+// everything costs 250 us of list compaction per block).
 #include "reid_internal.h"
 #include <math.h>
 
@@ -63,11 +65,14 @@ __device__ __forceinline__ int compact_row(unsigned long long* list, int n, int 
     sc[lane + 64] = k1;
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // rank by counting; the keys come as 16-byte broadcast reads, eight per step (slots past n hold ~0: never smaller than a key)
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     int r0 = 0, r1 = 0;
-    for (int j = 0; j < n; ++j) {
-        const unsigned long long kj = sc[j];
-        r0 += kj < k0 ? 1 : 0;
-        r1 += kj < k1 ? 1 : 0;
+    const int n8 = (n + 7) & ~7;
+    for (int j = 0; j < n8; j += 8) {
+        const u64x2 a = *(const u64x2*)(sc + j), b = *(const u64x2*)(sc + j + 2), c = *(const u64x2*)(sc + j + 4), d = *(const u64x2*)(sc + j + 6);
+        r0 += (a.x < k0) + (a.y < k0) + (b.x < k0) + (b.y < k0) + (c.x < k0) + (c.y < k0) + (d.x < k0) + (d.y < k0);
+        r1 += (a.x < k1) + (a.y < k1) + (b.x < k1) + (b.y < k1) + (c.x < k1) + (c.y < k1) + (d.x < k1) + (d.y < k1);
     }
     if (lane < n && r0 < k) list[r0] = k0;
     if (lane + 64 < n && r1 < k) list[r1] = k1;
@@ -79,7 +84,18 @@ __device__ __forceinline__ int compact_row(unsigned long long* list, int n, int 
     return n < k ? n : k;
 }
 
-template <int METRIC>
+__device__ __forceinline__ unsigned int key32(float v) {
+    const unsigned int u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unkey32(unsigned int u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// BOUND = true: no lists - the block takes ONE tile of the sample and folds its distances into p.gmin[row][col % k] (minimum
+// per row and column group).  The k groups are disjoint, so a row's k group minima are k different elements and their maximum
+// bounds the row's k-th smallest distance from above: the main pass starts from that threshold.
+template <int METRIC, bool BOUND>
 __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
@@ -107,7 +123,14 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
     const int nt0 = seg * per, nt1 = nt0 + per < nnt ? nt0 + per : nnt;
 
     if (tid < BM) {
-        thr[tid] = (p.thr0 && tid < rows_a) ? p.thr0[m_blk + tid] : INFINITY;
+        float t0 = INFINITY;
+        if (!BOUND && p.gmin && tid < rows_a) {   // max over the k group minima of the sample (see BOUND above)
+            const unsigned int* g = p.gmin + (long long)(m_blk + tid) * p.k;
+            unsigned int mx = 0;
+            for (int j = 0; j < p.k; ++j) mx = g[j] > mx ? g[j] : mx;
+            t0 = mx == 0xffffffffu ? INFINITY : unkey32(mx);
+        }
+        thr[tid] = t0;
         rsq_s[tid] = (p.row_sq && tid < rows_a) ? p.row_sq[m_blk + tid] : 0.f;
         cnt[tid] = 0;
     }
@@ -200,6 +223,34 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
         }
         __syncthreads();   // every wave has left the K loop: the stage buffers are free (compaction scratch, next tile's DMA)
 
+        if constexpr (BOUND) {   // group minima of this tile in LDS (over the stage buffers), then one global atomic per (row, group)
+            unsigned int* gm = (unsigned int*)lds;
+            for (int i = tid; i < BM * p.k; i += 256) gm[i] = 0xffffffffu;
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int col = n_blk + wn * 64 + b * 32 + li;
+                const bool colok = col < p.N;
+                float cq = (colok && p.col_sq) ? p.col_sq[col] : 0.f;
+                if (METRIC == REID_METRIC_COS_HALF || METRIC == REID_METRIC_COS) cq = sqrtf(cq);
+                const int grp = col % p.k;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int rbase = wm * 64 + a * 32 + 4 * lh;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = rbase + (e & 3) + 8 * (e >> 2);
+                        const float v = dist_of<METRIC>(acc[a][b][e], rsq_s[row], cq);
+                        if (colok && v == v) atomicMin(&gm[row * p.k + grp], key32(v));
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < rows_a * p.k; i += 256)
+                if (gm[i] != 0xffffffffu) atomicMin(p.gmin + (long long)m_blk * p.k + i, gm[i]);
+            __syncthreads();
+            continue;
+        }
         // ---- filter: two halves of 64 columns (b = MFMA column block of each of the two wave columns)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -242,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
         }
     }
     // ---- every row's list down to its <= k smallest, ascending; the count goes out for the merge
-    {
+    if constexpr (!BOUND) {
         unsigned long long* sc = (unsigned long long*)lds + wave * SEL_CAP;
         for (int r = wave * 32; r < wave * 32 + 32; ++r) {
             if (r >= rows_a) break;
@@ -255,23 +306,27 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
 }
 
 // One wave per row: merge of the row's S ascending lists (counts[row][s] keys each) -> D[row][k], I[row][k] ascending, padded with
-// (+inf, -1).  k rounds of "smallest key above the last one"; ties cannot occur (keys carry the column).
-__global__ __launch_bounds__(64) void select_merge_kernel(const unsigned long long* __restrict__ lists, const int* __restrict__ counts,
-                                                          int S, int k, float* __restrict__ D, int32_t* __restrict__ I,
-                                                          float* __restrict__ kth) {
-    const int row = blockIdx.x, lane = threadIdx.x;
+// (+inf, -1).  The S * k slots sit in registers (NPL per lane); k rounds of wave minimum, the owner retires its key.  Keys are
+// unique (they carry the column), so exactly one lane retires per round.
+template <int NPL>
+__global__ __launch_bounds__(256) void select_merge_kernel(const unsigned long long* __restrict__ lists, const int* __restrict__ counts,
+                                                           int M, int S, int k, float* __restrict__ D, int32_t* __restrict__ I) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
     const unsigned long long* L = lists + (long long)row * S * SEL_CAP;
     const int* cn = counts + (long long)row * S;
-    unsigned long long last = 0;
-    bool first = true;
+    unsigned long long key[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = lane + 64 * i;
+        const int s = c / k, j = c - s * k;
+        key[i] = (c < S * k && j < cn[s]) ? L[(long long)s * SEL_CAP + j] : ~0ull;
+    }
     for (int r = 0; r < k; ++r) {
-        unsigned long long best = ~0ull;
-        for (int c = lane; c < S * k; c += 64) {
-            const int s = c / k, j = c - s * k;
-            if (j >= cn[s]) continue;
-            const unsigned long long key = L[(long long)s * SEL_CAP + j];
-            if ((first || key > last) && key < best) best = key;
-        }
+        unsigned long long mine = key[0];
+#pragma unroll
+        for (int i = 1; i < NPL; ++i) mine = key[i] < mine ? key[i] : mine;
+        unsigned long long best = mine;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long other = __shfl_xor(best, o);
@@ -280,16 +335,28 @@ __global__ __launch_bounds__(64) void select_merge_kernel(const unsigned long lo
         if (lane == 0) {
             if (D) D[(long long)row * k + r] = best == ~0ull ? INFINITY : unpack_val(best);
             if (I) I[(long long)row * k + r] = best == ~0ull ? -1 : (int32_t)(best & 0xffffffffu);
-            if (kth && r == k - 1) kth[row] = best == ~0ull ? INFINITY : unpack_val(best);
         }
-        last = best;
-        first = false;
+        if (best != ~0ull) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+                if (key[i] == best) key[i] = ~0ull;
+        }
     }
 }
 
 template <int METRIC>
-void launch_metric(reid_ctx* ctx, const SelectParams& p, int blocks) {
-    hipLaunchKernelGGL((dist_select_kernel<METRIC>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+void launch_metric(reid_ctx* ctx, const SelectParams& p, int blocks, bool bound) {
+    if (bound) hipLaunchKernelGGL((dist_select_kernel<METRIC, true>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((dist_select_kernel<METRIC, false>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+}
+void launch_any(reid_ctx* ctx, const SelectParams& p, int blocks, bool bound) {
+    switch (p.metric) {
+        case REID_METRIC_L2: launch_metric<REID_METRIC_L2>(ctx, p, blocks, bound); break;
+        case REID_METRIC_L2SQR: launch_metric<REID_METRIC_L2SQR>(ctx, p, blocks, bound); break;
+        case REID_METRIC_COS_HALF: launch_metric<REID_METRIC_COS_HALF>(ctx, p, blocks, bound); break;
+        case REID_METRIC_COS: launch_metric<REID_METRIC_COS>(ctx, p, blocks, bound); break;
+        default: launch_metric<REID_METRIC_DOT>(ctx, p, blocks, bound); break;
+    }
 }
 
 }  // namespace
@@ -299,6 +366,7 @@ int select_segments(int m, int n) {
     const int nmt = (m + BM - 1) / BM, nnt = (n + BN - 1) / BN;
     int S = (512 + nmt - 1) / nmt;
     if (S > nnt) S = nnt;
+    if (S > 32) S = 32;        // S * k <= 32 * 64 slots: the merge keeps them in registers
     if (S < 1) S = 1;
     const int per = (nnt + S - 1) / S;
     return (nnt + per - 1) / per;   // no empty segments
@@ -310,22 +378,35 @@ bool dist_select_supported(const SelectParams& p) {
            ((uintptr_t)p.B % 16) == 0;
 }
 
-// lists: [M][S][SEL_CAP] u64, counts: [M][S] int - scratch of the caller.  d_D / d_I / d_kth may be null.
-int launch_dist_select(reid_ctx* ctx, const SelectParams& p, float* d_D, int32_t* d_I, float* d_kth) {
+// Sample pass: group minima of the first p.N (= sample) rows of y into p.gmin [M][k] (set to 0xff.. by the caller); one tile per block.
+int launch_dist_bound(reid_ctx* ctx, const SelectParams& p) {
+    const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
+    SelectParams q = p;
+    q.S = nnt;
+    prof_begin(ctx, REID_K_DIST_GEMM, 2.0 * p.M * p.N * p.K, 4.0 * ((double)p.M * p.K + (double)p.N * p.K));
+    launch_any(ctx, q, nmt * nnt, true);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+// lists: [M][S][SEL_CAP] u64, counts: [M][S] int - scratch of the caller; p.gmin: null or the sample's group minima.
+int launch_dist_select(reid_ctx* ctx, const SelectParams& p, float* d_D, int32_t* d_I) {
     const int nmt = (p.M + BM - 1) / BM;
-    const int blocks = nmt * p.S;
     prof_begin(ctx, REID_K_DIST_GEMM, 2.0 * p.M * p.N * p.K, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + 2.0 * p.M * p.k));
-    switch (p.metric) {
-        case REID_METRIC_L2: launch_metric<REID_METRIC_L2>(ctx, p, blocks); break;
-        case REID_METRIC_L2SQR: launch_metric<REID_METRIC_L2SQR>(ctx, p, blocks); break;
-        case REID_METRIC_COS_HALF: launch_metric<REID_METRIC_COS_HALF>(ctx, p, blocks); break;
-        case REID_METRIC_COS: launch_metric<REID_METRIC_COS>(ctx, p, blocks); break;
-        default: launch_metric<REID_METRIC_DOT>(ctx, p, blocks); break;
-    }
+    launch_any(ctx, p, nmt * p.S, false);
     prof_end(ctx);
     LAUNCH_CHECK();
     prof_begin(ctx, REID_K_SELECT, 0, (double)p.M * p.S * p.k * 8.0);
-    hipLaunchKernelGGL(select_merge_kernel, dim3(p.M), dim3(64), 0, ctx->stream, p.lists, p.counts, p.S, p.k, d_D, d_I, d_kth);
+    const int slots = p.S * p.k, blocks = (p.M + 3) / 4;
+#define MERGE(NPL) hipLaunchKernelGGL((select_merge_kernel<NPL>), dim3(blocks), dim3(256), 0, ctx->stream, p.lists, p.counts, p.M, p.S, p.k, d_D, d_I)
+    if (slots <= 64) MERGE(1);
+    else if (slots <= 128) MERGE(2);
+    else if (slots <= 256) MERGE(4);
+    else if (slots <= 512) MERGE(8);
+    else if (slots <= 1024) MERGE(16);
+    else MERGE(32);
+#undef MERGE
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

@@ -96,14 +96,15 @@ struct SelectParams {
     int lda, ldb, M, N, K;      // K % 32 == 0 (zero-padded rows)
     const float* row_sq;        // |x_i|^2, |y_j|^2 (null for REID_METRIC_DOT)
     const float* col_sq;
-    const float* thr0;          // optional per-row upper bound of the k-th smallest distance (null: +inf)
+    unsigned int* gmin;         // [M][k] group minima of a sample of y as order-preserving keys (null: start from +inf)
     int metric, k, S, index_base;
     unsigned long long* lists;  // scratch [M][S][SEL_CAP]
     int* counts;                // scratch [M][S]
 };
 int select_segments(int m, int n);
 bool dist_select_supported(const SelectParams& p);
-int launch_dist_select(reid_ctx* ctx, const SelectParams& p, float* d_D, int32_t* d_I, float* d_kth);
+int launch_dist_bound(reid_ctx* ctx, const SelectParams& p);
+int launch_dist_select(reid_ctx* ctx, const SelectParams& p, float* d_D, int32_t* d_I);
 
 // ---- fp16-input / fp32-accumulate GEMM (gemm_f16.hip)
 enum A16Mode {
