@@ -1095,14 +1095,15 @@ static int select_fused_dev(reid_ctx* ctx, const float* d_x, int m, const float*
     if (k > SEL_KMAX || n < 2 * sample || (long long)m * n < (1ll << 18)) return 1;
     const float *xp, *yp;
     int ldx, ldy;
-    REID_TRY(pad_rows_to(ctx, "sel.xpad", d_x, m, d, 32, &xp, &ldx));
-    REID_TRY(pad_rows_to(ctx, "sel.ypad", d_y, n, d, 32, &yp, &ldy));
+    REID_TRY(pad_rows_to(ctx, "sel.xpad", d_x, m, d, 64, &xp, &ldx));   // whole pairs of K-tiles
+    REID_TRY(pad_rows_to(ctx, "sel.ypad", d_y, n, d, 64, &yp, &ldy));
     SelectParams p;
     memset(&p, 0, sizeof(p));
     p.A = xp; p.lda = ldx;
     p.B = yp; p.ldb = ldy;
     p.M = m; p.N = n; p.K = ldx;
     p.metric = metric; p.k = k;
+    if (const char* e = getenv("REID_SELECT_EXP")) p.exp_skip = atoi(e);
     if (!dist_select_supported(p)) return 1;
     if (metric != REID_METRIC_DOT) {
         float *xx, *yy;
@@ -1113,14 +1114,17 @@ static int select_fused_dev(reid_ctx* ctx, const float* d_x, int m, const float*
         p.row_sq = xx; p.col_sq = yy;
     }
     p.S = select_segments(m, n);
-    REID_TRY(ctx_ws(ctx, "sel.lists", (size_t)m * p.S * SEL_CAP * 8, (void**)&p.lists));
-    REID_TRY(ctx_ws(ctx, "sel.counts", (size_t)m * p.S * 4, (void**)&p.counts));
-    // per-row bound from a SAMPLE of y (its first 1024 rows - part of y, so a bound of the sample's k-th smallest holds for all of y)
-    REID_TRY(ctx_ws(ctx, "sel.gmin", (size_t)m * k * 4, (void**)&p.gmin));
-    HIP_TRY(hipMemsetAsync(p.gmin, 0xff, (size_t)m * k * 4, ctx->stream));
-    SelectParams ps = p;
-    ps.N = sample;
-    REID_TRY(launch_dist_bound(ctx, ps));
+    REID_TRY(ctx_ws(ctx, "sel.final", (size_t)m * p.S * k * 8, (void**)&p.final_keys));
+    if (k > 1) {
+        REID_TRY(ctx_ws(ctx, "sel.lists", (size_t)m * p.S * SEL_CAP * 8, (void**)&p.lists));
+        // per-row bound from a SAMPLE of y (its first 1024 rows - part of y, so a bound of the sample's k-th smallest holds for all
+        // of y); the arg-min form needs none (its threshold is the running minimum itself)
+        REID_TRY(ctx_ws(ctx, "sel.gmin", (size_t)m * k * 4, (void**)&p.gmin));
+        HIP_TRY(hipMemsetAsync(p.gmin, 0xff, (size_t)m * k * 4, ctx->stream));
+        SelectParams ps = p;
+        ps.N = sample;
+        REID_TRY(launch_dist_bound(ctx, ps));
+    }
     return launch_dist_select(ctx, p, d_D, d_I);
 }
 

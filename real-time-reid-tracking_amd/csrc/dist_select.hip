@@ -56,9 +56,11 @@ __device__ __forceinline__ float dist_of(float dot, float rs, float cq) {   // t
     return dot;
 }
 
-// one wave: the k smallest of list[0..n) (n <= CAP) to list[0..min(n,k)) in ascending order; returns the new count and, through
-// *thr_out, the k-th smallest value when n >= k.  sc: 128 keys of wave-private LDS.
-__device__ __forceinline__ int compact_row(unsigned long long* list, int n, int k, unsigned long long* sc, float* thr_out, int lane) {
+// one wave: the k smallest of list[0..n) (n <= CAP) to dst[0..min(n,k)) in ascending order (dst may be list itself: every key is
+// in a register before the first store); returns the new count; the lane that holds the k-th smallest key (if n >= k) gets its
+// value in *kth (the others keep theirs).  sc: 128 keys of wave-private LDS.
+__device__ __forceinline__ int compact_row(const unsigned long long* list, unsigned long long* dst, int n, int k, unsigned long long* sc,
+                                           float* kth, int lane) {
     const unsigned long long k0 = lane < n ? list[lane] : ~0ull;
     const unsigned long long k1 = lane + 64 < n ? list[lane + 64] : ~0ull;
     sc[lane] = k0;
@@ -74,11 +76,11 @@ __device__ __forceinline__ int compact_row(unsigned long long* list, int n, int 
         r0 += (a.x < k0) + (a.y < k0) + (b.x < k0) + (b.y < k0) + (c.x < k0) + (c.y < k0) + (d.x < k0) + (d.y < k0);
         r1 += (a.x < k1) + (a.y < k1) + (b.x < k1) + (b.y < k1) + (c.x < k1) + (c.y < k1) + (d.x < k1) + (d.y < k1);
     }
-    if (lane < n && r0 < k) list[r0] = k0;
-    if (lane + 64 < n && r1 < k) list[r1] = k1;
+    if (lane < n && r0 < k) dst[r0] = k0;
+    if (lane + 64 < n && r1 < k) dst[r1] = k1;
     if (n >= k) {
-        if (lane < n && r0 == k - 1) *thr_out = unpack_val(k0);
-        if (lane + 64 < n && r1 == k - 1) *thr_out = unpack_val(k1);
+        if (lane < n && r0 == k - 1) *kth = unpack_val(k0);
+        if (lane + 64 < n && r1 == k - 1) *kth = unpack_val(k1);
     }
     __builtin_amdgcn_wave_barrier();
     return n < k ? n : k;
@@ -92,22 +94,29 @@ __device__ __forceinline__ float unkey32(unsigned int u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-// BOUND = true: no lists - the block takes ONE tile of the sample and folds its distances into p.gmin[row][col % k] (minimum
-// per row and column group).  The k groups are disjoint, so a row's k group minima are k different elements and their maximum
-// bounds the row's k-th smallest distance from above: the main pass starts from that threshold.
-template <int METRIC, bool BOUND>
+// MODE_SELECT: lists + compaction as described at the top.
+// MODE_BOUND : no lists - the block takes ONE tile of the sample and folds its distances into p.gmin[row][col % k] (minimum per
+//              row and column group).  The k groups are disjoint, so a row's k group minima are k different elements and their
+//              maximum bounds the row's k-th smallest distance from above: the select pass starts from that threshold.
+// MODE_ARGMIN: k = 1 - no lists either: a candidate goes straight into the row's running minimum (64-bit LDS atomic minimum of
+//              the key), which is also the threshold.
+enum { MODE_SELECT = 0, MODE_BOUND = 1, MODE_ARGMIN = 2 };
+
+template <int METRIC, int MODE>
 __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
-    __shared__ __attribute__((aligned(16))) float thr[BM];
-    __shared__ __attribute__((aligned(16))) float rsq_s[BM];   // |x_i|^2 of the block's rows
+    __shared__ __attribute__((aligned(16))) float thr[BM];      // value of the row's k-th smallest key so far (exact test)
+    __shared__ __attribute__((aligned(16))) float pth[BM];      // REID_METRIC_L2: the same bound before the square root (pre-filter)
+    __shared__ __attribute__((aligned(16))) float rsq_s[BM];    // |x_i|^2 of the block's rows
+    __shared__ unsigned long long best[MODE == MODE_ARGMIN ? BM : 1];
     __shared__ int cnt[BM];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int nk = p.K / BK;
+    const int nk = p.K / BK;                                    // even (K % 64 == 0): every tile starts in LDS stage 0
     const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
     const int per = (nnt + p.S - 1) / p.S;
 
@@ -122,17 +131,22 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
     const int rows_a = p.M - m_blk < BM ? p.M - m_blk : BM;
     const int nt0 = seg * per, nt1 = nt0 + per < nnt ? nt0 + per : nnt;
 
+    auto set_thr = [&](int r, float v) {   // L2: v <= thr  =>  w <= thr^2 (1 + 1.2e-7) for the correctly rounded sqrtf; 1e-6 covers thr * thr too
+        thr[r] = v;
+        if (METRIC == REID_METRIC_L2) pth[r] = v * v * (1.0f + 1e-6f);
+    };
     if (tid < BM) {
         float t0 = INFINITY;
-        if (!BOUND && p.gmin && tid < rows_a) {   // max over the k group minima of the sample (see BOUND above)
+        if (MODE == MODE_SELECT && p.gmin && tid < rows_a) {   // max over the k group minima of the sample (MODE_BOUND)
             const unsigned int* g = p.gmin + (long long)(m_blk + tid) * p.k;
             unsigned int mx = 0;
             for (int j = 0; j < p.k; ++j) mx = g[j] > mx ? g[j] : mx;
             t0 = mx == 0xffffffffu ? INFINITY : unkey32(mx);
         }
-        thr[tid] = t0;
+        set_thr(tid, t0);
         rsq_s[tid] = (p.row_sq && tid < rows_a) ? p.row_sq[m_blk + tid] : 0.f;
         cnt[tid] = 0;
+        if (MODE == MODE_ARGMIN) best[tid] = ~0ull;
     }
     unsigned long long* lists = p.lists + ((long long)m_blk * p.S + seg) * SEL_CAP;   // row r of the tile: + r * S * CAP
     const long long row_stride = (long long)p.S * SEL_CAP;
@@ -154,77 +168,92 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
         a_rd[kk] = (wm * 64 + li) * ROWB + pos;
         b_rd[kk] = A_BYTES + (wn * 64 + li) * ROWB + pos;
     }
-    __syncthreads();
-
-    for (int nt = nt0; nt < nt1; ++nt) {
+    // operand descriptor of one tile of y: rows past the last read as zeros (offset beyond the descriptor)
+    struct BDesc {
+        __amdgpu_buffer_rsrc_t rs;
+        int voff[BJ];
+    };
+    auto describe_b = [&](int nt, BDesc& d) {
         const int n_blk = nt * BN;
         const int rows_b = p.N - n_blk < BN ? p.N - n_blk : BN;
-        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(p.B + (long long)n_blk * p.ldb), 0, (int)((long long)(rows_b - 1) * p.ldb * 4 + (long long)p.K * 4), 0x00020000);
-        int b_voff[BJ];
+        d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long long)n_blk * p.ldb), 0,
+                                                 (int)((long long)(rows_b - 1) * p.ldb * 4 + (long long)p.K * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int row = (wave * BJ + j) * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            b_voff[j] = row < rows_b ? (int)(((long long)row * p.ldb + chunk * 4) * 4) : (int)0x7fffff00;
+            d.voff[j] = row < rows_b ? (int)(((long long)row * p.ldb + chunk * 4) * 4) : (int)0x7fffff00;
         }
-        auto stage = [&](int kt, int slot) {
-            char* As = lds + slot * STAGE;
-            char* Bs = As + A_BYTES;
+    };
+    auto stage = [&](const BDesc& d, int kt, int slot) {
+        char* As = lds + slot * STAGE;
+        char* Bs = As + A_BYTES;
 #pragma unroll
-            for (int j = 0; j < AJ; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(As + (wave * AJ + j) * 1024), 16, a_voff[j], kt * BK * 4, 0, 0);
+        for (int j = 0; j < AJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(As + (wave * AJ + j) * 1024), 16, a_voff[j], kt * BK * 4, 0, 0);
 #pragma unroll
-            for (int j = 0; j < BJ; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, LPTR(Bs + (wave * BJ + j) * 1024), 16, b_voff[j], kt * BK * 4, 0, 0);
-        };
-        f32x16 acc[2][2];
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs, LPTR(Bs + (wave * BJ + j) * 1024), 16, d.voff[j], kt * BK * 4, 0, 0);
+    };
+    f32x16 acc[2][2];
+    auto mfma_tile = [&](int slot) {
+        const char* base = lds + slot * STAGE;
+        f32x4 af[2][2], bf[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[0][a] = *(const f32x4*)(base + a_rd[0] + a * 32 * ROWB);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bf[0][b] = *(const f32x4*)(base + b_rd[0] + b * 32 * ROWB);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[(kk + 1) & 1][a] = *(const f32x4*)(base + a_rd[kk + 1] + a * 32 * ROWB);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bf[(kk + 1) & 1][b] = *(const f32x4*)(base + b_rd[kk + 1] + b * 32 * ROWB);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][a][e], bf[kk & 1][b][e], acc[a][b], 0, 0, 0);
+        }
+    };
+    __syncthreads();
+
+    // The K-tiles of the block's successive tiles form ONE stream through the two LDS stages: the last K-tile of a tile has the
+    // first K-tile of the next tile in flight behind it (stage 0), so a tile does not start with an exposed DMA round trip; the
+    // selection epilogue runs in between, with its scratch in stage 1 (just consumed).
+    BDesc cur, nxt;
+    describe_b(nt0, cur);
+    stage(cur, 0, 0);
+    for (int nt = nt0; nt < nt1; ++nt) {
+        const int n_blk = nt * BN;
+        const bool more = nt + 1 < nt1;
+        if (more) describe_b(nt + 1, nxt);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-        auto mfma_tile = [&](int slot) {
-            const char* base = lds + slot * STAGE;
-            f32x4 af[2][2], bf[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) af[0][a] = *(const f32x4*)(base + a_rd[0] + a * 32 * ROWB);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) bf[0][b] = *(const f32x4*)(base + b_rd[0] + b * 32 * ROWB);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (kk < 3) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) af[(kk + 1) & 1][a] = *(const f32x4*)(base + a_rd[kk + 1] + a * 32 * ROWB);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) bf[(kk + 1) & 1][b] = *(const f32x4*)(base + b_rd[kk + 1] + b * 32 * ROWB);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][a][e], bf[kk & 1][b][e], acc[a][b], 0, 0, 0);
-            }
-        };
-        stage(0, 0);
         for (int kt = 0; kt < nk; kt += 2) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (kt + u < nk) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    RAW_BARRIER();
-                    if (kt + u + 1 < nk) stage(kt + u + 1, u ^ 1);
-                    mfma_tile(u);
-                }
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of K-tile kt have landed
+            RAW_BARRIER();                                     // ... everyone's have, and everyone is done with stage 1
+            stage(cur, kt + 1, 1);
+            mfma_tile(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RAW_BARRIER();
+            if (kt + 2 < nk) stage(cur, kt + 2, 0);
+            else if (more) stage(nxt, 0, 0);
+            mfma_tile(1);
         }
-        __syncthreads();   // every wave has left the K loop: the stage buffers are free (compaction scratch, next tile's DMA)
+        RAW_BARRIER();   // every wave has left the K loop: stage 1 is free (scratch); stage 0 is being filled for the next tile
+        char* scratch = lds + STAGE;
 
-        if constexpr (BOUND) {   // group minima of this tile in LDS (over the stage buffers), then one global atomic per (row, group)
-            unsigned int* gm = (unsigned int*)lds;
+        if constexpr (MODE == MODE_BOUND) {   // group minima of this tile in LDS, then one global atomic per (row, group)
+            unsigned int* gm = (unsigned int*)scratch;
             for (int i = tid; i < BM * p.k; i += 256) gm[i] = 0xffffffffu;
             __syncthreads();
 #pragma unroll
@@ -249,78 +278,99 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
             for (int i = tid; i < rows_a * p.k; i += 256)
                 if (gm[i] != 0xffffffffu) atomicMin(p.gmin + (long long)m_blk * p.k + i, gm[i]);
             __syncthreads();
-            continue;
-        }
-        // ---- filter: two halves of 64 columns (b = MFMA column block of each of the two wave columns)
+        } else if (!p.exp_skip) {
+            // ---- filter: two halves of 64 columns (b = MFMA column block of each of the two wave columns)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n_blk + wn * 64 + b * 32 + li;
-            const bool colok = col < p.N;
-            float cq = (colok && p.col_sq) ? p.col_sq[col] : 0.f;
-            if (METRIC == REID_METRIC_COS_HALF || METRIC == REID_METRIC_COS) cq = sqrtf(cq);
+            for (int b = 0; b < 2; ++b) {
+                const int col = n_blk + wn * 64 + b * 32 + li;
+                const bool colok = col < p.N;
+                float cq = (colok && p.col_sq) ? p.col_sq[col] : 0.f;
+                if (METRIC == REID_METRIC_COS_HALF || METRIC == REID_METRIC_COS) cq = sqrtf(cq);
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int rbase = wm * 64 + a * 32 + 4 * lh;
-                float th[16], rs[16];
+                for (int a = 0; a < 2; ++a) {
+                    const int rbase = wm * 64 + a * 32 + 4 * lh;
+                    float th[16], rs[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 t4 = *(const f32x4*)(thr + rbase + 8 * q);
-                    const f32x4 r4 = *(const f32x4*)(rsq_s + rbase + 8 * q);
-                    th[4 * q] = t4.x; th[4 * q + 1] = t4.y; th[4 * q + 2] = t4.z; th[4 * q + 3] = t4.w;
-                    rs[4 * q] = r4.x; rs[4 * q + 1] = r4.y; rs[4 * q + 2] = r4.z; rs[4 * q + 3] = r4.w;
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 t4 = *(const f32x4*)((METRIC == REID_METRIC_L2 ? pth : thr) + rbase + 8 * q);
+                        const f32x4 r4 = *(const f32x4*)(rsq_s + rbase + 8 * q);
+                        th[4 * q] = t4.x; th[4 * q + 1] = t4.y; th[4 * q + 2] = t4.z; th[4 * q + 3] = t4.w;
+                        rs[4 * q] = r4.x; rs[4 * q + 1] = r4.y; rs[4 * q + 2] = r4.z; rs[4 * q + 3] = r4.w;
+                    }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float v = dist_of<METRIC>(acc[a][b][e], rs[e], cq);
-                    const int row = rbase + (e & 3) + 8 * (e >> 2);
-                    if (colok && row < rows_a && v <= th[e]) {
-                        const int slot = atomicAdd(&cnt[row], 1);
-                        lists[row * row_stride + slot] = pack_key(v, col + p.index_base);
+                    for (int e = 0; e < 16; ++e) {
+                        // L2: pre-filter on the value under the square root (two instructions); the root and the exact test only
+                        // for what passes.  The other metrics compare the distance itself.
+                        const float w = METRIC == REID_METRIC_L2 ? (rs[e] + cq) - 2.0f * acc[a][b][e] : dist_of<METRIC>(acc[a][b][e], rs[e], cq);
+                        const int row = rbase + (e & 3) + 8 * (e >> 2);
+                        if (colok && row < rows_a && w <= th[e]) {
+                            const float v = METRIC == REID_METRIC_L2 ? sqrtf(fmaxf(w, 1e-12f)) : w;
+                            if (METRIC != REID_METRIC_L2 || v <= thr[row]) {
+                                const unsigned long long key = pack_key(v, col + p.index_base);
+                                if constexpr (MODE == MODE_ARGMIN) {
+                                    atomicMin(&best[row], key);
+                                } else {
+                                    const int slot = atomicAdd(&cnt[row], 1);
+                                    lists[row * row_stride + slot] = key;
+                                }
+                            }
+                        }
                     }
                 }
-            }
-            __syncthreads();   // the half's appends are done (and visible: workgroup-scope fence)
-            // ---- compaction of the rows whose list passed 64 keys: wave w looks after rows w*32 .. w*32+31
-            unsigned long long* sc = (unsigned long long*)lds + wave * SEL_CAP;
-            for (int r = wave * 32; r < wave * 32 + 32; ++r) {
-                const int n = cnt[r];
-                if (n > 64) {
-                    const int m2 = compact_row(lists + r * row_stride, n, p.k, sc, &thr[r], lane);
-                    if (lane == 0) cnt[r] = m2;
+                __syncthreads();   // the half's candidates are in (and visible: workgroup-scope fence)
+                if constexpr (MODE == MODE_ARGMIN) {
+                    if (tid < BM && best[tid] != ~0ull) set_thr(tid, unpack_val(best[tid]));
+                } else {
+                    // ---- compaction of the rows whose list passed 64 keys: wave w looks after rows w*32 .. w*32+31
+                    unsigned long long* sc = (unsigned long long*)scratch + wave * SEL_CAP;
+                    for (int r = wave * 32; r < wave * 32 + 32; ++r) {
+                        const int n = cnt[r];
+                        if (n > 64) {
+                            float kth = INFINITY;
+                            const int m2 = compact_row(lists + r * row_stride, lists + r * row_stride, n, p.k, sc, &kth, lane);
+                            kth = __shfl(kth, __builtin_ctzll(__ballot(kth != INFINITY) | (1ull << 63)));
+                            if (lane == 0) {
+                                cnt[r] = m2;
+                                if (kth != INFINITY) set_thr(r, kth);
+                            }
+                        }
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
+        cur = nxt;
     }
-    // ---- every row's list down to its <= k smallest, ascending; the count goes out for the merge
-    if constexpr (!BOUND) {
-        unsigned long long* sc = (unsigned long long*)lds + wave * SEL_CAP;
+    // ---- results of the segment: the row's <= k smallest keys, ascending, padded with ~0, dense [M][S][k] for the merge
+    if constexpr (MODE == MODE_ARGMIN) {
+        if (tid < rows_a) p.final_keys[(long long)(m_blk + tid) * p.S + seg] = best[tid];
+    } else if constexpr (MODE == MODE_SELECT) {
+        unsigned long long* sc = (unsigned long long*)(lds + STAGE) + wave * SEL_CAP;
         for (int r = wave * 32; r < wave * 32 + 32; ++r) {
             if (r >= rows_a) break;
-            const int n = cnt[r];
-            const int m2 = compact_row(lists + r * row_stride, n, p.k, sc, &thr[r], lane);
-            if (lane == 0) p.counts[(long long)(m_blk + r) * p.S + seg] = m2;
+            float kth;
+            unsigned long long* out = p.final_keys + ((long long)(m_blk + r) * p.S + seg) * p.k;
+            const int m2 = compact_row(lists + r * row_stride, out, cnt[r], p.k, sc, &kth, lane);
+            if (lane >= m2 && lane < p.k) out[lane] = ~0ull;
         }
     }
 #endif
 }
 
-// One wave per row: merge of the row's S ascending lists (counts[row][s] keys each) -> D[row][k], I[row][k] ascending, padded with
-// (+inf, -1).  The S * k slots sit in registers (NPL per lane); k rounds of wave minimum, the owner retires its key.  Keys are
-// unique (they carry the column), so exactly one lane retires per round.
+// One wave per row: merge of the row's S ascending lists final_keys[row][s][0..k) (padded with ~0) -> D[row][k], I[row][k] ascending,
+// padded with (+inf, -1).  The S * k keys sit in registers (NPL per lane, coalesced loads); k rounds of wave minimum, the owner
+// retires its key.  Keys are unique (they carry the column), so exactly one lane retires per round.
 template <int NPL>
-__global__ __launch_bounds__(256) void select_merge_kernel(const unsigned long long* __restrict__ lists, const int* __restrict__ counts,
-                                                           int M, int S, int k, float* __restrict__ D, int32_t* __restrict__ I) {
+__global__ __launch_bounds__(256) void select_merge_kernel(const unsigned long long* __restrict__ final_keys, int M, int S, int k,
+                                                           float* __restrict__ D, int32_t* __restrict__ I) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
-    const unsigned long long* L = lists + (long long)row * S * SEL_CAP;
-    const int* cn = counts + (long long)row * S;
+    const unsigned long long* L = final_keys + (long long)row * S * k;
     unsigned long long key[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int c = lane + 64 * i;
-        const int s = c / k, j = c - s * k;
-        key[i] = (c < S * k && j < cn[s]) ? L[(long long)s * SEL_CAP + j] : ~0ull;
+        key[i] = c < S * k ? L[c] : ~0ull;
     }
     for (int r = 0; r < k; ++r) {
         unsigned long long mine = key[0];
@@ -345,35 +395,38 @@ __global__ __launch_bounds__(256) void select_merge_kernel(const unsigned long l
 }
 
 template <int METRIC>
-void launch_metric(reid_ctx* ctx, const SelectParams& p, int blocks, bool bound) {
-    if (bound) hipLaunchKernelGGL((dist_select_kernel<METRIC, true>), dim3(blocks), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((dist_select_kernel<METRIC, false>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+void launch_metric(reid_ctx* ctx, const SelectParams& p, int blocks, int mode) {
+    if (mode == MODE_BOUND) hipLaunchKernelGGL((dist_select_kernel<METRIC, MODE_BOUND>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+    else if (mode == MODE_ARGMIN) hipLaunchKernelGGL((dist_select_kernel<METRIC, MODE_ARGMIN>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((dist_select_kernel<METRIC, MODE_SELECT>), dim3(blocks), dim3(256), 0, ctx->stream, p);
 }
-void launch_any(reid_ctx* ctx, const SelectParams& p, int blocks, bool bound) {
+void launch_any(reid_ctx* ctx, const SelectParams& p, int blocks, int mode) {
     switch (p.metric) {
-        case REID_METRIC_L2: launch_metric<REID_METRIC_L2>(ctx, p, blocks, bound); break;
-        case REID_METRIC_L2SQR: launch_metric<REID_METRIC_L2SQR>(ctx, p, blocks, bound); break;
-        case REID_METRIC_COS_HALF: launch_metric<REID_METRIC_COS_HALF>(ctx, p, blocks, bound); break;
-        case REID_METRIC_COS: launch_metric<REID_METRIC_COS>(ctx, p, blocks, bound); break;
-        default: launch_metric<REID_METRIC_DOT>(ctx, p, blocks, bound); break;
+        case REID_METRIC_L2: launch_metric<REID_METRIC_L2>(ctx, p, blocks, mode); break;
+        case REID_METRIC_L2SQR: launch_metric<REID_METRIC_L2SQR>(ctx, p, blocks, mode); break;
+        case REID_METRIC_COS_HALF: launch_metric<REID_METRIC_COS_HALF>(ctx, p, blocks, mode); break;
+        case REID_METRIC_COS: launch_metric<REID_METRIC_COS>(ctx, p, blocks, mode); break;
+        default: launch_metric<REID_METRIC_DOT>(ctx, p, blocks, mode); break;
     }
 }
 
 }  // namespace
 
 int select_segments(int m, int n) {
-    // >= two blocks per CU (256 CUs): S segments of y's column tiles per row tile; never more segments than column tiles
+    // blocks = row tiles x S must fit ONE round of two blocks per CU (256 CUs): persistent blocks of a second, partial round would
+    // run while most of the chip idles (125 row tiles x 5 segments = 625 blocks took as long as 1024 would).  Never more
+    // segments than column tiles, at most 32 (S * k <= 2048 keys: the merge keeps them in registers), no empty segment.
     const int nmt = (m + BM - 1) / BM, nnt = (n + BN - 1) / BN;
-    int S = (512 + nmt - 1) / nmt;
+    int S = 512 / nmt;
     if (S > nnt) S = nnt;
-    if (S > 32) S = 32;        // S * k <= 32 * 64 slots: the merge keeps them in registers
+    if (S > 32) S = 32;
     if (S < 1) S = 1;
     const int per = (nnt + S - 1) / S;
-    return (nnt + per - 1) / per;   // no empty segments
+    return (nnt + per - 1) / per;
 }
 
 bool dist_select_supported(const SelectParams& p) {
-    return p.k >= 1 && p.k <= SEL_KMAX && p.K % BK == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
+    return p.k >= 1 && p.k <= SEL_KMAX && p.K % (2 * BK) == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
            (long long)BM * p.lda * 4 < 0x7fff0000ll && (long long)BN * p.ldb * 4 < 0x7fff0000ll && ((uintptr_t)p.A % 16) == 0 &&
            ((uintptr_t)p.B % 16) == 0;
 }
@@ -384,22 +437,22 @@ int launch_dist_bound(reid_ctx* ctx, const SelectParams& p) {
     SelectParams q = p;
     q.S = nnt;
     prof_begin(ctx, REID_K_DIST_GEMM, 2.0 * p.M * p.N * p.K, 4.0 * ((double)p.M * p.K + (double)p.N * p.K));
-    launch_any(ctx, q, nmt * nnt, true);
+    launch_any(ctx, q, nmt * nnt, MODE_BOUND);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
 }
 
-// lists: [M][S][SEL_CAP] u64, counts: [M][S] int - scratch of the caller; p.gmin: null or the sample's group minima.
+// p.lists: [M][S][SEL_CAP] u64 scratch (unused for k = 1), p.final_keys: [M][S][k] u64 scratch, p.gmin: null or the sample's group minima.
 int launch_dist_select(reid_ctx* ctx, const SelectParams& p, float* d_D, int32_t* d_I) {
     const int nmt = (p.M + BM - 1) / BM;
     prof_begin(ctx, REID_K_DIST_GEMM, 2.0 * p.M * p.N * p.K, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + 2.0 * p.M * p.k));
-    launch_any(ctx, p, nmt * p.S, false);
+    launch_any(ctx, p, nmt * p.S, p.k == 1 ? MODE_ARGMIN : MODE_SELECT);
     prof_end(ctx);
     LAUNCH_CHECK();
     prof_begin(ctx, REID_K_SELECT, 0, (double)p.M * p.S * p.k * 8.0);
     const int slots = p.S * p.k, blocks = (p.M + 3) / 4;
-#define MERGE(NPL) hipLaunchKernelGGL((select_merge_kernel<NPL>), dim3(blocks), dim3(256), 0, ctx->stream, p.lists, p.counts, p.M, p.S, p.k, d_D, d_I)
+#define MERGE(NPL) hipLaunchKernelGGL((select_merge_kernel<NPL>), dim3(blocks), dim3(256), 0, ctx->stream, p.final_keys, p.M, p.S, p.k, d_D, d_I)
     if (slots <= 64) MERGE(1);
     else if (slots <= 128) MERGE(2);
     else if (slots <= 256) MERGE(4);

@@ -93,13 +93,13 @@ constexpr int SEL_KMAX = 64;    // largest k of the fused path (a list is compac
 struct SelectParams {
     const float* A;             // x [M][lda]
     const float* B;             // y [N][ldb]
-    int lda, ldb, M, N, K;      // K % 32 == 0 (zero-padded rows)
+    int lda, ldb, M, N, K;      // K % 64 == 0 (zero-padded rows)
     const float* row_sq;        // |x_i|^2, |y_j|^2 (null for REID_METRIC_DOT)
     const float* col_sq;
     unsigned int* gmin;         // [M][k] group minima of a sample of y as order-preserving keys (null: start from +inf)
-    int metric, k, S, index_base;
-    unsigned long long* lists;  // scratch [M][S][SEL_CAP]
-    int* counts;                // scratch [M][S]
+    int metric, k, S, index_base, exp_skip;
+    unsigned long long* lists;  // scratch [M][S][SEL_CAP] (k > 1)
+    unsigned long long* final_keys;   // scratch [M][S][k]: every segment's result for the merge
 };
 int select_segments(int m, int n);
 bool dist_select_supported(const SelectParams& p);
