@@ -140,12 +140,15 @@ int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int h, 
 /* out[m][n] = metric(x[m][d], y[n][d])        reid/losses/utils.py:12-35, reid/evaluate.py:58 */
 int reid_distmat(reid_ctx* ctx, const float* x, int m, const float* y, int n, int d, int metric, float* out);
 int reid_distmat_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric, float* d_out);
-/* per-row minimum of the distance matrix without returning the matrix; ties -> lowest column index */
+/* per-row minimum of the distance matrix; ties -> lowest column index.  From 2048 rows of y on the selection runs in the
+ * epilogue of the distance GEMM (csrc/dist_select.hip) and the m x n matrix is never written; smaller problems go through a
+ * scratch matrix of a few MB.  evaluate.py:58-63 (the top-1 of `score`). */
 int reid_argmin_rows(reid_ctx* ctx, const float* x, int m, const float* y, int n, int d, int metric,
                      int32_t* idx, float* val);
 int reid_argmin_rows_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric,
                          int32_t* d_idx, float* d_val);
-/* brute-force squared-L2 k-NN: D fp32[nq][k] ascending, I int32[nq][k]; ties -> lowest index.
+/* brute-force squared-L2 k-NN: D fp32[nq][k] ascending, I int32[nq][k]; ties -> lowest index.  k <= 64 and nb >= 2048: fused
+ * distance + selection (no nq x nb matrix), otherwise distance matrix tiles + a top-k pass.
  * search_raw_array_pytorch / IndexFlatL2.search, reid/faiss_utils.py:56-139 */
 int reid_knn(reid_ctx* ctx, const float* xq, int nq, const float* xb, int nb, int d, int k, float* D, int32_t* I);
 int reid_knn_dev(reid_ctx* ctx, const float* d_xq, int nq, const float* d_xb, int nb, int d, int k,

@@ -1114,9 +1114,11 @@ static int select_fused_dev(reid_ctx* ctx, const float* d_x, int m, const float*
         p.row_sq = xx; p.col_sq = yy;
     }
     p.S = select_segments(m, n);
-    REID_TRY(ctx_ws(ctx, "sel.final", (size_t)m * p.S * k * 8, (void**)&p.final_keys));
-    if (k > 1) {
+    if (k == 1) {
+        REID_TRY(ctx_ws(ctx, "sel.final", (size_t)m * p.S * 8, (void**)&p.final_keys));
+    } else {
         REID_TRY(ctx_ws(ctx, "sel.lists", (size_t)m * p.S * SEL_CAP * 8, (void**)&p.lists));
+        REID_TRY(ctx_ws(ctx, "sel.counts", (size_t)m * p.S * 4, (void**)&p.counts));
         // per-row bound from a SAMPLE of y (its first 1024 rows - part of y, so a bound of the sample's k-th smallest holds for all
         // of y); the arg-min form needs none (its threshold is the running minimum itself)
         REID_TRY(ctx_ws(ctx, "sel.gmin", (size_t)m * k * 4, (void**)&p.gmin));
@@ -1125,7 +1127,18 @@ static int select_fused_dev(reid_ctx* ctx, const float* d_x, int m, const float*
         ps.N = sample;
         REID_TRY(launch_dist_bound(ctx, ps));
     }
-    return launch_dist_select(ctx, p, d_D, d_I);
+    REID_TRY(launch_dist_select(ctx, p, d_D, d_I));
+    if (p.exp_skip == 4 && k > 1) {   // diagnostics: how long are the candidate lists when the sweep ends?
+        std::vector<int> h((size_t)m * p.S);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(h.data(), p.counts, h.size() * 4, hipMemcpyDeviceToHost));
+        long long sum = 0;
+        int mx = 0;
+        for (int v : h) { sum += v; mx = v > mx ? v : mx; }
+        fprintf(stderr, "[dist_select] m %d n %d k %d S %d: candidates per (row, segment) mean %.1f max %d, per row %.0f\n", m, n, k, p.S,
+                (double)sum / h.size(), mx, (double)sum / m);
+    }
+    return REID_OK;
 }
 
 extern "C" int reid_argmin_rows_dev(reid_ctx* ctx, const float* d_x, int m, const float* d_y, int n, int d, int metric,

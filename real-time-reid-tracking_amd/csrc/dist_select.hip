@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
             for (int i = tid; i < rows_a * p.k; i += 256)
                 if (gm[i] != 0xffffffffu) atomicMin(p.gmin + (long long)m_blk * p.k + i, gm[i]);
             __syncthreads();
-        } else if (!p.exp_skip) {
+        } else if (p.exp_skip != 1) {
             // ---- filter: two halves of 64 columns (b = MFMA column block of each of the two wave columns)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -297,24 +297,41 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
                         th[4 * q] = t4.x; th[4 * q + 1] = t4.y; th[4 * q + 2] = t4.z; th[4 * q + 3] = t4.w;
                         rs[4 * q] = r4.x; rs[4 * q + 1] = r4.y; rs[4 * q + 2] = r4.z; rs[4 * q + 3] = r4.w;
                     }
+                    // L2: pre-filter on the value under the square root (two instructions); the root and the exact test only
+                    // for what passes.  The other metrics compare the distance itself.
+                    // Two phases per group of 16 elements: all slot requests (LDS atomics with return) are issued before the
+                    // first answer is needed, then the keys go out - an `if (pass) { atomic; store }` per element serialised 64
+                    // LDS round trips per tile (the body runs whenever ANY lane passes: ~always at a few per cent per lane).
+                    float v[16];
+                    int slot[16];
+                    unsigned pass = 0;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        // L2: pre-filter on the value under the square root (two instructions); the root and the exact test only
-                        // for what passes.  The other metrics compare the distance itself.
                         const float w = METRIC == REID_METRIC_L2 ? (rs[e] + cq) - 2.0f * acc[a][b][e] : dist_of<METRIC>(acc[a][b][e], rs[e], cq);
+                        v[e] = w;
                         const int row = rbase + (e & 3) + 8 * (e >> 2);
-                        if (colok && row < rows_a && w <= th[e]) {
-                            const float v = METRIC == REID_METRIC_L2 ? sqrtf(fmaxf(w, 1e-12f)) : w;
-                            if (METRIC != REID_METRIC_L2 || v <= thr[row]) {
-                                const unsigned long long key = pack_key(v, col + p.index_base);
-                                if constexpr (MODE == MODE_ARGMIN) {
-                                    atomicMin(&best[row], key);
-                                } else {
-                                    const int slot = atomicAdd(&cnt[row], 1);
-                                    lists[row * row_stride + slot] = key;
-                                }
+                        pass |= (colok && row < rows_a && w <= th[e]) ? (1u << e) : 0u;
+                    }
+                    if (__ballot(pass != 0) == 0) continue;   // nobody in the wave: the common case once thr is tight
+                    if (METRIC == REID_METRIC_L2) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            if (pass & (1u << e)) {
+                                v[e] = sqrtf(fmaxf(v[e], 1e-12f));
+                                if (!(v[e] <= thr[rbase + (e & 3) + 8 * (e >> 2)])) pass &= ~(1u << e);
                             }
                         }
+                    }
+                    if constexpr (MODE == MODE_ARGMIN) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (pass & (1u << e)) atomicMin(&best[rbase + (e & 3) + 8 * (e >> 2)], pack_key(v[e], col + p.index_base));
+                    } else if (p.exp_skip != 2) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) slot[e] = (pass & (1u << e)) ? atomicAdd(&cnt[rbase + (e & 3) + 8 * (e >> 2)], 1) : 0;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (pass & (1u << e)) lists[(rbase + (e & 3) + 8 * (e >> 2)) * row_stride + slot[e]] = pack_key(v[e], col + p.index_base);
                     }
                 }
                 __syncthreads();   // the half's candidates are in (and visible: workgroup-scope fence)
@@ -341,18 +358,12 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
         }
         cur = nxt;
     }
-    // ---- results of the segment: the row's <= k smallest keys, ascending, padded with ~0, dense [M][S][k] for the merge
+    // ---- results of the segment: the arg-min key, or the length of the row's candidate list (its k smallest are among them; the
+    // merge kernel selects - compacting 128 lists at the end of a block, a few waves on an otherwise finished CU, cost 48 us)
     if constexpr (MODE == MODE_ARGMIN) {
         if (tid < rows_a) p.final_keys[(long long)(m_blk + tid) * p.S + seg] = best[tid];
     } else if constexpr (MODE == MODE_SELECT) {
-        unsigned long long* sc = (unsigned long long*)(lds + STAGE) + wave * SEL_CAP;
-        for (int r = wave * 32; r < wave * 32 + 32; ++r) {
-            if (r >= rows_a) break;
-            float kth;
-            unsigned long long* out = p.final_keys + ((long long)(m_blk + r) * p.S + seg) * p.k;
-            const int m2 = compact_row(lists + r * row_stride, out, cnt[r], p.k, sc, &kth, lane);
-            if (lane >= m2 && lane < p.k) out[lane] = ~0ull;
-        }
+        if (tid < rows_a) p.counts[(long long)(m_blk + tid) * p.S + seg] = cnt[tid];
     }
 #endif
 }
@@ -391,6 +402,129 @@ __global__ __launch_bounds__(256) void select_merge_kernel(const unsigned long l
             for (int i = 0; i < NPL; ++i)
                 if (key[i] == best) key[i] = ~0ull;
         }
+    }
+}
+
+// One wave per row, k > 1: selection of the k smallest among the row's S candidate lists (counts[row][s] unsorted keys each,
+// <= SEL_CAP; ~700 keys for the Market-size search).  k rounds of wave minimum are latency-bound (a 64-bit cross-lane minimum
+// is six LDS-crossbar round trips: 40 us per row); instead:
+//   1. the lists go to LDS back to back, then into registers (32 per lane, static indices);
+//   2. pivot P = k-th smallest of the 64 per-lane minima (rank by counting over 64 LDS broadcast reads): at least k keys are
+//      <= P, and - the lanes' shares being random subsets - only a few more;
+//   3. the keys <= P are compacted into LDS (ballot + prefix count) and ranked by counting; a key of rank r < k is output r.
+// More than 128 survivors (adversarial data) or more than 2048 keys: k rounds of "smallest key above the last" over memory.
+constexpr int MERGE_LDS = 2048;   // keys per wave held in LDS / registers
+__global__ __launch_bounds__(256) void select_merge_lists_kernel(const unsigned long long* __restrict__ lists, const int* __restrict__ counts,
+                                                                 int M, int S, int k, float* __restrict__ D, int32_t* __restrict__ I) {
+    __shared__ unsigned long long sh[4][MERGE_LDS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    typedef unsigned long long u64;
+    const u64* L = lists + (long long)row * S * SEL_CAP;
+    const int* cn = counts + (long long)row * S;
+    const int mycnt = lane < S ? cn[lane] : 0;             // S <= 32: lane s holds the length of list s
+    int total = mycnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    auto put = [&](int r, u64 key) {
+        if (D) D[(long long)row * k + r] = key == ~0ull ? INFINITY : unpack_val(key);
+        if (I) I[(long long)row * k + r] = key == ~0ull ? -1 : (int32_t)(key & 0xffffffffu);
+    };
+    u64* shw = sh[wave];
+    bool done = false;
+    if (total <= MERGE_LDS) {
+        int at = 0;
+        for (int s0 = 0; s0 < S; s0 += 8) {   // eight lists per step, every load of a step issued before the first is used
+            u64 v0[8], v1[8];
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                c[u] = s0 + u < S ? __shfl(mycnt, s0 + u) : 0;
+                const u64* Ls = L + (long long)(s0 + u) * SEL_CAP;
+                v0[u] = lane < c[u] ? Ls[lane] : 0;
+                v1[u] = lane + 64 < c[u] ? Ls[lane + 64] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (lane < c[u]) shw[at + lane] = v0[u];
+                if (lane + 64 < c[u]) shw[at + lane + 64] = v1[u];
+                at += c[u];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u64 key[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) key[i] = lane + 64 * i < total ? shw[lane + 64 * i] : ~0ull;
+        u64 mn = key[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) mn = key[i] < mn ? key[i] : mn;
+        __builtin_amdgcn_wave_barrier();
+        // pivot: the k-th smallest lane minimum (all keys when fewer than k lanes hold one)
+        shw[lane] = mn;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int rk = 0;
+        for (int j = 0; j < 64; ++j) rk += shw[j] < mn ? 1 : 0;
+        const int holders = total < 64 ? total : 64;
+        const int want = (k < holders ? k : holders) - 1;                // rank of the pivot among the lane minima
+        const unsigned long long who = __ballot(mn != ~0ull && rk == want);   // unique: keys are unique
+        u64 P = ~0ull;
+        if (who) {
+            const int src = __builtin_ctzll(who);
+            P = ((u64)(unsigned)__shfl((int)(mn >> 32), src) << 32) | (unsigned)__shfl((int)(mn & 0xffffffffu), src);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // survivors -> LDS (the minima were consumed above)
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i * 64 < total) {
+                const bool pass = key[i] <= P && key[i] != ~0ull;
+                const unsigned long long bal = __ballot(pass);
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1));
+                if (pass && pos < 128) shw[pos] = key[i];
+                base += __popcll(bal);
+            }
+        }
+        if (base <= 128) {
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const u64 k0 = lane < base ? shw[lane] : ~0ull, k1 = lane + 64 < base ? shw[lane + 64] : ~0ull;
+            int r0 = 0, r1 = 0;
+            for (int j = 0; j < base; ++j) {
+                const u64 kj = shw[j];
+                r0 += kj < k0 ? 1 : 0;
+                r1 += kj < k1 ? 1 : 0;
+            }
+            if (lane < base && r0 < k) put(r0, k0);
+            if (lane + 64 < base && r1 < k) put(r1, k1);
+            for (int r = base + lane; r < k; r += 64) put(r, ~0ull);    // fewer than k candidates in all of y
+            done = true;
+        }
+    }
+    if (done) return;
+    u64 last = 0;
+    bool first = true;
+    for (int r = 0; r < k; ++r) {
+        u64 best = ~0ull;
+        for (int s = 0; s < S; ++s) {
+            const int c = __shfl(mycnt, s);
+            for (int j = lane; j < c; j += 64) {
+                const u64 key = L[(long long)s * SEL_CAP + j];
+                if ((first || key > last) && key < best) best = key;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 other = __shfl_xor(best, o);
+            best = other < best ? other : best;
+        }
+        if (lane == 0) put(r, best);
+        last = best;
+        first = false;
+        if (best == ~0ull) last = ~0ull - 1;   // nothing left: every later round finds nothing either
     }
 }
 
@@ -452,6 +586,12 @@ int launch_dist_select(reid_ctx* ctx, const SelectParams& p, float* d_D, int32_t
     LAUNCH_CHECK();
     prof_begin(ctx, REID_K_SELECT, 0, (double)p.M * p.S * p.k * 8.0);
     const int slots = p.S * p.k, blocks = (p.M + 3) / 4;
+    if (p.k > 1) {
+        hipLaunchKernelGGL(select_merge_lists_kernel, dim3(blocks), dim3(256), 0, ctx->stream, p.lists, p.counts, p.M, p.S, p.k, d_D, d_I);
+        prof_end(ctx);
+        LAUNCH_CHECK();
+        return REID_OK;
+    }
 #define MERGE(NPL) hipLaunchKernelGGL((select_merge_kernel<NPL>), dim3(blocks), dim3(256), 0, ctx->stream, p.final_keys, p.M, p.S, p.k, d_D, d_I)
     if (slots <= 64) MERGE(1);
     else if (slots <= 128) MERGE(2);

@@ -99,7 +99,8 @@ struct SelectParams {
     unsigned int* gmin;         // [M][k] group minima of a sample of y as order-preserving keys (null: start from +inf)
     int metric, k, S, index_base, exp_skip;
     unsigned long long* lists;  // scratch [M][S][SEL_CAP] (k > 1)
-    unsigned long long* final_keys;   // scratch [M][S][k]: every segment's result for the merge
+    int* counts;                // scratch [M][S]: lengths of the lists when the sweep ends (k > 1)
+    unsigned long long* final_keys;   // scratch [M][S]: every segment's arg-min key (k = 1)
 };
 int select_segments(int m, int n);
 bool dist_select_supported(const SelectParams& p);
