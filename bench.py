@@ -5,13 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Default workload = BASELINE configs[1] on every rank: embed 4096 synthetic uint8 crops (128x256, already resident in HBM)
+Default = every BASELINE configuration in ONE JSON line: configs[1] is the headline (`value`, `roofline`, `cpu_baseline` at the
+top level, as the contract asks), configs[0]'s batch size / configs[2] / configs[4] / configs[3] follow as the sub-objects
+`batch256`, `swin`, `market`, `tracking`, each with its own `roofline` and bounded `cpu_baseline` (run_all).
+Headline = BASELINE configs[1] on every rank: embed 4096 synthetic uint8 crops (128x256, already resident in HBM)
 with ResNet18-IBN-SE in the reference's arithmetic (fp32), [N>1: ONE RCCL all-gather of the 512-d embeddings, issued through
 the C ABI - csrc/comm.hip, no torch.distributed on the data path], then the L2 distance matrix of this rank's 4096
 embeddings against all gathered ones.  Weak scaling: per-GPU work is fixed, value = crops of ALL ranks / max-over-ranks
 time.  Prints ONE JSON line on rank 0.  The fp16-storage mode is measured in the same run and reported as `f16_path`.
 
-Other BASELINE configs, same launch line plus --workload:
+One configuration alone, same launch line plus --workload (embed = the headline alone):
     --workload swin      configs[2]: Swin-T v1, 4096 images 224x224 per rank (weak)
     --workload tracking  configs[3]: 600-frame detection stream, each frame's crops dealt round-robin to the ranks,
                          all-gather of the frame's embeddings, feature-bank cost + DIoU on every rank (strong)
@@ -460,6 +463,24 @@ def run_tracking(job, args):
             lat.append(time.perf_counter() - t1)
     job.barrier()
     elapsed = float(comm.all_reduce([time.perf_counter() - t0], "max")[0])
+    # roofline object of the frame's convolutions: the first 100 frames again with every launch of the class bracketed by HIP
+    # events on its stream (same flow as the timed region; on EVERY rank - the frames hold a collective)
+    from reid_amd import _ffi
+    eng.profile_reset()
+    eng.profile(True)
+    nprof = min(100, frames)
+    if pipelined:
+        run_pipelined(0, nprof, [])
+    else:
+        for f in range(nprof):
+            frame(f)
+    eng.sync()
+    conv = eng.profile_get(_ffi.K_CONV_GEMM)
+    eng.profile(False)
+    job.barrier()
+    if not (pipelined and world == 1 and args.cameras > 1):
+        stream.metric.close()
+        eng.set_precision(0)
     if rank != 0:
         return None
     lat = np.asarray(lat) * 1e3
@@ -486,20 +507,6 @@ def run_tracking(job, args):
         elc = time.perf_counter() - t0c
         cpu = {"value": round(fc / elc, 2), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "%d frames, %d crops (%.1f s): oracle preprocess + oracle/seres18.py + numpy bank cost + DIoU" % (fc, cc, elc)}
-    # roofline object of the frame's convolutions: the first 100 frames again with every launch of the class bracketed by HIP
-    # events on its stream (same flow as the timed region)
-    from reid_amd import _ffi
-    eng.profile_reset()
-    eng.profile(True)
-    nprof = min(100, frames)
-    if pipelined:
-        run_pipelined(0, nprof, [])
-    else:
-        for f in range(nprof):
-            frame(f)
-    eng.sync()
-    conv = eng.profile_get(_ffi.K_CONV_GEMM)
-    eng.profile(False)
     peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16" else PEAK_F32_MFMA_TFLOPS
     conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
     roof = {"kernel": "convolution kernels of a frame's forward (~%d crops per rank: launches of at most one wave of blocks, latency-bound K loops)"
@@ -552,6 +559,8 @@ def run_tracking(job, args):
             "allgather_us_median": round(float(np.median(gather_us)), 1) if gather_us else None}
     out["roofline"] = roof
     if multi is not None:
+        stream.metric.close()
+        eng.set_precision(0)
         out["camera_streams"] = multi
     if cpu is not None:
         out["cpu_baseline"] = cpu
@@ -581,6 +590,10 @@ def run_market(job, args):
     if hi > lo:
         eng.distmat_dev(dq.ptr, nq, dg.ptr, hi - lo, d, _ffi.METRIC_L2, dist.ptr)
     dist_ms = eng.timer_stop()
+    eng.timer_start()
+    for _ in range(5):       # the search alone: fused distance + top-20 (no matrix) + exchange + merge
+        parallel.knn_gallery_sharded_dev(eng, dq.ptr, nq, dg.ptr, hi - lo, lo, d, k, dD.ptr, dI.ptr, world)
+    search_ms = eng.timer_stop() / 5
     I = dI.numpy()
     # Rank-1 over the merged lists, reference rule (reid/evaluate.py:55-105): first item that is not junk (same id AND same camera)
     junk = (gl[I] == ql[:, None]) & (gc[I] == qc[:, None])
@@ -595,9 +608,11 @@ def run_market(job, args):
            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "BASELINE configs[4]: 3368 x 15913 x 512, gallery rows sharded over %d rank(s): shard distance matrix + "
-                                  "top-%d per shard, all-gather (fp32 distances, int32 indices), device k-way merge" % (world, k)},
-           "distmat_shard_ms": round(dist_ms, 3), "rank1_top%d" % k: rank1,
+           "config": {"workload": "BASELINE configs[4]: 3368 x 15913 x 512, gallery rows sharded over %d rank(s): shard distance matrix, then "
+                                  "the search - top-%d per shard with the selection fused into the distance GEMM (no matrix), all-gather "
+                                  "(fp32 distances, int32 indices), device k-way merge" % (world, k)},
+           "distmat_shard_ms": round(dist_ms, 3), "search_ms": round(search_ms, 3),
+           "search_tflops": round(2.0 * nq * (hi - lo) * d / (search_ms * 1e-3) / 1e12, 2), "rank1_top%d" % k: rank1,
            "roofline": {"kernel": "gemm_f32_dma_kernel<E_DIST> (dense LDS-DMA GEMM + distance epilogue, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                         "achieved": round(flops / (dist_ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flops / (dist_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic_from_profile("market"),
@@ -612,13 +627,89 @@ def run_market(job, args):
     return out
 
 
+SUB_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config", "roofline", "cpu_baseline",
+            "f16_path", "f32_path", "other_kernels", "embed_ms", "distmat_ms", "distmat_shard_ms", "search_ms", "search_tflops",
+            "crops_per_s", "ms_per_frame_median", "ms_per_frame_p95", "allgather_us_median", "camera_streams", "rank1_top20",
+            "whole_net_tflops", "f16_vs_f32_max_cosine_err")
+
+
+def run_all(job, args):
+    """The default line: BASELINE configs[1] as the headline (value / roofline / cpu_baseline as before) plus the other
+    configurations as sub-objects of the SAME JSON line, each with its own roofline and bounded cpu_baseline:
+    `batch256` (configs[0]'s size: 256 crops + 256 x 256 distmat), `swin` (configs[2]), `market` (configs[4]), `tracking`
+    (configs[3] stand-in, exact fp32 with the fp16-storage run nested as f16_path).  A sub-workload that raises is reported as
+    {"error": ...}; one that does not come back within its time limit (a collective some rank never entered) ends the job
+    from a watchdog thread: rank 0 prints the line with what it has, every rank leaves with exit code 0."""
+    import copy
+    import threading
+    state = {"out": None, "current": None, "deadline": None}
+
+    def watchdog():
+        while True:
+            time.sleep(1.0)
+            dl = state["deadline"]
+            if dl is not None and time.monotonic() > dl:
+                if job.rank == 0 and state["out"] is not None:
+                    state["out"][state["current"]] = {"error": "no answer within the time limit (watchdog)"}
+                    print(json.dumps(state["out"]), flush=True)
+                os._exit(0)
+
+    out = run_embed(job, args)
+    state["out"] = out
+    threading.Thread(target=watchdog, daemon=True).start()
+
+    def sub(name, fn, limit_s, **over):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        state["current"], state["deadline"] = name, time.monotonic() + limit_s
+        try:
+            res = fn(job, a)
+            if res is not None:
+                res = {k: res[k] for k in SUB_KEYS if k in res}
+        except Exception as e:     # noqa: BLE001 - recorded in the line; the remaining sub-workloads still run on one GPU
+            res = {"error": "%s: %s" % (type(e).__name__, e)}
+            if job.world > 1:      # the ranks are no longer in step: stop here (the watchdog releases ranks stuck in a collective)
+                state["deadline"] = time.monotonic() + 20
+                if out is not None:
+                    out[name] = res
+                raise
+        state["deadline"] = None
+        if out is not None:
+            out[name] = res
+
+    def tracking_both(job_, a):
+        r32 = run_tracking(job_, a)
+        a16 = copy.copy(a)
+        a16.precision, a16.no_cpu = "f16", True
+        r16 = run_tracking(job_, a16)
+        if r32 is not None:
+            r32["f16_path"] = {k: r16[k] for k in ("value", "ms_per_step", "crops_per_s", "ms_per_frame_median", "ms_per_frame_p95",
+                                                   "roofline", "camera_streams") if k in r16}
+        return r32
+
+    try:
+        sub("batch256", run_embed, 240, crops=256, steps=20, warmup=3, no_cpu=True)
+        sub("swin", run_swin, 300, crops=4096, steps=2, warmup=1)
+        sub("market", run_market, 240, steps=20, warmup=3)
+        sub("tracking", tracking_both, 300, precision="f32", cameras=2 if job.world == 1 else 0)
+    except Exception as e:     # noqa: BLE001 - multi-rank job out of step: print what there is and leave
+        print("[bench rank %d] sub-workload failed: %r" % (job.rank, e), file=sys.stderr, flush=True)
+        if job.rank == 0 and out is not None:
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    state["deadline"] = None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["embed", "swin", "tracking", "market"], default="embed",
-                    help="embed = BASELINE configs[1] (the metric's configuration, default); the others are configs[2..4]")
+    ap.add_argument("--workload", choices=["all", "embed", "batch256", "swin", "tracking", "market"], default="all",
+                    help="all (default) = BASELINE configs[1] as the headline + the other configurations as sub-objects of the same "
+                         "line; embed = configs[1] alone; batch256 / swin / tracking / market = that configuration as its own line")
     ap.add_argument("--crops", type=int, default=4096, help="crops (images) per GPU per step (BASELINE config 2 / 3: 4096)")
     ap.add_argument("--frames", type=int, default=600, help="--workload tracking: frames of the stream")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "1024")))
@@ -630,12 +721,16 @@ def main():
                     help="arithmetic of the headline: f32 = the reference's (exact fp32 MFMA, default); f16 = fp16 storage / fp32 "
                          "accumulate (inside north_star's 1e-3 cosine tolerance, reported as the labelled side run by default)")
     args = ap.parse_args()
+    if args.workload == "batch256":
+        args.crops = 256
 
     job = Job(args)
     try:
-        out = {"embed": run_embed, "swin": run_swin, "tracking": run_tracking, "market": run_market}[args.workload](job, args)
+        fn = {"all": run_all, "embed": run_embed, "batch256": run_embed, "swin": run_swin, "tracking": run_tracking,
+              "market": run_market}[args.workload]
+        out = fn(job, args)
         if out is not None:
-            print(json.dumps(out))
+            print(json.dumps(out), flush=True)
         job.barrier()
     finally:
         job.close()
