@@ -58,8 +58,7 @@ def _torch_cuda_forward(x, embed_dev, engine, out_dims):
     xf = x.detach()
     if xf.dtype != torch.float32 or not xf.is_contiguous():
         xf = xf.float().contiguous()
-    with torch.cuda.device(xf.device):
-        engine.use_torch_stream()
+    with torch.cuda.device(xf.device), engine.on_torch_stream():
         outs = [torch.empty((xf.shape[0], d), dtype=torch.float32, device=xf.device) for d in out_dims]
         embed_dev(xf, outs)
     return outs

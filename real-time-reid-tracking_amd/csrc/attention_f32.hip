@@ -266,11 +266,8 @@ int launch_ema_tail(reid_ctx* ctx, const float* y, const float* sc, int n_img, i
     const int cg = C / 32, hw = H * W;
     const size_t lds = ((size_t)3 * cg * hw + (size_t)2 * cg * (H + W) + 6 * cg) * 4;
     ARG_CHECK(lds <= 150 * 1024);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)ema_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    // per device and not worth caching: a process-wide flag left a second device (or a racing thread) with the 48 KB default
+    HIP_TRY(hipFuncSetAttribute((const void*)ema_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * C * 12.0);
     hipLaunchKernelGGL(ema_tail_kernel, dim3(n_img * 32), dim3(256), lds, ctx->stream, y, sc, H, W, C, prm, out);
     prof_end(ctx);

@@ -599,7 +599,6 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
                 case 256324: return launch_cfg<AMODE, 256, 32, 4, 0, true>(ctx, p);
                 case 256642: return launch_cfg<AMODE, 256, 64, 2, 0, true>(ctx, p);
                 case 128323: return launch_cfg<AMODE, 128, 32, 3, 0, true>(ctx, p);
-                case 128642: return launch_cfg<AMODE, 128, 64, 2, 0, true>(ctx, p);
                 case 64323: return launch_cfg<AMODE, 64, 32, 3, 0, true>(ctx, p);
                 case 64642: return launch_cfg<AMODE, 64, 64, 2, 0, true>(ctx, p);
                 default: break;

@@ -7,6 +7,7 @@
 // (swin_transformer.py:193-194,230-231) is folded into the attention kernel's indexing alone: window position (y', x')
 // reads and writes token ((y'+3) % H, (x'+3) % W).
 #include "reid_internal.h"
+#include <mutex>
 #include <math.h>
 #include <string.h>
 #include <sstream>
@@ -829,12 +830,25 @@ struct SwinWeights {
     const float *tail_g, *tail_b, *tail_p, *neck_s, *neck_t, *cls_w;
 };
 
+// context -> its Swin weights.  Camera streams load / destroy contexts from several host threads: every access to the map itself
+// goes through swin_mutex (std::map nodes are stable, so a SwinWeights found under the lock stays valid until its own context
+// is destroyed - which the owner of that context does, not another thread).
+static std::mutex& swin_mutex() {
+    static std::mutex m;
+    return m;
+}
 static std::map<reid_ctx*, SwinWeights>& swin_registry() {
     static std::map<reid_ctx*, SwinWeights> r;
     return r;
 }
+static SwinWeights* swin_find(reid_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(swin_mutex());
+    auto it = swin_registry().find(ctx);
+    return it == swin_registry().end() ? nullptr : &it->second;
+}
 
 void swin_release(reid_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(swin_mutex());
     auto& r = swin_registry();
     auto it = r.find(ctx);
     if (it != r.end()) {
@@ -1026,20 +1040,23 @@ extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats,
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     w.loaded = true;
-    swin_registry()[ctx] = w;
+    {
+        std::lock_guard<std::mutex> lk(swin_mutex());
+        swin_registry()[ctx] = w;
+    }
     return REID_OK;
 }
 
 extern "C" int reid_swin_dims(reid_ctx* ctx, int* embed_dim, int* num_class) {
     ARG_CHECK(ctx);
     CTX_GUARD(ctx);
-    auto it = swin_registry().find(ctx);
-    if (it == swin_registry().end()) {
+    const SwinWeights* sw = swin_find(ctx);
+    if (!sw) {
         reid_set_error("no Swin weights loaded");
         return REID_ERR_STATE;
     }
     if (embed_dim) *embed_dim = 96;
-    if (num_class) *num_class = it->second.num_class;
+    if (num_class) *num_class = sw->num_class;
     return REID_OK;
 }
 
@@ -1253,12 +1270,12 @@ extern "C" int reid_debug_swin_stage(reid_ctx* ctx, int stage, float* out, size_
 extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int h, int w, float* d_emb, float* d_logits) {
     ARG_CHECK(ctx && d_x && d_emb && n >= 0 && h > 0 && w > 0 && h % 224 == 0 && w % 224 == 0);
     CTX_GUARD(ctx);
-    auto it = swin_registry().find(ctx);
-    if (it == swin_registry().end() || !it->second.loaded) {
+    const SwinWeights* swp = swin_find(ctx);
+    if (!swp || !swp->loaded) {
         reid_set_error("reid_swin_embed_*: call reid_swin_load first");
         return REID_ERR_STATE;
     }
-    const SwinWeights& sw = it->second;
+    const SwinWeights& sw = *swp;
     const int chunk = ctx->chunk < 256 ? ctx->chunk : 256;   // ~13 MB of fp32 activations per 224x224 image
     const size_t img = (size_t)3 * h * w;
     for (int i = 0; i < n; i += chunk) {
@@ -1273,12 +1290,12 @@ extern "C" int reid_swin_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, in
     ARG_CHECK(ctx && x && emb && n >= 0);
     CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
-    auto it = swin_registry().find(ctx);
-    if (it == swin_registry().end()) {
+    const SwinWeights* swp = swin_find(ctx);
+    if (!swp) {
         reid_set_error("reid_swin_embed_*: call reid_swin_load first");
         return REID_ERR_STATE;
     }
-    const int nc = it->second.num_class;
+    const int nc = swp->num_class;
     const size_t img = (size_t)3 * h * w;
     float *d_in, *d_emb, *d_log = nullptr;
     REID_TRY(ctx_ws(ctx, "io.in", (size_t)n * img * 4, (void**)&d_in));

@@ -36,11 +36,22 @@ class Engine:
     def close(self):
         if self.h:
             self.lib.reid_ctx_sync(self.h)
+            for bank in list(getattr(self, "_banks", [])):    # a bank belongs to its context: destroyed before it (no device leak
+                bank.close()                                  # when the engine goes first)
             for p in getattr(self, "_pinned", []):
                 self.lib.reid_host_free(self.h, p)
             self._pinned = []
             self.lib.reid_ctx_destroy(self.h)
             self.h = None
+
+    def register_bank(self, metric):
+        """Feature banks created on this engine (nn_matching.NearestNeighborDistanceMetric): `close` frees them first."""
+        self.__dict__.setdefault("_banks", []).append(metric)
+
+    def unregister_bank(self, metric):
+        banks = self.__dict__.get("_banks", [])
+        if metric in banks:
+            banks.remove(metric)
 
     def __del__(self):
         try:
@@ -70,6 +81,22 @@ class Engine:
         import torch
         s = torch.cuda.current_stream(self.device).cuda_stream
         self.set_stream(s if s else -1)
+
+    def on_torch_stream(self):
+        """Context manager: run on torch's current stream inside, back on the stream the engine had before outside - the
+        process-wide engine is shared with the host-path callers (Extractor, frame pipeline), which must not inherit torch's
+        stream (with the null stream the copy side-stream is switched off)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev = getattr(self, "_stream", 0)
+            self.use_torch_stream()
+            try:
+                yield self
+            finally:
+                self.set_stream(prev)        # drains the torch stream first (set_stream syncs on a switch)
+        return scope()
 
     def set_chunk(self, n):
         check(self.lib.reid_ctx_set_chunk(self.h, int(n)))
@@ -203,6 +230,12 @@ class Engine:
         slab = slabs.get(slot)
         if slab is None or slab.size < total:
             self.sync()          # the old slab may still be the source of an upload
+            if slab is not None:                 # superseded: give its pinned memory back now, not at close()
+                old = slab.ctypes.data
+                for p in list(self._pinned):
+                    if p.value == old:
+                        self.lib.reid_host_free(self.h, p)
+                        self._pinned.remove(p)
             slab = slabs[slot] = self.pinned(max(2 * total, 1 << 22))
         for i, c in enumerate(crops):   # straight into pinned memory: the only host copy of the pixels
             slab[offs[i]: offs[i] + c.size].reshape(c.shape)[...] = c

@@ -36,6 +36,8 @@ class NearestNeighborDistanceMetric:
             h = C.c_void_p()
             check(self._eng.lib.reid_bank_create(self._eng.h, self._max_tracks, self._ring, int(d), C.byref(h)))
             self._bank, self._d = h, int(d)
+            if hasattr(self._eng, "register_bank"):
+                self._eng.register_bank(self)
         elif d != self._d:
             raise ValueError(f"feature dimension changed from {self._d} to {d}")
 
@@ -44,6 +46,8 @@ class NearestNeighborDistanceMetric:
         if self._bank is not None and self._eng.h:
             self._eng.lib.reid_bank_destroy(self._bank)
         self._bank = None
+        if hasattr(self._eng, "unregister_bank"):
+            self._eng.unregister_bank(self)
 
     def __del__(self):
         try:
