@@ -121,12 +121,23 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
     const int per = (nnt + p.S - 1) / p.S;
 
     int t;
-    {   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD): an XCD's blocks take consecutive (segment, row tile)
-        // pairs, row tile fastest - they sweep the same segment of y, which stays in that XCD's L2
+    {   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD): an XCD's blocks take consecutive t
         const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    const int seg = t / nmt, mtile = t - seg * nmt;
+    // t -> (row tile, segment) in 8 x 8 PATCHES: the ~64 blocks an XCD holds at a time (32 CUs x 2) then share 8 tiles of x
+    // (2 MB, re-read for every tile of the sweep - from L2 instead of the fabric) and sweep 8 segments of y, each of whose
+    // tiles 8 of them read at about the same time.  (Row tile fastest over a whole segment gave an XCD 61 different tiles of x,
+    // 15 MB against 4 MB of L2: PMC FETCH_SIZE 0.44 GB per launch for 40 MB of operands.)
+    int mtile, seg;
+    {
+        const int pr = t / (8 * p.S), rem = t - pr * 8 * p.S;
+        const int rows_p = nmt - 8 * pr < 8 ? nmt - 8 * pr : 8;
+        const int pc = rem / (rows_p * 8), rem2 = rem - pc * rows_p * 8;
+        const int si = rem2 / rows_p, mi = rem2 - si * rows_p;
+        mtile = 8 * pr + mi;
+        seg = 8 * pc + si;
+    }
     const int m_blk = mtile * BM;
     const int rows_a = p.M - m_blk < BM ? p.M - m_blk : BM;
     const int nt0 = seg * per, nt1 = nt0 + per < nnt ? nt0 + per : nnt;

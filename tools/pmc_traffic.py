@@ -23,6 +23,9 @@ elif MODE == "swin_f32":   # Swin contractions in exact fp32: dense LDS-DMA GEMM
 elif MODE == "market":     # distance matrix of the Market-size retrieval (bench.py --workload market)
     CONV = re.compile(r"gemm_f32_dma_kernel")
     LABEL = "distance-matrix GEMM of the Market-size search (gemm_f32_dma_kernel<E_DIST>)"
+elif MODE == "select":     # fused distance + selection of the Market-size search (no matrix): sample-bound pass + sweep
+    CONV = re.compile(r"dist_select_kernelILi\d+ELi\d+E")   # <metric, mode>: mode 0 = sweep with lists, 1 = sample bound, 2 = arg-min sweep
+    LABEL = "fused distance + top-k selection of the Market-size search (dist_select_kernel: bound pass + sweep)"
 elif MODE == "swin_f16":
     CONV = re.compile(r"gemm_f16_kernel")
     LABEL = "Swin Linear / conv contractions of the fp16-storage path (gemm_f16 linear builds)"
@@ -61,8 +64,8 @@ res = {
     "command": ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload swin --crops 512 --steps 1 --warmup 1 --no-cpu --single --precision %s" % MODE[5:]
                 if MODE.startswith("swin_") else
                 "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload market --steps 2 --warmup 1 --no-cpu"
-                if MODE == "market" else
-                "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu --single --precision %s (4096 crops, chunk 1024)" % MODE),
+                if MODE in ("market", "select") else
+                "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --workload embed --no-cpu --single --precision %s (4096 crops, chunk 1024)" % MODE),
     "launches": launches,
     "fetch_size_kb_raw_per_launch": fetch_kb / max(1, launches),
     "write_size_kb_per_launch": write_kb / max(1, sum(v[0] for v in write.values())),
