@@ -71,6 +71,7 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     if (ctx->copy_ev) hipEventDestroy(ctx->copy_ev);
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
     for (auto& kv : ctx->ws) hipFree(kv.second.first);
+    for (auto& kv : ctx->split_w) hipFree(kv.second);
     for (auto& kv : ctx->pinned) hipHostFree(kv.second.first);
     if (ctx->se18.blob) hipFree(ctx->se18.blob);
     if (ctx->se18.blob16) hipFree(ctx->se18.blob16);
@@ -122,8 +123,9 @@ extern "C" int reid_ctx_set_chunk(reid_ctx* ctx, int n) {
 extern "C" int reid_ctx_set_precision(reid_ctx* ctx, int mode) {
     ARG_CHECK(ctx);
     CTX_GUARD(ctx);
-    if (mode != 0 && mode != 1) {
-        reid_set_error("reid_ctx_set_precision: mode must be 0 (exact fp32 MFMA) or 1 (fp16 storage / fp32 accumulate)");
+    if (mode != 0 && mode != 1 && mode != 2) {
+        reid_set_error("reid_ctx_set_precision: mode must be 0 (exact fp32 MFMA), 1 (fp16 storage / fp32 accumulate) or "
+                       "2 (fp32-class: hi/lo-split operands on the f16 matrix pipe, fp32 storage)");
         return REID_ERR_ARG;
     }
     ctx->precision = mode;
@@ -356,6 +358,8 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         if (w.zero_page) HIP_TRY(hipFree(w.zero_page));
         if (w.ep) HIP_TRY(hipFree(w.ep));
         w = Se18Weights();
+        for (auto& kv : ctx->split_w) (void)hipFree(kv.second);   // split forms of the old blob's weights
+        ctx->split_w.clear();
     }
     HIP_TRY(hipMalloc((void**)&w.blob, n_floats * sizeof(float)));
     HIP_TRY(hipMemcpy(w.blob, blob, n_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -487,6 +491,37 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
     const double flops = 2.0 * p.M * Cout * ktrue;
     const double in_bytes = (double)n * H * W * Cin * (amode == A_STEM_U8 ? 1.0 : 4.0);
     const double bytes = in_bytes + ((double)p.M * Cout + (double)Cout * ktrue) * 4.0 + (residual ? (double)p.M * Cout * 4.0 : 0.0);
+    if (ctx->precision == 2 && amode == A_IM2COL && R == 3 && S == 3 && stride == 1 && pad == 1 && !a_scale && Cin % 64 == 0 &&
+        Cout % 64 == 0 && ctx->se18.zero_page) {
+        // "fp32-class" arithmetic on the f16 matrix pipe (Gemm16Params, SPLIT build of conv3x3_f16.hip): the fp32 activations are
+        // packed to [xh | xl'] f16, the weights were split once; three f16 products per multiply, fp32 accumulate, fp32 in / out -
+        // the layers around the convolution (IBN, SE, residual stream) are the exact-fp32 path's, untouched
+        Gemm16Params q;
+        memset(&q, 0, sizeof(q));
+        q.H = H; q.W = W; q.Cin = 3 * Cin; q.R = 3; q.S = 3; q.stride = 1; q.pad = 1;
+        q.Ho = H; q.Wo = W;
+        q.M = n * H * W; q.N = Cout; q.K = 27 * Cin; q.ldb = 27 * Cin;
+        if (conv3x3_f16_supported(q) && q.M % 128 == 0) {
+            _Float16* a16;
+            REID_TRY(ctx_ws(ctx, "split.a", (size_t)q.M * 2 * Cin * 2, (void**)&a16));
+            REID_TRY(launch_split_pack(ctx, (const float*)x, q.M, Cin, a16));
+            auto it = ctx->split_w.find(wgt);
+            if (it == ctx->split_w.end()) {
+                void* w16;
+                HIP_TRY(hipMalloc(&w16, (size_t)Cout * 27 * Cin * 2));
+                REID_TRY(launch_split_weights(ctx, wgt, Cout, 9, Cin, (_Float16*)w16));
+                it = ctx->split_w.emplace(wgt, w16).first;
+            }
+            q.A = a16;
+            q.B = (const _Float16*)it->second;
+            q.C32 = out; q.ldc = Cout;
+            q.col_scale = col_scale; q.col_shift = col_shift; q.res32 = residual; q.relu = relu; q.relu_from = relu_from;
+            q.stats = stats;
+            q.acc_scale = 1.0f / 2048.0f;
+            q.zero_page = ctx->se18.zero_page;
+            return launch_conv3x3_split(ctx, q, REID_K_CONV_GEMM, flops, bytes);
+        }
+    }
     if (amode == A_IM2COL && ctx->f32_conv && conv_f32_supported(p)) return launch_conv_f32(ctx, p, REID_K_CONV_GEMM, flops, bytes);
     return launch_gemm_f32(ctx, amode, E_CONV, p, REID_K_CONV_GEMM, flops, bytes);
 }

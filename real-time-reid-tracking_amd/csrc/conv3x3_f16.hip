@@ -65,7 +65,7 @@ __device__ __forceinline__ int c_row_natural(int wm, int a, int e, int lh) {
     else return ((wm >> 1) * 16 + (wm & 1) * 8 + a * 2 + g + 4 * (e >> 3)) * 8 + (e & 7);
 }
 
-template <int TW, int IMGS, int BN, int LW>
+template <int TW, int IMGS, int BN, int LW, bool SPLIT = false>
 __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm16Params p) {
     constexpr int TH = 256 / (IMGS * TW);            // tile rows per image
     constexpr int WP = TW + 2, HP = TH + 2;          // halo pitch / rows
@@ -139,7 +139,10 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         const int gy = y0 - 1 + hy, gx = hx - 1, gi = img0 + im;
         const bool ok = hp < NPX && gi < n_img && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         const int c = (lane & 7) ^ ((hp >> 1) & 7);
-        const f16* src = ok ? p.A + (((long long)gi * p.H + gy) * p.W + gx) * p.Cin + chunk * 64 + c * 8 : p.zero_page;
+        // SPLIT: p.Cin = 3C virtual channels over a tensor of 2C ([xh | xl']): chunks of the last third read xh again
+        const int a_cin = SPLIT ? p.Cin / 3 * 2 : p.Cin;
+        const int a_chunk = (SPLIT && chunk >= a_cin / 64) ? chunk - a_cin / 64 : chunk;
+        const f16* src = ok ? p.A + (((long long)gi * p.H + gy) * p.W + gx) * a_cin + a_chunk * 64 + c * 8 : p.zero_page;
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(halo + buf * HALO_BYTES + q * 1024), 16, 0, 0);
     };
     const int nchunk = p.Cin / 64 / SK;               // chunks this block sums: [chunk0, chunk0 + nchunk)
@@ -330,6 +333,71 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         __syncthreads();   // the flag word is about to be overwritten by the residual tile
     }
 
+    if constexpr (SPLIT) {
+        // ------------------------------------------------------------------ fp32 epilogue of the SPLIT build: BN scale (x 2^-11)
+        // and shift, fp32 residual, ReLU from column relu_from on, fp32 stores, per-128-row column sums - straight from the
+        // accumulators (a row of the MFMA tile is 32 consecutive columns: 128-byte segments).  Rows past M only occur in the
+        // second 128-row half (M % 128 == 0): their row index is clamped for the residual load and their store is skipped.
+        const int ldc = (int)p.ldc;
+        const int m_blk = mtile * 256;
+        const int m_valid = p.M - m_blk;
+        float s1[TN], s2[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * (BN / 2) + b * 32 + li;
+            const int col = n_blk + lcol;
+            const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
+            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+            const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                float r[16];
+                int rowv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    rowv[e] = c_row_natural<TW, IMGS>(wm, a, e, lh);
+                    const int rc = rowv[e] < m_valid ? rowv[e] : 0;
+                    r[e] = p.res32 ? p.res32[(long long)(m_blk + rc) * ldc + col] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[a][b][e] * cs + sh;
+                    v += r[e];
+                    v = fmaxf(v, lo);
+                    if (rowv[e] < m_valid) {
+                        t1 += v;
+                        t2 += v * v;
+                        p.C32[(long long)(m_blk + rowv[e]) * ldc + col] = v;
+                    }
+                }
+            }
+            s1[b] = t1;
+            s2[b] = t2;
+        }
+        if (p.stats) {   // per 128 natural rows: waves wm 0,1 own rows 0..127, wm 2,3 rows 128..255 in every geometry
+            float* stat_lds = (float*)lds;  // [4][BN][2]
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int lcol = wn * (BN / 2) + b * 32 + li;
+                const float t1 = s1[b] + __shfl_xor(s1[b], 32);
+                const float t2 = s2[b] + __shfl_xor(s2[b], 32);
+                if (lh == 0) {
+                    stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
+                    stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < 2 * BN; t += 512) {
+                const int half = t / BN, c = t - half * BN;
+                if (half * 128 >= m_valid) continue;
+                float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + c) * 2;
+                o[0] = stat_lds[((half * 2) * BN + c) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + c) * 2 + 0];
+                o[1] = stat_lds[((half * 2) * BN + c) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + c) * 2 + 1];
+            }
+        }
+        return;
+    }
     // ------------------------------------------------------------------ epilogue (fp32 math, f16 stores)
     const int ldc = (int)p.ldc;
     const int m_blk = mtile * 256;
@@ -442,14 +510,14 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
     }
 }
 
-template <int TW, int IMGS, int LW>
+template <int TW, int IMGS, int LW, bool SPLIT = false>
 int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
     const int nmt = (p.M + 255) / 256;
     const int threads = LW ? 768 : 512;
     // few M tiles (a tracking frame): 64-wide N tiles put twice as many blocks on the chip
     if (p.N % 128 == 0 && (long long)nmt * (p.N / 128) >= 128) {
-        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW>), dim3(nmt * (p.N / 128)), dim3(threads), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(nmt * (p.N / 128)), dim3(threads), 0, ctx->stream, p);
     } else {
         // ... and when even those leave CUs idle, split the input channels over 2 or 4 blocks per tile (the K loop is
         // latency-bound at ~0.65 us per (chunk, tap) tile, so its length is what a small launch costs)
@@ -465,7 +533,7 @@ int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
             if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, 256 * sizeof(int), ctx->stream));
             p.split_k = sk; p.splitk_ws = ws; p.splitk_cnt = cnt;
         }
-        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64, LW>), dim3(tiles * sk), dim3(threads), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64, LW, SPLIT>), dim3(tiles * sk), dim3(threads), 0, ctx->stream, p);
     }
     LAUNCH_CHECK();
     return REID_OK;
@@ -491,6 +559,75 @@ int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double fl
         if (p.W == 32) st = launch_geom<32, 1, 0>(ctx, p);
         else if (p.W == 16) st = launch_geom<16, 1, 0>(ctx, p);
         else st = launch_geom<8, 2, 0>(ctx, p);
+    }
+    prof_end(ctx);
+    return st;
+}
+
+// ---- "fp32-class" convolutions on the f16 matrix pipe (Gemm16Params: SPLIT build) ---------------------------------------------
+namespace {
+// fp32 [rows][C] -> f16 [rows][2C]: [xh | xl'], xh = f16(x), xl' = f16((x - xh) * 2^11); eight channels per thread
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ x, long long rows, int C, f16* __restrict__ out) {
+    const int c8 = C >> 3;
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= rows * c8) return;
+    const long long row = i / c8;
+    const int c = (int)(i - row * c8) * 8;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 a = *(const f32x4*)(x + row * C + c), b = *(const f32x4*)(x + row * C + c + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    half8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = (f16)v[j];
+        lo[j] = (f16)((v[j] - (float)hi[j]) * 2048.0f);
+    }
+    *(half8*)(out + row * 2 * C + c) = hi;
+    *(half8*)(out + row * 2 * C + C + c) = lo;
+}
+// fp32 [cout][taps][cin] -> f16 [cout][taps][3 cin]: [wh * 2^11 | wh | wl'] per tap (wl' = f16((w - wh) * 2^11))
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, long long total, int cin, f16* __restrict__ out) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= total) return;
+    const long long rt = i / cin;            // (cout, tap)
+    const int c = (int)(i - rt * cin);
+    const float v = w[i];
+    const f16 wh = (f16)v;
+    f16* o = out + rt * 3 * cin;
+    o[c] = (f16)((float)wh * 2048.0f);
+    o[cin + c] = wh;
+    o[2 * cin + c] = (f16)((v - (float)wh) * 2048.0f);
+}
+}  // namespace
+
+int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out) {
+    ARG_CHECK(C % 8 == 0);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)rows * C * 8.0);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((rows * (C / 8) + 255) / 256)), dim3(256), 0, ctx->stream, x, rows, C, out);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, _Float16* out) {
+    const long long total = (long long)cout * taps * cin;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w, total, cin, out);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes) {
+    ARG_CHECK(conv3x3_f16_supported(p) && p.Cin % 192 == 0 && p.zero_page && p.ldb % 8 == 0 && p.M % 128 == 0 && p.C32);
+    prof_begin(ctx, kind, flops, bytes);
+    int st;
+    if (ctx->f16_loader_waves) {
+        if (p.W == 32) st = launch_geom<32, 1, 1, true>(ctx, p);
+        else if (p.W == 16) st = launch_geom<16, 1, 1, true>(ctx, p);
+        else st = launch_geom<8, 2, 1, true>(ctx, p);
+    } else {
+        if (p.W == 32) st = launch_geom<32, 1, 0, true>(ctx, p);
+        else if (p.W == 16) st = launch_geom<16, 1, 0, true>(ctx, p);
+        else st = launch_geom<8, 2, 0, true>(ctx, p);
     }
     prof_end(ctx);
     return st;

@@ -142,6 +142,13 @@ struct Gemm16Params {
     int split_k;
     float* splitk_ws;
     int* splitk_cnt;
+    // conv3x3_f16.hip, SPLIT build ("fp32-class" arithmetic on the f16 matrix pipe, reid_ctx_set_precision(ctx, 2)):
+    // x = xh + xl with xh = f16(x), xl' = f16((x - xh) * 2^11); x.w ~= xh.wh + (xl'.wh + xh.wl') / 2^11.  A holds [xh | xl'] per
+    // pixel (2C f16 = the bytes of fp32), the weights [wh * 2^11 | wh | wl'] per tap (Cin = 3C "virtual" channels: the third
+    // third re-reads xh), so ONE fp32 accumulator collects 2^11 times the product; acc_scale = 2^-11 goes into the BN scale.
+    // Output fp32 (C32), residual fp32 (res32), ReLU from column relu_from on.
+    float acc_scale;
+    int relu_from;
 };
 
 // reciprocals for the scatter epilogues: floor(x / d) == umulhi(x, ceil(2^32 / d)) for x < 2^32 / d (rows of one pass: < 2^20)
@@ -159,6 +166,9 @@ struct reid_ctx;
 int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, double flops, double bytes);
 bool conv3x3_f16_supported(const Gemm16Params& p);   // conv3x3_f16.hip: 3x3 s1 p1 with the input halo tile kept in LDS
 int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);
+int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build, see Gemm16Params
+int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out);           // fp32 [rows][C] -> f16 [rows][2C] = [xh | xl']
+int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, _Float16* out);  // fp32 [cout][taps][cin] -> f16 [cout][taps][3 cin]
 // fp16 elementwise kernels (elementwise_f16.hip)
 int launch_prep_u8_pad_f16(reid_ctx*, const uint8_t* crops, int n, int h, int w, int hp, int wp, _Float16* out);
 int launch_prep_f32_pad_f16(reid_ctx*, const float* nhwc3, int n, int h, int w, int hp, int wp, _Float16* out);
@@ -288,6 +298,7 @@ struct reid_ctx {
     // growable device workspaces, keyed by name
     std::map<std::string, std::pair<void*, size_t>> ws;
     std::map<std::string, std::pair<void*, size_t>> pinned;   // pinned host staging buffers (ctx_pinned)
+    std::map<const void*, void*> split_w;   // precision 2: conv weights (fp32, in the blob) -> their [wh * 2^11 | wh | wl'] f16 form
     int bank_fast = 1;                    // d = 512 feature-bank cost on the register-tiled kernel (REID_BANK_FAST=0: generic kernel)
     Se18Weights se18;
     int last_n = 0;  // crops in the last embed chunk (for reid_debug_stage)
