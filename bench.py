@@ -178,7 +178,7 @@ def run_embed(job, args):
 
     def run(precision, steps, warmup):
         """Timed region per the bench contract + a profiled repeat of the same steps for the roofline object."""
-        eng.set_precision(1 if precision == "f16" else 0)
+        eng.set_precision({"f32": 0, "f16": 1, "f16x3": 2}[precision])
         elapsed = job.timed(step, steps, warmup)
         # split of one step (embed / all-gather+distmat), HIP events on the launch stream
         eng.timer_start()
@@ -199,7 +199,10 @@ def run_embed(job, args):
         conv, dgm, elt = (eng.profile_get(k) for k in (_ffi.K_CONV_GEMM, _ffi.K_DIST_GEMM, _ffi.K_ELEMENTWISE))
         eng.profile(False)
         f16 = precision == "f16"
-        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+        x3 = precision == "f16x3"
+        # f16x3: every multiply of the 3x3 stride-1 convolutions (91 % of the MACs) is three f16 matrix-core products, so the
+        # pipe's dense peak counts a third per ALGORITHMIC flop; the stride-2 / 1x1 convolutions and the stem stay on the fp32 pipe
+        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F16_MFMA_TFLOPS / 3.0 if x3 else PEAK_F32_MFMA_TFLOPS
         conv_tflops = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         return {
             "value": round(n * world * steps / elapsed, 1), "ms_per_step": round(elapsed * 1e3 / steps, 3),
@@ -209,9 +212,10 @@ def run_embed(job, args):
             "whole_net_fraction_of_hbm_roofline": round(FUSED_BYTES_PER_CROP * (0.5 if f16 else 1.0) * n / (embed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": {
                 "kernel": ("convolution kernels of the fp16 path, v_mfma_f32_32x32x16_f16: conv3x3_f16 (LDS halo, layers 2-4), conv3x3_c64_f16 (layer 1, weights in registers), stem_pool_f16 (7x7 + BN + maxpool), gemm_f16 (strided / 1x1)" if f16 else
+                           "convolution kernels of the fp32-class path: conv3x3_f16 SPLIT build (3x3 stride-1, x.w = xh.wh + (xl.wh + xh.wl) with hi/lo-split f16 operands, three v_mfma_f32_32x32x16_f16 per multiply, fp32 accumulate; peak = 2.5 PF / 3 per algorithmic flop) + conv_f32_dma (stride-2, 1x1) + the 7x7 stem on the fp32 pipe" if x3 else
                            "convolution kernels of the fp32 path, v_mfma_f32_32x32x2_f32 (exact fp32): conv_f32_dma_kernel (implicit GEMM, LDS-DMA staging, all 3x3 / 1x1 convs) + the 7x7 stem"),
                 "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile("conv_f16" if f16 else "conv_f32"),
+                "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile("conv_f16" if f16 else "conv_f16x3" if x3 else "conv_f32"),
                 "launches": conv["launches"], "avg_launch_us": round(conv["ms"] * 1e3 / max(1, conv["launches"]), 2),
                 "algorithmic_gflop_per_launch": round(conv["flops"] / max(1, conv["launches"]) / 1e9, 3),
                 "algorithmic_bytes_per_launch": round(conv["bytes"] / max(1, conv["launches"]), 1),
@@ -227,21 +231,26 @@ def run_embed(job, args):
         }
 
     main_res = run(args.precision, args.steps, args.warmup)
-    other = "f32" if args.precision == "f16" else "f16"
-    other_res = run(other, max(1, min(3, args.steps)), 1) if not args.single else None
+    others = {} if args.single else {o: run(o, max(1, min(3, args.steps)), 1) for o in ("f32", "f16x3", "f16") if o != args.precision}
 
-    # parity inside the bench: the two precisions agree on the embeddings of this rank (cosine)
+    # parity inside the bench: the arithmetic modes agree on the embeddings of this rank (cosine against exact fp32)
     e = {}
-    for mode, name in ((1, "f16"), (0, "f32")):
+    for mode, name in ((1, "f16"), (2, "f16x3"), (0, "f32")):
         eng.set_precision(mode)
         eng.embed_u8_dev(crops.ptr, 256, emb_local.ptr)
         e[name] = emb_local.numpy()[:256]
     cos = (e["f16"] * e["f32"]).sum(1) / np.linalg.norm(e["f16"], axis=1) / np.linalg.norm(e["f32"], axis=1)
     cos_err = float((1 - cos).max())
+    cos3 = (e["f16x3"] * e["f32"]).sum(1) / np.linalg.norm(e["f16x3"], axis=1) / np.linalg.norm(e["f32"], axis=1)
+    x3_err = {"max_1_minus_cos": float((1 - cos3).max()), "max_rel_err": float(np.abs(e["f16x3"] - e["f32"]).max() / np.abs(e["f32"]).max())}
 
     if rank != 0:
         return None
     f16 = args.precision == "f16"
+    arith = {"f32": "exact fp32 (v_mfma_f32_32x32x2_f32), the reference's arithmetic",
+             "f16": "fp16 storage, fp32 accumulate (north_star tolerance 1e-3 cosine; measured below)",
+             "f16x3": "fp32-class: fp32 storage; 3x3 stride-1 convolutions as three f16 matrix-core products per multiply on hi/lo-split "
+                      "operands, fp32 accumulate (held to the exact-fp32 mode's parity thresholds in tests/test_gpu_parity.py)"}
     out = {
         "metric": "crops/sec embedded + NxM distmat ms, ResNet18-SE 128x256",
         "value": main_res["value"],
@@ -253,20 +262,21 @@ def run_embed(job, args):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f16" if f16 else "f32",
+        "dtype": args.precision,
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: ResNet18-SE embed %d distinct uint8 crops (128x256) per GPU + %dx%d L2 distmat"
                                % (n, n, n * world),
                    "crops_per_gpu": n, "embed_dim": d, "chunk": args.chunk,
-                   "arithmetic": ("fp16 storage, fp32 accumulate (north_star tolerance 1e-3 cosine; measured below)" if f16
-                                  else "exact fp32 (v_mfma_f32_32x32x2_f32), the reference's arithmetic"),
+                   "arithmetic": arith[args.precision],
                    "sharding": ("crops sharded by rank, one RCCL all-gather of [N,512] embeddings through the C ABI (reid_allgather_dev)"
                                 if world > 1 else "single GPU")},
         "f16_vs_f32_max_cosine_err": cos_err,
+        "f16x3_vs_f32": x3_err,
     }
     out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
-    if other_res is not None:
-        out[other + "_path"] = other_res
+    for o, r in others.items():
+        r["arithmetic"] = arith[o]
+        out[o + "_path"] = r
     if not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_embed(sd)
     return out
@@ -369,7 +379,7 @@ def run_tracking(job, args):
     eng, comm, world, rank = job.eng, job.comm, job.world, job.rank
     sd = synth.seres18_state_dict(0, gem_p=3.0)
     eng.load_seres18(*weights.pack_seres18(sd)[:2])
-    eng.set_precision(1 if args.precision == "f16" else 0)
+    eng.set_precision({"f32": 0, "f16": 1, "f16x3": 2}[args.precision])
     frames = args.frames
     rng = np.random.default_rng(3)
     counts = np.clip(rng.poisson(30, frames), 1, 80)
@@ -507,7 +517,7 @@ def run_tracking(job, args):
         elc = time.perf_counter() - t0c
         cpu = {"value": round(fc / elc, 2), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "%d frames, %d crops (%.1f s): oracle preprocess + oracle/seres18.py + numpy bank cost + DIoU" % (fc, cc, elc)}
-    peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16" else PEAK_F32_MFMA_TFLOPS
+    peak = {"f16": PEAK_F16_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0, "f32": PEAK_F32_MFMA_TFLOPS}[args.precision]
     conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
     roof = {"kernel": "convolution kernels of a frame's forward (~%d crops per rank: launches of at most one wave of blocks, latency-bound K loops)"
                       % round(ncrops / frames / world),
@@ -522,7 +532,7 @@ def run_tracking(job, args):
         blob, manifest = weights.pack_seres18(sd)[:2]
         cams = []
         for c in range(args.cameras):
-            cs = CameraStream(blob, manifest, 1 if args.precision == "f16" else 0)
+            cs = CameraStream(blob, manifest, {"f32": 0, "f16": 1, "f16x3": 2}[args.precision])
             cs.metric.partial_fit(rng.normal(size=(40 * 100, 512)).astype(np.float32), np.repeat(tracks, 100), tracks)
             cams.append(cs)
 
@@ -628,7 +638,7 @@ def run_market(job, args):
 
 
 SUB_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config", "roofline", "cpu_baseline",
-            "f16_path", "f32_path", "other_kernels", "embed_ms", "distmat_ms", "distmat_shard_ms", "search_ms", "search_tflops",
+            "f16_path", "f32_path", "f16x3_path", "f16x3_vs_f32", "other_kernels", "embed_ms", "distmat_ms", "distmat_shard_ms", "search_ms", "search_tflops",
             "crops_per_s", "ms_per_frame_median", "ms_per_frame_p95", "allgather_us_median", "camera_streams", "rank1_top20",
             "whole_net_tflops", "f16_vs_f32_max_cosine_err")
 
@@ -680,12 +690,13 @@ def run_all(job, args):
 
     def tracking_both(job_, a):
         r32 = run_tracking(job_, a)
-        a16 = copy.copy(a)
-        a16.precision, a16.no_cpu = "f16", True
-        r16 = run_tracking(job_, a16)
-        if r32 is not None:
-            r32["f16_path"] = {k: r16[k] for k in ("value", "ms_per_step", "crops_per_s", "ms_per_frame_median", "ms_per_frame_p95",
-                                                   "roofline", "camera_streams") if k in r16}
+        for prec in ("f16x3", "f16"):
+            a2 = copy.copy(a)
+            a2.precision, a2.no_cpu = prec, True
+            r2 = run_tracking(job_, a2)
+            if r32 is not None:
+                r32[prec + "_path"] = {k: r2[k] for k in ("value", "ms_per_step", "crops_per_s", "ms_per_frame_median", "ms_per_frame_p95",
+                                                           "roofline", "camera_streams") if k in r2}
         return r32
 
     try:
@@ -717,12 +728,14 @@ def main():
     ap.add_argument("--cameras", type=int, default=2, help="--workload tracking, one GPU: also run this many concurrent camera streams")
     ap.add_argument("--no-pipeline", action="store_true", help="--workload tracking: one synchronous call per operation (A/B)")
     ap.add_argument("--single", action="store_true", help="measure only --precision (skip the other arithmetic)")
-    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("REID_PRECISION", "f32"),
+    ap.add_argument("--precision", choices=["f32", "f16", "f16x3"], default=os.environ.get("REID_PRECISION", "f32"),
                     help="arithmetic of the headline: f32 = the reference's (exact fp32 MFMA, default); f16 = fp16 storage / fp32 "
                          "accumulate (inside north_star's 1e-3 cosine tolerance, reported as the labelled side run by default)")
     args = ap.parse_args()
     if args.workload == "batch256":
         args.crops = 256
+    if args.workload == "swin" and args.precision == "f16x3":
+        raise SystemExit("--precision f16x3 applies to the ResNet18-SE convolutions (embed / batch256 / tracking)")
 
     job = Job(args)
     try:

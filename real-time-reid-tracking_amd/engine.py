@@ -102,6 +102,8 @@ class Engine:
         check(self.lib.reid_ctx_set_chunk(self.h, int(n)))
 
     def set_precision(self, mode):
+        """0 exact fp32 (the reference's arithmetic), 1 fp16 storage / fp32 accumulate, 2 "fp32-class": fp32 storage, the 3x3
+        stride-1 convolutions as three f16 matrix-core products per multiply on hi/lo-split operands (fp32 accumulate)."""
         check(self.lib.reid_ctx_set_precision(self.h, int(mode)))
 
     def malloc(self, nbytes):

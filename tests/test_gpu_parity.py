@@ -66,9 +66,20 @@ def test_conv2d_nhwc(eng, cfg):
 
 
 # ----------------------------------------------------------------------------- embedding
+@pytest.mark.parametrize("precision", [0, 2])
 @pytest.mark.parametrize("tag,crops_fn", [("seed0", synth.crops_u8), ("smooth1", synth.smooth_crops_u8)])
-def test_seres18_embed_matches_reference_fixture(eng, golden_dir, tag, crops_fn):
-    """Eval-mode semantics.  Tolerance: north_star 1e-3 cosine; the fp32 MFMA path is held to 1e-5."""
+def test_seres18_embed_matches_reference_fixture(eng, golden_dir, tag, crops_fn, precision):
+    """Eval-mode semantics.  Tolerance: north_star 1e-3 cosine; the fp32 MFMA path is held to 1e-5 - and so is
+    precision 2, the "fp32-class" mode (3x3 stride-1 convolutions as three f16 products per multiply with hi/lo-split operands
+    and fp32 accumulation on the f16 matrix pipe; everything else is the exact-fp32 path): same thresholds, stage by stage."""
+    eng.set_precision(precision)
+    try:
+        _seres18_fixture_check(eng, golden_dir, tag, crops_fn)
+    finally:
+        eng.set_precision(0)
+
+
+def _seres18_fixture_check(eng, golden_dir, tag, crops_fn):
     g = np.load(os.path.join(golden_dir, "seres18_%s.npz" % tag))
     seed, n = int(g["seed"]), int(g["n"])
     sd = synth.seres18_state_dict(seed)
@@ -806,7 +817,7 @@ def test_tta_descriptor_matches_oracle(eng_w0):
 
 
 # ----------------------------------------------------------------------------- BASELINE configs[1] at full size
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 def test_full_size_config1_properties(eng_w0, precision):
     """4096 crops + 4096 x 4096 L2 matrix (BASELINE configs[1]) through size-independent properties: the batch holds 256
     distinct crops, each 16 times, in shuffled order.  Crops are independent in eval mode (per-sample InstanceNorm / SE), so
@@ -831,7 +842,7 @@ def test_full_size_config1_properties(eng_w0, precision):
         first = np.asarray([np.flatnonzero(ids == c)[0] for c in range(256)])
         assert np.array_equal(emb, emb[first][ids])                     # (a) position invariance, bit-exact
         rel = np.abs(emb_small - emb[:1000]).max() / np.abs(emb).max()
-        assert rel < (2e-3 if precision else 1e-4)                      # (a) pass-size invariance, to rounding
+        assert rel < (2e-3 if precision == 1 else 1e-4)                 # (a) pass-size invariance, to rounding
         dist = eng.distmat(emb, emb, _ffi.METRIC_L2)
         scale = float(np.median(dist))
         assert np.abs(dist - dist.T).max() <= 1e-4 * scale
@@ -845,7 +856,7 @@ def test_full_size_config1_properties(eng_w0, precision):
         sample = first[:6]
         want = seres18.embed_u8(sd, crops[sample])                      # (c)
         cos = (emb[sample] * want).sum(1) / np.linalg.norm(emb[sample], axis=1) / np.linalg.norm(want, axis=1)
-        assert (1 - cos).max() < (1e-4 if precision else 1e-5)
+        assert (1 - cos).max() < (1e-4 if precision == 1 else 1e-5)
     finally:
         eng.set_chunk(128)
         eng.set_precision(0)
@@ -871,7 +882,7 @@ def test_f16_path_small_and_odd_batches(eng_w0, n):
 
 
 # ----------------------------------------------------------------------------- reference-held vectors at BASELINE sizes
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("tag,crops_fn,seed", [("rand0", synth.crops_u8, 0), ("smooth5", synth.smooth_crops_u8, 5)])
 def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, crops_fn, seed):
     """BASELINE configs[0]: 256 crops -> emb[256,512] -> (1 - cos) / 2 matrix -> row arg-min, against vectors the REFERENCE's own
@@ -888,19 +899,22 @@ def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, c
     finally:
         eng.set_precision(0)
     cos = (emb * ref).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(ref, axis=1)
-    assert (1 - cos).max() < (1e-4 if precision else 1e-5)                # north_star allows 1e-3
+    f16s = precision == 1                                                 # precision 2 (fp32-class) is held to the fp32 thresholds
+    assert (1 - cos).max() < (1e-4 if f16s else 1e-5)                     # north_star allows 1e-3
     dist = eng.distmat(emb, emb, _ffi.METRIC_COS_HALF)
-    np.testing.assert_allclose(dist, g[tag + "_cosdist"], atol=(2e-4 if precision else 2e-6))
+    np.testing.assert_allclose(dist, g[tag + "_cosdist"], atol=(2e-4 if f16s else 2e-6))
     d = dist.copy()
     np.fill_diagonal(d, np.inf)
     flips = np.flatnonzero(d.argmin(1) != g[tag + "_argmin"])
-    noise = 2e-4 if precision else 2e-6                                   # twice the distance error asserted above
+    noise = 2e-4 if f16s else 2e-6                                        # twice the distance error asserted above
     decided = int((gap >= noise).sum())
     print("config1 %s precision %d: %d of 256 rows decided (reference top-2 gap >= %.0e), %d arg-mins differ, largest gap among "
           "them %.2e" % (tag, precision, decided, noise, len(flips), gap[flips].max() if len(flips) else 0.0))
     assert (gap[flips] < noise).all(), (flips, gap[flips])
     if tag == "smooth5":
-        assert decided >= (150 if precision else 250)                     # realistic crops: (nearly) every row is decided
+        assert decided >= (150 if f16s else 250)                          # realistic crops: (nearly) every row is decided
+        if not f16s:
+            assert len(flips) == 0                                        # ... and the fp32 / fp32-class modes agree on all of them
 
 
 @pytest.mark.parametrize("tag,sigma", [("s03", 0.3), ("s30", 3.0)])
@@ -1308,10 +1322,20 @@ def test_swin_window_attention_mfma_equals_valu_kernel(eng):
 
 
 # ----------------------------------------------------------------------------- sibling backbones
+@pytest.mark.parametrize("precision", [0, 2])
 @pytest.mark.parametrize("tag,name,sd_fn", [("ca", "cares18_ibn", synth.cares18_state_dict), ("ema", "emares18_ibn", synth.emares18_state_dict)])
-def test_sibling_backbones_match_reference_fixture(eng, golden_dir, tag, name, sd_fn):
+def test_sibling_backbones_match_reference_fixture(eng, golden_dir, tag, name, sd_fn, precision):
     """CARes18_IBN (TripletAttention blocks) and EMARes18_IBN (EMA blocks) on the ResNet18-IBN conv kernels, against the embeddings,
-    logits and per-block outputs the REFERENCE's own classes produced (tests/golden/siblings.npz)."""
+    logits and per-block outputs the REFERENCE's own classes produced (tests/golden/siblings.npz); precision 2 = the same with the
+    3x3 convolutions in fp32-class arithmetic on the f16 matrix pipe, same thresholds."""
+    eng.set_precision(precision)
+    try:
+        _sibling_check(eng, golden_dir, tag, name, sd_fn)
+    finally:
+        eng.set_precision(0)
+
+
+def _sibling_check(eng, golden_dir, tag, name, sd_fn):
     from reid_amd.models import build_model
     g = np.load(os.path.join(golden_dir, "siblings.npz"))
     model = build_model(name, num_classes=751, loss="triplet", pretrained=False, use_gpu=True)
@@ -1557,3 +1581,27 @@ def test_fused_select_long_sweeps_and_adversarial_order(eng, order):
     idx, val = eng.argmin_rows(xq, xb, _ffi.METRIC_L2)
     fl2 = eng.distmat(xq, xb, _ffi.METRIC_L2)
     assert np.array_equal(idx, fl2.argmin(1)) and np.array_equal(val, fl2.min(1))
+
+
+# ----------------------------------------------------------------------------- precision 2 at tracking sizes
+@pytest.mark.parametrize("n", [1, 3, 7, 30, 33])
+def test_fp32_class_mode_small_and_odd_batches(eng_w0, n):
+    """precision 2 on batches that leave tiles ragged and take the split-K form of the halo kernel (a tracking frame): against
+    the exact-fp32 mode at the fp32 thresholds, and the same crops inside a larger batch."""
+    eng, sd = eng_w0
+    crops = synth.smooth_crops_u8(n, 60 + n)
+    ref = eng.embed_u8(crops)
+    eng.set_precision(2)
+    try:
+        got = eng.embed_u8(crops)
+        again = eng.embed_u8(np.concatenate([crops, crops[::-1]]))
+        ragged = eng.embed_ragged_u8([c[: 200 + 5 * i, : 100 + 3 * i] for i, c in enumerate(crops)])
+    finally:
+        eng.set_precision(0)
+    ragged_ref = eng.embed_ragged_u8([c[: 200 + 5 * i, : 100 + 3 * i] for i, c in enumerate(crops)])
+    cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (1 - cos).max() < 1e-5
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-5 * scale
+    assert np.abs(again[:n] - got).max() <= 2e-5 * scale and np.abs(again[n:][::-1] - got).max() <= 2e-5 * scale
+    assert np.abs(ragged - ragged_ref).max() <= 2e-5 * np.abs(ragged_ref).max()
