@@ -45,6 +45,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_SWIN_FOLD")) c->swin_fold = atoi(e);
     if (const char* e = getenv("REID_SWIN_STOP")) c->swin_stop = atoi(e);
     if (const char* e = getenv("REID_SELECT_TWO_PASS")) c->select_two_pass = atoi(e);
+    if (const char* e = getenv("REID_SPLIT_TERMS")) c->split_terms = atoi(e) == 4 ? 4 : 3;
     if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
     if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
@@ -491,25 +492,28 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
     const double flops = 2.0 * p.M * Cout * ktrue;
     const double in_bytes = (double)n * H * W * Cin * (amode == A_STEM_U8 ? 1.0 : 4.0);
     const double bytes = in_bytes + ((double)p.M * Cout + (double)Cout * ktrue) * 4.0 + (residual ? (double)p.M * Cout * 4.0 : 0.0);
-    if (ctx->precision == 2 && amode == A_IM2COL && R == 3 && S == 3 && stride == 1 && pad == 1 && !a_scale && Cin % 64 == 0 &&
-        Cout % 64 == 0 && ctx->se18.zero_page) {
-        // "fp32-class" arithmetic on the f16 matrix pipe (Gemm16Params, SPLIT build of conv3x3_f16.hip): the fp32 activations are
-        // packed to [xh | xl'] f16, the weights were split once; three f16 products per multiply, fp32 accumulate, fp32 in / out -
-        // the layers around the convolution (IBN, SE, residual stream) are the exact-fp32 path's, untouched
+    if (ctx->precision == 2 && amode == A_IM2COL && !a_scale && Cin % 64 == 0 && Cout % 64 == 0 && ctx->se18.zero_page) {
+        // "fp32-class" arithmetic on the f16 matrix pipe (Gemm16Params, SPLIT builds of conv3x3_f16.hip / gemm_f16.hip): the fp32
+        // activations are packed to [xh | xl'] f16, the weights were split once; three f16 products per multiply, fp32 accumulate,
+        // fp32 in / out - the layers around the convolution (IBN, SE, residual stream) are the exact-fp32 path's, untouched
         Gemm16Params q;
         memset(&q, 0, sizeof(q));
-        q.H = H; q.W = W; q.Cin = 3 * Cin; q.R = 3; q.S = 3; q.stride = 1; q.pad = 1;
-        q.Ho = H; q.Wo = W;
-        q.M = n * H * W; q.N = Cout; q.K = 27 * Cin; q.ldb = 27 * Cin;
-        if (conv3x3_f16_supported(q) && q.M % 128 == 0) {
+        const int T = ctx->split_terms;
+        q.split_terms = T;
+        q.H = H; q.W = W; q.Cin = T * Cin; q.R = R; q.S = S; q.stride = stride; q.pad = pad;
+        q.Ho = p.Ho; q.Wo = p.Wo;
+        q.M = p.M; q.N = Cout; q.K = R * S * T * Cin; q.ldb = q.K;
+        const bool halo = R == 3 && S == 3 && stride == 1 && pad == 1 && conv3x3_f16_supported(q);
+        if (q.M % 128 == 0 && (halo || Cout % 128 == 0)) {
             _Float16* a16;
-            REID_TRY(ctx_ws(ctx, "split.a", (size_t)q.M * 2 * Cin * 2, (void**)&a16));
-            REID_TRY(launch_split_pack(ctx, (const float*)x, q.M, Cin, a16));
+            const long long rows_in = (long long)n * H * W;
+            REID_TRY(ctx_ws(ctx, "split.a", (size_t)rows_in * 2 * Cin * 2, (void**)&a16));
+            REID_TRY(launch_split_pack(ctx, (const float*)x, rows_in, Cin, a16));
             auto it = ctx->split_w.find(wgt);
             if (it == ctx->split_w.end()) {
                 void* w16;
-                HIP_TRY(hipMalloc(&w16, (size_t)Cout * 27 * Cin * 2));
-                REID_TRY(launch_split_weights(ctx, wgt, Cout, 9, Cin, (_Float16*)w16));
+                HIP_TRY(hipMalloc(&w16, (size_t)Cout * q.K * 2));
+                REID_TRY(launch_split_weights(ctx, wgt, Cout, R * S, Cin, T, (_Float16*)w16));
                 it = ctx->split_w.emplace(wgt, w16).first;
             }
             q.A = a16;
@@ -519,7 +523,8 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
             q.stats = stats;
             q.acc_scale = 1.0f / 2048.0f;
             q.zero_page = ctx->se18.zero_page;
-            return launch_conv3x3_split(ctx, q, REID_K_CONV_GEMM, flops, bytes);
+            return halo ? launch_conv3x3_split(ctx, q, REID_K_CONV_GEMM, flops, bytes)
+                        : launch_gemm_f16_split(ctx, q, REID_K_CONV_GEMM, flops, bytes);
         }
     }
     if (amode == A_IM2COL && ctx->f32_conv && conv_f32_supported(p)) return launch_conv_f32(ctx, p, REID_K_CONV_GEMM, flops, bytes);

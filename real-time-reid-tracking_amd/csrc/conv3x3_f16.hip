@@ -140,8 +140,9 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         const bool ok = hp < NPX && gi < n_img && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         const int c = (lane & 7) ^ ((hp >> 1) & 7);
         // SPLIT: p.Cin = 3C virtual channels over a tensor of 2C ([xh | xl']): chunks of the last third read xh again
-        const int a_cin = SPLIT ? p.Cin / 3 * 2 : p.Cin;
-        const int a_chunk = (SPLIT && chunk >= a_cin / 64) ? chunk - a_cin / 64 : chunk;
+        // (split_terms = 4 adds the xl.wl product: four thirds -> [xh | xl' | xh | xl'] against [wh 2^11 | wh | wl' | wl])
+        const int a_cin = SPLIT ? p.Cin / p.split_terms * 2 : p.Cin;
+        const int a_chunk = SPLIT ? chunk % (a_cin / 64) : chunk;
         const f16* src = ok ? p.A + (((long long)gi * p.H + gy) * p.W + gx) * a_cin + a_chunk * 64 + c * 8 : p.zero_page;
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(halo + buf * HALO_BYTES + q * 1024), 16, 0, 0);
     };
@@ -586,17 +587,19 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
     *(half8*)(out + row * 2 * C + C + c) = lo;
 }
 // fp32 [cout][taps][cin] -> f16 [cout][taps][3 cin]: [wh * 2^11 | wh | wl'] per tap (wl' = f16((w - wh) * 2^11))
-__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, long long total, int cin, f16* __restrict__ out) {
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, long long total, int cin, int terms,
+                                                            f16* __restrict__ out) {
     const long long i = blockIdx.x * 256LL + threadIdx.x;
     if (i >= total) return;
     const long long rt = i / cin;            // (cout, tap)
     const int c = (int)(i - rt * cin);
     const float v = w[i];
     const f16 wh = (f16)v;
-    f16* o = out + rt * 3 * cin;
+    f16* o = out + rt * terms * cin;
     o[c] = (f16)((float)wh * 2048.0f);
     o[cin + c] = wh;
     o[2 * cin + c] = (f16)((v - (float)wh) * 2048.0f);
+    if (terms == 4) o[3 * cin + c] = (f16)(v - (float)wh);   // xl'.wl / 2^11 on the accumulator's scale: the unscaled low part
 }
 }  // namespace
 
@@ -609,15 +612,16 @@ int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Flo
     return REID_OK;
 }
 
-int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, _Float16* out) {
+int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, int terms, _Float16* out) {
     const long long total = (long long)cout * taps * cin;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w, total, cin, out);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w, total, cin, terms, out);
     LAUNCH_CHECK();
     return REID_OK;
 }
 
 int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes) {
-    ARG_CHECK(conv3x3_f16_supported(p) && p.Cin % 192 == 0 && p.zero_page && p.ldb % 8 == 0 && p.M % 128 == 0 && p.C32);
+    ARG_CHECK(conv3x3_f16_supported(p) && (p.split_terms == 3 || p.split_terms == 4) && p.Cin % (64 * p.split_terms) == 0 && p.zero_page &&
+              p.ldb % 8 == 0 && p.M % 128 == 0 && p.C32);
     prof_begin(ctx, kind, flops, bytes);
     int st;
     if (ctx->f16_loader_waves) {

@@ -58,7 +58,9 @@ __device__ __forceinline__ float gelu_f16_storage(float v) {
 // LIN: the linear-layer epilogue (Swin) instead of the convolution epilogue - a template parameter, not a run-time branch:
 // carrying both epilogues cost the 256-wide conv instantiations 66 more spilled VGPRs (72 -> 214 us per launch)
 // (launch bound = waves per SIMD: the linear builds up to 128 columns must stay within 128 VGPRs so that TWO blocks share a CU)
-template <int AMODE, int BN, int BK, int NST, int STAG, bool LIN = false>
+// SPLIT: the "fp32-class" form (Gemm16Params: acc_scale / split_terms; conv3x3_f16.hip has the 3x3 stride-1 sibling): im2col over
+// split_terms x C virtual channels of a [xh | xl'] tensor, fp32 epilogue (BN, fp32 residual, ReLU from a column on, column sums)
+template <int AMODE, int BN, int BK, int NST, int STAG, bool LIN = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kernel(const Gemm16Params p_in) {
     constexpr int BM = 256;
     constexpr int WM = BN == 256 ? 2 : 4;         // waves along M
@@ -156,11 +158,16 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
             // K order (tap, channel); Cin % BK == 0.  (A channel-chunk-major order that lets the nine taps re-read the same
             // lines back to back was measured: no change.)
             const int tap = k0 / p.Cin;
-            const int c0 = k0 - tap * p.Cin;
+            int c0 = k0 - tap * p.Cin;
+            int a_cin = p.Cin;
+            if constexpr (SPLIT) {   // p.Cin virtual channels over a tensor of 2C: [xh | xl' | xh (| xl')]
+                a_cin = p.Cin / p.split_terms * 2;
+                c0 = c0 % a_cin;
+            }
             const int r = tap / p.S, s = tap - r * p.S;
             const int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
             const bool ok = a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const f16* src = ok ? p.A + (((long long)a_img[j] * p.H + iy) * p.W + ix) * p.Cin + c0 + a_chunk[j] * 8 : p.zero_page;
+            const f16* src = ok ? p.A + (((long long)a_img[j] * p.H + iy) * p.W + ix) * a_cin + c0 + a_chunk[j] * 8 : p.zero_page;
             __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
         } else {  // A16_STEM: zero-padded NHWC4 image, k = r*32 + s*4 + c; a 16-B chunk = one pixel pair of one kernel row
             const int kq = kt * CH + a_chunk[j];   // chunk index along K: kernel row = kq / 4, pixel pair = kq % 4
@@ -313,6 +320,70 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
     const int row0 = wm * WTM + 4 * lh;
     const int m_valid = p.M - m_blk;  // rows of this tile that exist (>= 256 except for a ragged last tile)
 
+    if constexpr (SPLIT) {   // fp32 epilogue straight from the accumulators (see conv3x3_f16.hip, SPLIT build)
+        float s1[TN], s2[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = wn * WTN + b * 32 + li;
+            const int col = n_blk + lcol;
+            const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
+            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+            const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                float r[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
+                    const int rc = rl < m_valid ? rl : 0;
+                    r[e] = p.res32 ? p.res32[(long long)(m_blk + rc) * ldc + col] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = row0 + a * 32 + (e & 3) + 8 * (e >> 2);
+                    float v = acc[a][b][e] * cs + sh;
+                    v += r[e];
+                    v = fmaxf(v, lo);
+                    if (rl < m_valid) {
+                        t1 += v;
+                        t2 += v * v;
+                        p.C32[(long long)(m_blk + rl) * ldc + col] = v;
+                    }
+                }
+            }
+            s1[b] = t1;
+            s2[b] = t2;
+        }
+        if (p.stats) {   // per 128-row tile: the block covers two of them
+            float* stat_lds = (float*)lds;  // [WM][BN][2]
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int lcol = wn * WTN + b * 32 + li;
+                const float t1 = s1[b] + __shfl_xor(s1[b], 32);
+                const float t2 = s2[b] + __shfl_xor(s2[b], 32);
+                if (lh == 0) {
+                    stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
+                    stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < 2 * BN; t += 512) {
+                const int half = t / BN, c = t - half * BN;
+                if (half * 128 >= m_valid) continue;
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM / 2; ++w) {
+                    t1 += stat_lds[((half * (WM / 2) + w) * BN + c) * 2 + 0];
+                    t2 += stat_lds[((half * (WM / 2) + w) * BN + c) * 2 + 1];
+                }
+                float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + c) * 2;
+                o[0] = t1;
+                o[1] = t2;
+            }
+        }
+        return;
+    }
     if constexpr (LIN) {   // linear layers (Swin): bias, erf-GELU, fp32 residual stream, fp32 or f16 output, ragged M and N
 #if defined(__HIP_DEVICE_COMPILE__)
         // Swin's K loops are 3-24 tiles long: the epilogue decides these launches.  Its two hot forms carry no per-element
@@ -640,6 +711,18 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
 }
 
 }  // namespace
+
+// strided 3x3 and 1x1 convolutions of the "fp32-class" mode: one build (128-wide tile, BK 32, three stages: two blocks per CU)
+int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes) {
+    ARG_CHECK(p.M > 0 && p.M % 128 == 0 && p.N % 128 == 0 && p.K % 32 == 0 && p.ldb % 8 == 0 && p.C32 && p.zero_page &&
+              (p.split_terms == 3 || p.split_terms == 4) && p.Cin % (64 * p.split_terms) == 0 && p.K == p.R * p.S * p.Cin);
+    prof_begin(ctx, kind, flops, bytes);
+    hipLaunchKernelGGL((gemm_f16_kernel<A16_IM2COL, 128, 32, 3, 0, false, true>), dim3(((p.M + 255) / 256) * (p.N / 128)), dim3(512), 0,
+                       ctx->stream, p);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
 
 int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, double flops, double bytes) {
     ARG_CHECK(p.M > 0 && (p.lin || p.M % 128 == 0) && p.N % 64 == 0 && p.K % 32 == 0 && p.ldb % 8 == 0);

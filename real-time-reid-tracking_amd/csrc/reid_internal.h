@@ -149,6 +149,7 @@ struct Gemm16Params {
     // Output fp32 (C32), residual fp32 (res32), ReLU from column relu_from on.
     float acc_scale;
     int relu_from;
+    int split_terms;            // 3 (default) or 4 (adds the xl.wl product)
 };
 
 // reciprocals for the scatter epilogues: floor(x / d) == umulhi(x, ceil(2^32 / d)) for x < 2^32 / d (rows of one pass: < 2^20)
@@ -167,8 +168,9 @@ int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, d
 bool conv3x3_f16_supported(const Gemm16Params& p);   // conv3x3_f16.hip: 3x3 s1 p1 with the input halo tile kept in LDS
 int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);
 int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build, see Gemm16Params
+int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build of gemm_f16 (im2col: strided / 1x1)
 int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out);           // fp32 [rows][C] -> f16 [rows][2C] = [xh | xl']
-int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, _Float16* out);  // fp32 [cout][taps][cin] -> f16 [cout][taps][3 cin]
+int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, int terms, _Float16* out);  // fp32 [cout][taps][cin] -> f16 [cout][taps][terms * cin]
 // fp16 elementwise kernels (elementwise_f16.hip)
 int launch_prep_u8_pad_f16(reid_ctx*, const uint8_t* crops, int n, int h, int w, int hp, int wp, _Float16* out);
 int launch_prep_f32_pad_f16(reid_ctx*, const float* nhwc3, int n, int h, int w, int hp, int wp, _Float16* out);
@@ -316,6 +318,7 @@ struct reid_ctx {
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
     int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
     int f32_stem_pool = 1;   // fp32 path: MaxPool(3,2,1) on the stem kernel's accumulators (REID_F32_STEMPOOL=0: separate kernel)
+    int split_terms = 3;     // precision 2: f16 products per multiply (REID_SPLIT_TERMS=4 adds the low x low product)
     int select_two_pass = 0; // REID_SELECT_TWO_PASS=1: arg-min / k-NN through the full distance matrix (A/B against dist_select.hip)
     int swin_stop = -1;      // diagnostics (REID_SWIN_STOP = block * 10 + phase): skip the rest of the Swin blocks after that point
     int swin_fold = 1;       // Swin, fp16-storage mode: to_out and post_proj folded into one Linear (REID_SWIN_FOLD=0: two launches)

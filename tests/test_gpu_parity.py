@@ -913,8 +913,10 @@ def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, c
     assert (gap[flips] < noise).all(), (flips, gap[flips])
     if tag == "smooth5":
         assert decided >= (150 if f16s else 250)                          # realistic crops: (nearly) every row is decided
-        if not f16s:
-            assert len(flips) == 0                                        # ... and the fp32 / fp32-class modes agree on all of them
+    if not f16s:
+        # the bar for a headline arithmetic (round-2 verdict): the exact-fp32 and the fp32-class mode reproduce the reference's
+        # arg-min on ALL 256 rows of BOTH sets (the kernels are deterministic, so this holds on every MI355X)
+        assert len(flips) == 0, (flips, gap[flips])
 
 
 @pytest.mark.parametrize("tag,sigma", [("s03", 0.3), ("s30", 3.0)])
