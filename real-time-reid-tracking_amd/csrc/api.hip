@@ -474,7 +474,7 @@ static const int IMG_H = 256, IMG_W = 128;
 int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
                      int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
                      const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats,
-                     float* out, int relu_from) {
+                     float* out, int relu_from, const _Float16* x_packed) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x;
@@ -504,11 +504,18 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
         q.Ho = p.Ho; q.Wo = p.Wo;
         q.M = p.M; q.N = Cout; q.K = R * S * T * Cin; q.ldb = q.K;
         const bool halo = R == 3 && S == 3 && stride == 1 && pad == 1 && conv3x3_f16_supported(q);
-        if (q.M % 128 == 0 && (halo || Cout % 128 == 0)) {
-            _Float16* a16;
-            const long long rows_in = (long long)n * H * W;
-            REID_TRY(ctx_ws(ctx, "split.a", (size_t)rows_in * 2 * Cin * 2, (void**)&a16));
-            REID_TRY(launch_split_pack(ctx, (const float*)x, rows_in, Cin, a16));
+        // strided / 1x1 convolutions of a tracking-sized batch: too few 128-wide tiles for the SPLIT GEMM (no split-K form) - they
+        // stay on the exact-fp32 kernel, which splits K for small launches
+        const bool enough = halo || (Cout % 128 == 0 && (long long)(q.M / 256) * (Cout / 128) >= 128);
+        if (q.M % 128 == 0 && enough) {
+            const _Float16* a16 = x_packed;
+            if (!a16) {
+                _Float16* buf;
+                const long long rows_in = (long long)n * H * W;
+                REID_TRY(ctx_ws(ctx, "split.a", (size_t)rows_in * 2 * Cin * 2, (void**)&buf));
+                REID_TRY(launch_split_pack(ctx, (const float*)x, rows_in, Cin, buf));
+                a16 = buf;
+            }
             auto it = ctx->split_w.find(wgt);
             if (it == ctx->split_w.end()) {
                 void* w16;
@@ -576,6 +583,13 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
 
     const float* cur = b.pool;
     int H = 64, W = 32;
+    // precision 2: the block input as [xh | xl'] f16, packed once (the pooled stem output) or written by the previous block's
+    // SE tail; conv1 and the shortcut's 1x1 convolution both read it
+    _Float16* cur16 = nullptr;
+    if (ctx->precision == 2 && w.arch == 0 && ctx->f32_conv == 1) {
+        REID_TRY(ctx_ws(ctx, "split.cur", (size_t)n * per * 2 * 2, (void**)&cur16));
+        REID_TRY(launch_split_pack(ctx, b.pool, (long long)n * 64 * 32, 64, cur16));
+    }
     for (int i = 0; i < 8; ++i) {
         const Se18Block& k = w.blk[i];
         // four rotating buffers; in debug-keep mode every block gets its own four
@@ -597,11 +611,11 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
             // (+ ReLU) in conv1's epilogue, the InstanceNorm half (statistics of the whole image) by one in-place pass
             if (k.ibn) {
                 REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr,
-                                   0, w.ep + (size_t)i * 1024, w.ep + (size_t)i * 1024 + 512, nullptr, 1, b.stats, c1, half));
+                                   0, w.ep + (size_t)i * 1024, w.ep + (size_t)i * 1024 + 512, nullptr, 1, b.stats, c1, half, cur16));
                 REID_TRY(launch_in_apply(ctx, c1, b.stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta));
             } else {
                 REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr,
-                                   0, k.bn1_scale, k.bn1_shift, nullptr, 1, nullptr, c1));
+                                   0, k.bn1_scale, k.bn1_shift, nullptr, 1, nullptr, c1, 0, cur16));
             }
             REID_TRY(conv_gemm(ctx, A_IM2COL, c1, n, Ho, Wo, k.c, k.conv2_w, k.c, 3, 3, 1, 1, 9 * k.c, nullptr, nullptr, 0,
                                k.bn2_scale, k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, b.stats, y));
@@ -619,7 +633,7 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
         const float* shortcut = cur;
         if (k.ds) {
             REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.ds_w, k.c, 1, 1, k.stride, 0, k.cin, nullptr, nullptr, 0,
-                               k.ds_scale, k.ds_shift, nullptr, 0, nullptr, sc));
+                               k.ds_scale, k.ds_shift, nullptr, 0, nullptr, sc, 0, cur16));
             shortcut = sc;
         }
         float* out = c1;  // conv1 output is dead after conv2
@@ -628,7 +642,7 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
         } else if (w.arch == 2) {   // EMARes18_IBN: EMA + shortcut + ReLU (EMA_Res18.py:79-86)
             REID_TRY(launch_ema_tail(ctx, y, shortcut, n, Ho, Wo, k.c, k.ema, out));
         } else if (ctx->f32_conv == 1) {   // SE gate + combine in one launch
-            REID_TRY(launch_se_tail(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, y, shortcut, out));
+            REID_TRY(launch_se_tail(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, y, shortcut, out, i < 7 ? cur16 : nullptr));
         } else {
             REID_TRY(launch_se_finalize(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, b.se));
             REID_TRY(launch_se_combine(ctx, y, shortcut, b.se, n, hw, k.c, out));

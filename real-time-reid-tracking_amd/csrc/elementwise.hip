@@ -224,7 +224,7 @@ __global__ void se_combine_kernel(const float* __restrict__ y, const float* __re
 __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ stats, int tiles, int c, int mid, int hw,
                                                       const float* __restrict__ w1, const float* __restrict__ w2,
                                                       const float* __restrict__ y, const float* __restrict__ sc, int rows,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, _Float16* __restrict__ packed) {
     __shared__ __attribute__((aligned(16))) float pooled[512];
     __shared__ float hid[64];
     __shared__ __attribute__((aligned(16))) float gate[512];
@@ -280,6 +280,15 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
         f32x4 o = ss * yy + rr;
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         *(f32x4*)(out + base + (long long)i * 4) = o;
+        if (packed) {   // precision 2: the next block's convolutions read [oh | ol'] (ol' = f16((o - oh) 2^11)): written here, not by a pass of its own
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 hi = {(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+            const h4 lo = {(_Float16)((o.x - (float)hi.x) * 2048.0f), (_Float16)((o.y - (float)hi.y) * 2048.0f),
+                           (_Float16)((o.z - (float)hi.z) * 2048.0f), (_Float16)((o.w - (float)hi.w) * 2048.0f)};
+            const long long pix = (long long)img * hw + (long long)blockIdx.x * rows + i / c4n;
+            *(h4*)(packed + pix * 2 * c + cc * 4) = hi;
+            *(h4*)(packed + pix * 2 * c + c + cc * 4) = lo;
+        }
     }
 }
 
@@ -419,12 +428,12 @@ int tail_slices(int n_img, int hw) {
 }
 
 int launch_se_tail(reid_ctx* ctx, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1, const float* w2,
-                   const float* y, const float* sc, float* out) {
+                   const float* y, const float* sc, float* out, _Float16* packed) {
     ARG_CHECK(c % 4 == 0 && c <= 512 && mid <= 64);
     const int slices = tail_slices(n_img, hw);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 12.0);
     hipLaunchKernelGGL(se_tail_kernel, dim3(slices, n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2, y, sc,
-                       hw / slices, out);
+                       hw / slices, out, packed);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

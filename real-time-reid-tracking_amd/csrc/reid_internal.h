@@ -221,7 +221,7 @@ int launch_se_finalize(reid_ctx*, const float* stats, int n_img, int tiles, int 
                        const float* w2, float* s);
 int tail_slices(int n_img, int hw);   // elementwise.hip: blocks per image of the fused tail kernels
 int launch_se_tail(reid_ctx*, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1, const float* w2,
-                   const float* y, const float* sc, float* out);
+                   const float* y, const float* sc, float* out, _Float16* packed = nullptr);   // packed: also [oh | ol'] f16 [.., 2c]
 int launch_se_combine(reid_ctx*, const float* y, const float* sc, const float* s, int n_img, int hw, int c, float* out);
 int launch_gem_neck(reid_ctx*, const float* x, int n_img, int hw, int c, const float* p, const float* scale,
                     const float* shift, float* gem_out, float* emb);
@@ -342,7 +342,7 @@ struct reid_ctx {
 int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
               int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
               const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats, float* out,
-              int relu_from = 0);
+              int relu_from = 0, const _Float16* x_packed = nullptr);   // x_packed (precision 2): x already as [xh | xl']
 int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H, int W, int Cin, const _Float16* wgt, int Cout,
                 int R, int S, int stride, int pad, int K, const float* col_scale, const float* col_shift,
                 const _Float16* residual, int relu, float* stats, _Float16* out, int Hp = 0, int Wp = 0);
