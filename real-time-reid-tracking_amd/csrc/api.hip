@@ -606,19 +606,25 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
         const int Ho = (H + 2 - 3) / k.stride + 1, Wo = (W + 2 - 3) / k.stride + 1;
         const int hw = Ho * Wo, tiles = hw / 128;
         const int half = k.ibn ? k.c / 2 : 0;
+        _Float16* c1_16 = nullptr;
         if (ctx->f32_conv == 1) {
             // LDS-DMA conv kernel (conv_f32.hip): its loader copies, so bn1 is finished by the producer - the BatchNorm channels
             // (+ ReLU) in conv1's epilogue, the InstanceNorm half (statistics of the whole image) by one in-place pass
             if (k.ibn) {
                 REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr,
                                    0, w.ep + (size_t)i * 1024, w.ep + (size_t)i * 1024 + 512, nullptr, 1, b.stats, c1, half, cur16));
-                REID_TRY(launch_in_apply(ctx, c1, b.stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta));
+                if (cur16 && !keep) {   // precision 2: InstanceNorm finish + [xh | xl'] in one pass (conv2 is c1's only reader)
+                    REID_TRY(ctx_ws(ctx, "split.c1", (size_t)n * hw * k.c * 2 * 2, (void**)&c1_16));
+                    REID_TRY(launch_in_apply_pack(ctx, c1, b.stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, c1_16));
+                } else {
+                    REID_TRY(launch_in_apply(ctx, c1, b.stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta));
+                }
             } else {
                 REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr,
                                    0, k.bn1_scale, k.bn1_shift, nullptr, 1, nullptr, c1, 0, cur16));
             }
             REID_TRY(conv_gemm(ctx, A_IM2COL, c1, n, Ho, Wo, k.c, k.conv2_w, k.c, 3, 3, 1, 1, 9 * k.c, nullptr, nullptr, 0,
-                               k.bn2_scale, k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, b.stats, y));
+                               k.bn2_scale, k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, b.stats, y, 0, c1_16));
         } else {
         // conv1 (raw) + per-(image, channel) sum / sumsq partials for the InstanceNorm half
         REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr, 0,

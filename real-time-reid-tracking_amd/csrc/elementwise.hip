@@ -173,6 +173,53 @@ __global__ __launch_bounds__(256) void in_apply_kernel(float* __restrict__ x, co
     }
 }
 
+// ---- precision 2: the same finish of an IBN layer, but the consumer (conv2 in fp32-class arithmetic) reads [xh | xl'] f16, so the
+// result goes straight there: channels < half = relu(x * a + b), the BatchNorm half as the conv epilogue left it; nothing is
+// written back in fp32 (conv2 is the only reader of this tensor).  One pass instead of in_apply + split_pack.
+__global__ __launch_bounds__(256) void in_apply_pack_kernel(const float* __restrict__ x, const float* __restrict__ stats, int tiles, int c,
+                                                            int half, int hw, int rows, const float* __restrict__ in_gamma,
+                                                            const float* __restrict__ in_beta, _Float16* __restrict__ packed) {
+    __shared__ float sa[512], sb[512];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    for (int ch = tid; ch < c; ch += 256) {
+        if (ch >= half) {   // BatchNorm half: identity here
+            sa[ch] = 1.f;
+            sb[ch] = 0.f;
+            continue;
+        }
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = 0; t < tiles; ++t) {
+            const float* st = stats + (((long long)img * tiles + t) * c + ch) * 2;
+            s1 += (double)st[0];
+            s2 += (double)st[1];
+        }
+        const double mean = s1 / hw;
+        double var = s2 / hw - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double inv = 1.0 / sqrt(var + 1e-5);
+        sa[ch] = (float)(inv * (double)in_gamma[ch]);
+        sb[ch] = (float)((double)in_beta[ch] - mean * inv * (double)in_gamma[ch]);
+    }
+    __syncthreads();
+    const int q = c >> 2;
+    const long long pix0 = (long long)img * hw + (long long)blockIdx.x * rows;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < rows * q; i += 256) {
+        const int row = i / q, cc = i - row * q;
+        f32x4 v = *(const f32x4*)(x + (pix0 + row) * c + cc * 4);
+        if (cc * 4 < half) {   // half % 4 == 0: a chunk is entirely InstanceNorm or entirely BatchNorm
+            const f32x4 a = *(const f32x4*)&sa[cc * 4], b = *(const f32x4*)&sb[cc * 4];
+            v = v * a + b;
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        const h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        const h4 lo = {(_Float16)((v.x - (float)hi.x) * 2048.0f), (_Float16)((v.y - (float)hi.y) * 2048.0f),
+                       (_Float16)((v.z - (float)hi.z) * 2048.0f), (_Float16)((v.w - (float)hi.w) * 2048.0f)};
+        *(h4*)(packed + (pix0 + row) * 2 * c + cc * 4) = hi;
+        *(h4*)(packed + (pix0 + row) * 2 * c + c + cc * 4) = lo;
+    }
+}
+
 // ---- SEBlock (SERes18_IBN.py:32-41): s = sigmoid(W2 . relu(W1 . avgpool(y))), no bias, norm layer disabled (:36).
 // avgpool comes from the conv2 epilogue's per-tile column sums.  One block per image.  w1: [mid][c], w2: [mid][c] (fc2^T).
 __global__ __launch_bounds__(256) void se_finalize_kernel(const float* __restrict__ stats, int tiles, int c, int mid,
@@ -395,6 +442,17 @@ int launch_in_apply(reid_ctx* ctx, float* x, const float* stats, int n_img, int 
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * half * 8.0);
     hipLaunchKernelGGL(in_apply_kernel, dim3(hw / 128, n_img), dim3(256), 0, ctx->stream, x, stats, tiles, c, half, hw, 128, in_gamma,
                        in_beta);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+int launch_in_apply_pack(reid_ctx* ctx, const float* x, const float* stats, int n_img, int tiles, int c, int half, int hw,
+                         const float* in_gamma, const float* in_beta, _Float16* packed) {
+    ARG_CHECK(half >= 4 && half % 4 == 0 && c % 4 == 0 && c <= 512 && hw % 128 == 0 && packed);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 8.0);
+    hipLaunchKernelGGL(in_apply_pack_kernel, dim3(hw / 128, n_img), dim3(256), 0, ctx->stream, x, stats, tiles, c, half, hw, 128,
+                       in_gamma, in_beta, packed);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

@@ -223,6 +223,8 @@ int tail_slices(int n_img, int hw);   // elementwise.hip: blocks per image of th
 int launch_se_tail(reid_ctx*, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1, const float* w2,
                    const float* y, const float* sc, float* out, _Float16* packed = nullptr);   // packed: also [oh | ol'] f16 [.., 2c]
 int launch_se_combine(reid_ctx*, const float* y, const float* sc, const float* s, int n_img, int hw, int c, float* out);
+int launch_in_apply_pack(reid_ctx*, const float* x, const float* stats, int n_img, int tiles, int c, int half, int hw,
+                         const float* in_gamma, const float* in_beta, _Float16* packed);   // precision 2: IBN finish -> [xh | xl']
 int launch_gem_neck(reid_ctx*, const float* x, int n_img, int hw, int c, const float* p, const float* scale,
                     const float* shift, float* gem_out, float* emb);
 int launch_row_sqnorm(reid_ctx*, const float* x, int m, int d, long long ld, float* out);
