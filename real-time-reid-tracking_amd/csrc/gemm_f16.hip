@@ -153,16 +153,22 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
         }
         const int j = q;
         if constexpr (AMODE == A16_DENSE) {
-            __builtin_amdgcn_global_load_lds(GPTR(p.A + a_base[j] + k0 + a_chunk[j] * 8), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
+            int ka = k0;
+            if constexpr (LIN) {   // fp32-class linears: K = 3 Kr virtual columns over A = [xh | xl'] (the last third re-reads xh)
+                if (p.split_terms) ka = k0 % p.a_k;
+            }
+            __builtin_amdgcn_global_load_lds(GPTR(p.A + a_base[j] + ka + a_chunk[j] * 8), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
         } else if constexpr (AMODE == A16_IM2COL) {
             // K order (tap, channel); Cin % BK == 0.  (A channel-chunk-major order that lets the nine taps re-read the same
             // lines back to back was measured: no change.)
             const int tap = k0 / p.Cin;
             int c0 = k0 - tap * p.Cin;
             int a_cin = p.Cin;
-            if constexpr (SPLIT) {   // p.Cin virtual channels over a tensor of 2C: [xh | xl' | xh (| xl')]
-                a_cin = p.Cin / p.split_terms * 2;
-                c0 = c0 % a_cin;
+            if constexpr (SPLIT || LIN) {   // p.Cin virtual channels over a tensor of 2C: [xh | xl' | xh (| xl')]
+                if (SPLIT || p.split_terms) {
+                    a_cin = p.Cin / p.split_terms * 2;
+                    c0 = c0 % a_cin;
+                }
             }
             const int r = tap / p.S, s = tap - r * p.S;
             const int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
@@ -389,6 +395,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
         // Swin's K loops are 3-24 tiles long: the epilogue decides these launches.  Its two hot forms carry no per-element
         // address arithmetic, predicate or run-time branch; everything else takes the general loop at the end.
         const int n_real = p.n_real ? p.n_real : p.N;
+        const float asc = p.split_terms ? p.acc_scale : 1.0f;   // fp32-class linears: the accumulator holds 2^11 x the product
         constexpr bool LIN_LDS = BM * BN * 2 <= NST * STAGE;
         // (1) f16 outputs that are plain row-major (qkv, fc1): staged through LDS, leave as whole 16-byte pieces of a row
         const bool staged = LIN_LDS && !p.C32 && !p.res32 && p.scat_h == 0 && (n_real & 7) == 0;
@@ -405,8 +412,9 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
-                            float v = acc[a][b][e] + bias;
+                            float v = acc[a][b][e] * asc + bias;
                             if constexpr (ACT) v = gelu_f16_storage(v);
+                            acc[a][b][e] = v;   // kept for the low tile of a packed output
                             tile[(row0 + a * 32 + (e & 3) + 8 * (e >> 2)) * BN + lcol] = (f16)v;
                         }
                 }
@@ -419,6 +427,26 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
                 const int row = idx / C8, c8 = idx - row * C8;
                 if (row < m_valid && n_blk + c8 * 8 < n_real)
                     *(half8*)(p.C + (long long)(m_blk + row) * ldc + n_blk + c8 * 8) = *(const half8*)(tile + row * BN + c8 * 8);
+            }
+            if (p.pack_out) {   // [yh | yl']: the low tile (yl' = f16((y - yh) 2^11)) goes n_real columns further
+                __syncthreads();
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int lcol = wn * WTN + b * 32 + li;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float v = acc[a][b][e];
+                            tile[(row0 + a * 32 + (e & 3) + 8 * (e >> 2)) * BN + lcol] = (f16)((v - (float)(f16)v) * 2048.0f);
+                        }
+                }
+                __syncthreads();
+                for (int idx = tid; idx < BM * C8; idx += 512) {
+                    const int row = idx / C8, c8 = idx - row * C8;
+                    if (row < m_valid && n_blk + c8 * 8 < n_real)
+                        *(half8*)(p.C + (long long)(m_blk + row) * ldc + n_real + n_blk + c8 * 8) = *(const half8*)(tile + row * BN + c8 * 8);
+                }
             }
             return;
         }
@@ -450,7 +478,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
                         }
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
-                            float v = acc[a][b][e] + bias;
+                            float v = acc[a][b][e] * asc + bias;
                             if constexpr (ACT) v = gelu_f16_storage(v);
                             if constexpr (RES) v += res[e];
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff, (a * 32 + (e & 3) + 8 * (e >> 2)) * ldc * 4, 0);
@@ -496,7 +524,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
                         if (colv[b] >= n_real) continue;
-                        float v = acc[a][b][e] + bias[b];
+                        float v = acc[a][b][e] * asc + bias[b];
                         if (p.act == 1) v = gelu_f16_storage(v);
                         const long long o = obase + colv[b];
                         if (p.res32) v += p.res32[o];

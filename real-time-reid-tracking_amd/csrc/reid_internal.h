@@ -150,6 +150,8 @@ struct Gemm16Params {
     float acc_scale;
     int relu_from;
     int split_terms;            // 3 (default) or 4 (adds the xl.wl product)
+    int pack_out;               // LIN staged epilogue: C is [yh | yl'] f16 [M][2 n_real] (hi tile at column n_blk, low tile n_real further)
+    int a_k;                    // LIN dense build with split_terms != 0: columns of A ([xh | xl'] = 2 K); K-tile k0 reads column k0 % a_k
 };
 
 // reciprocals for the scatter epilogues: floor(x / d) == umulhi(x, ceil(2^32 / d)) for x < 2^32 / d (rows of one pass: < 2^20)

@@ -196,9 +196,11 @@ __device__ __forceinline__ void st4(f16* p, f32x4 v) {
     *(half4*)p = h;
 }
 // T = float (exact mode) or f16 (fp16-storage mode: qkv comes from / the result goes to the f16 GEMMs); ldq = row stride of qkv
+// packed != nullptr (T = float, precision 2): the result goes out as [oh | ol'] f16 [tokens][2C] for the fp32-class to_out linear
 template <typename T>
 __global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ qkv, int ldq, int n_img, int H, int W, int heads,
-                                                          int shifted, const float* __restrict__ pos, T* __restrict__ out) {
+                                                          int shifted, const float* __restrict__ pos, T* __restrict__ out,
+                                                          f16* __restrict__ packed = nullptr) {
     __shared__ float kv[4][2][49 * 32];
     __shared__ float spos[169];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -274,6 +276,18 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ 
 #pragma unroll
         for (int d = 0; d < 32; ++d) o[d] += pj * vj[d];
     }
+    if (packed) {
+        f16* ph = packed + tok * 2 * C + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            half4 hi = {(f16)o[d], (f16)o[d + 1], (f16)o[d + 2], (f16)o[d + 3]};
+            half4 lo = {(f16)((o[d] - (float)hi[0]) * 2048.0f), (f16)((o[d + 1] - (float)hi[1]) * 2048.0f),
+                        (f16)((o[d + 2] - (float)hi[2]) * 2048.0f), (f16)((o[d + 3] - (float)hi[3]) * 2048.0f)};
+            *(half4*)(ph + d) = hi;
+            *(half4*)(ph + C + d) = lo;
+        }
+        return;
+    }
     T* dst = out + tok * C + head * 32;
 #pragma unroll
     for (int d = 0; d < 32; d += 4) {
@@ -285,7 +299,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ 
 
 // ---- LayerNorm over the channel dimension, 16-byte accesses: LPT lanes per token (32 for C = 96: two tokens per wave; 64
 // otherwise), a lane owns the 4-channel chunks sub + LPT * j.  Two-pass (mean, then centred sum of squares) in registers.
-template <typename OUT, int LPT>
+// PACK (OUT = f16, precision 2): the normalised token goes out as [yh | yl'] f16 [tokens][2c] (yl' = f16((y - yh) 2^11))
+template <typename OUT, int LPT, bool PACK = false>
 __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restrict__ x, long long ntok, int c, float eps,
                                                            const float* __restrict__ g, const float* __restrict__ b,
                                                            OUT* __restrict__ out) {
@@ -319,15 +334,29 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
     for (int o = LPT / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = 1.0f / sqrtf(q / c + eps);
     if (!live) return;
-    OUT* oi = out + tok * c;
+    OUT* oi = out + tok * c * (PACK ? 2 : 1);
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
         const int ch = sub + LPT * j;
         if (ch < nch) {
             const f32x4 gg = *(const f32x4*)(g + ch * 4), bb = *(const f32x4*)(b + ch * 4);
-            st4(oi + ch * 4, (v[j] - mean) * rstd * gg + bb);
+            const f32x4 y = (v[j] - mean) * rstd * gg + bb;
+            if constexpr (PACK) {
+                half4 hi = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
+                half4 lo = {(f16)((y.x - (float)hi[0]) * 2048.0f), (f16)((y.y - (float)hi[1]) * 2048.0f),
+                            (f16)((y.z - (float)hi[2]) * 2048.0f), (f16)((y.w - (float)hi[3]) * 2048.0f)};
+                *(half4*)(oi + ch * 4) = hi;
+                *(half4*)(oi + c + ch * 4) = lo;
+            } else {
+                st4(oi + ch * 4, y);
+            }
         }
     }
+}
+
+void launch_layernorm_packed(reid_ctx* ctx, const float* x, long long T, int C, const float* g, const float* b, f16* out) {
+    if (C <= 128) hipLaunchKernelGGL((layernorm_v4_kernel<f16, 32, true>), dim3((unsigned)((T + 7) / 8)), dim3(256), 0, ctx->stream, x, T, C, 1e-5f, g, b, out);
+    else hipLaunchKernelGGL((layernorm_v4_kernel<f16, 64, true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, x, T, C, 1e-5f, g, b, out);
 }
 
 template <typename OUT>
@@ -703,8 +732,43 @@ inline int grid_for(long long work, int block) {
 }
 
 // ------------------------------------------------------------------------------------------------ GEMM helpers
+// x_packed (precision 2): x already as [xh | xl'] f16 [m][2k]; out_packed: the result as [yh | yl'] f16 [m][2n] instead of fp32 `out`
 int linear(reid_ctx* ctx, const float* x, long long m, int k, const float* w, const float* bias, int n, int act,
-           const float* residual, float* out) {
+           const float* residual, float* out, const f16* x_packed = nullptr, f16* out_packed = nullptr) {
+    if (ctx->precision == 2 && k % 32 == 0 && (m >= 1024 || x_packed)) {
+        // fp32-class arithmetic on the f16 matrix pipe (reid_ctx_set_precision(ctx, 2); the ResNet convolutions' trick,
+        // conv3x3_f16.hip): x -> [xh | xl'] f16, weights [wh 2^11 | wh | wl'] made once, three products per multiply through the
+        // f16 linear build with K = 3 k virtual columns, fp32 accumulate, fp32 in / out
+        const f16* a16 = x_packed;
+        if (!a16) {
+            f16* buf;
+            REID_TRY(ctx_ws(ctx, "swin.split.a", (size_t)m * 2 * k * 2, (void**)&buf));
+            REID_TRY(launch_split_pack(ctx, x, m, k, buf));
+            a16 = buf;
+        }
+        const int npad = (n + 63) / 64 * 64;
+        auto it = ctx->split_w.find(w);
+        if (it == ctx->split_w.end()) {
+            void* w16;
+            HIP_TRY(hipMalloc(&w16, (size_t)npad * 3 * k * 2));
+            HIP_TRY(hipMemsetAsync(w16, 0, (size_t)npad * 3 * k * 2, ctx->stream));
+            REID_TRY(launch_split_weights(ctx, w, n, 1, k, 3, (f16*)w16));
+            it = ctx->split_w.emplace(w, w16).first;
+        }
+        Gemm16Params q;
+        memset(&q, 0, sizeof(q));
+        q.A = a16; q.lda = 2 * k;
+        q.B = (const f16*)it->second; q.ldb = 3 * k;
+        q.M = (int)m; q.N = npad; q.K = 3 * k;
+        if (out_packed) {   // f16 [m][2n]: the epilogue writes the hi tile, then the low tile n columns further
+            q.C = out_packed; q.ldc = 2 * n; q.pack_out = 1;
+        } else {
+            q.C32 = out; q.ldc = n;
+        }
+        q.col_shift = bias; q.lin = 1; q.act = act; q.n_real = n; q.res32 = residual;
+        q.split_terms = 3; q.a_k = 2 * k; q.acc_scale = 1.0f / 2048.0f;
+        return launch_gemm_f16(ctx, A16_DENSE, q, REID_K_CONV_GEMM, 2.0 * m * n * k, 4.0 * ((double)m * k + (double)n * k + (double)m * n));
+    }
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x; p.lda = k;
@@ -751,9 +815,50 @@ int conv16(reid_ctx* ctx, const f16* zero_page, const f16* x, int n, int H, int 
 }
 
 // generic NHWC conv as implicit GEMM with bias (+residual); scatter for ConvTranspose parities
+// precision 2: a convolution of the Swin trunk (patch merging, the 8x8 stride-8 alignment conv, a ConvTranspose as four parity
+// convolutions in one launch) in fp32-class arithmetic: x packed to [xh | xl'], weights [wh 2^11 | wh | wl'] per tap made once,
+// the f16 im2col linear build over 3 Cin virtual channels, fp32 out.  parities = 4: `w` holds the four parity weight sets.
+int conv_split(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, const float* w, const float* bias, int Cout, int R, int S,
+               int stride, int pad_y, int pad_x, int Ho, int Wo, const float* residual, float* out, int scat_h, int scat_w, int py,
+               int px, int parities, const f16* zero_page) {
+    const long long rows = (long long)n * H * W;
+    f16* a16;
+    REID_TRY(ctx_ws(ctx, "swin.split.a", (size_t)rows * 2 * Cin * 2, (void**)&a16));
+    REID_TRY(launch_split_pack(ctx, x, rows, Cin, a16));
+    const int npad = (Cout + 63) / 64 * 64, taps = R * S;
+    const size_t per = (size_t)npad * taps * 3 * Cin;
+    auto it = ctx->split_w.find(w);
+    if (it == ctx->split_w.end()) {
+        void* w16;
+        HIP_TRY(hipMalloc(&w16, per * parities * 2));
+        HIP_TRY(hipMemsetAsync(w16, 0, per * parities * 2, ctx->stream));
+        for (int q = 0; q < parities; ++q)
+            REID_TRY(launch_split_weights(ctx, w + (size_t)q * Cout * taps * Cin, Cout, taps, Cin, 3, (f16*)w16 + q * per));
+        it = ctx->split_w.emplace(w, w16).first;
+    }
+    Gemm16Params p;
+    memset(&p, 0, sizeof(p));
+    p.A = a16;
+    p.par4 = parities == 4; p.par_stride = (long long)per;
+    p.H = H; p.W = W; p.Cin = 3 * Cin; p.R = R; p.S = S; p.stride = stride; p.asym = 1; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.Ho = Ho; p.Wo = Wo;
+    p.B = (const f16*)it->second; p.ldb = (long long)taps * 3 * Cin;
+    p.M = n * Ho * Wo; p.N = npad; p.K = taps * 3 * Cin;
+    p.C32 = out; p.ldc = Cout;
+    p.col_shift = bias; p.lin = 1; p.n_real = Cout; p.res32 = residual;
+    p.split_terms = 3; p.acc_scale = 1.0f / 2048.0f;
+    set_scatter(p, scat_h, scat_w, py, px);
+    p.zero_page = zero_page;
+    return launch_gemm_f16(ctx, A16_IM2COL, p, REID_K_CONV_GEMM, 2.0 * p.M * Cout * taps * Cin * parities,
+                           4.0 * ((double)rows * Cin + (double)Cout * taps * Cin * parities + (double)p.M * Cout * parities));
+}
+
 int conv_bias(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, const float* w, const float* bias, int Cout, int R,
               int S, int stride, int pad_y, int pad_x, int Ho, int Wo, const float* residual, float* out, int scat_h = 0,
-              int scat_w = 0, int py = 0, int px = 0) {
+              int scat_w = 0, int py = 0, int px = 0, const f16* zero_page = nullptr) {
+    if (ctx->precision == 2 && zero_page && Cin % 32 == 0 && (long long)n * Ho * Wo >= 1024)
+        return conv_split(ctx, x, n, H, W, Cin, w, bias, Cout, R, S, stride, pad_y, pad_x, Ho, Wo, residual, out, scat_h, scat_w, py, px, 1,
+                          zero_page);
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x;
@@ -773,7 +878,9 @@ int conv_bias(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, const
 // ConvTranspose2d(4, 2, 1) as its four output parities (2x2 stride-1 convs with one-sided padding, scattered to (2j+py, 2i+px));
 // wts: four [Cout][4 Cin] matrices.  One launch of 4 x the tile grid on the LDS-DMA kernel, else one launch per parity.
 int conv_transpose_parities(reid_ctx* ctx, const float* x, int n, int Hi, int Wi, int ci, const float* wts, const float* bias, int co,
-                            const float* residual, float* out) {
+                            const float* residual, float* out, const f16* zero_page = nullptr) {
+    if (ctx->precision == 2 && zero_page && ci % 32 == 0 && (long long)n * Hi * Wi >= 1024)
+        return conv_split(ctx, x, n, Hi, Wi, ci, wts, bias, co, 2, 2, 1, 1, 1, Hi, Wi, residual, out, Hi, Wi, 0, 0, 4, zero_page);
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x;
@@ -848,6 +955,9 @@ static SwinWeights* swin_find(reid_ctx* ctx) {
 }
 
 void swin_release(reid_ctx* ctx) {
+    // split forms of the old blob's weights (precision 2) are keyed by address: a new blob may reuse the addresses
+    for (auto& kv : ctx->split_w) (void)hipFree(kv.second);
+    ctx->split_w.clear();
     std::lock_guard<std::mutex> lk(swin_mutex());
     auto& r = swin_registry();
     auto it = r.find(ctx);
@@ -1111,7 +1221,8 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 REID_TRY(conv16(ctx, w.zero_page, x16, n, Hs, Ws, kDims[s - 1], w.merge16[s], w.merge_b[s], C, 2, 2, 2, 0, 0, Hs / 2, Ws / 2,
                                 nullptr, nullptr, xcur));
             } else {
-                REID_TRY(conv_bias(ctx, prev, n, Hs, Ws, kDims[s - 1], w.merge_w[s], w.merge_b[s], C, 2, 2, 2, 0, 0, Hs / 2, Ws / 2, nullptr, xcur));
+                REID_TRY(conv_bias(ctx, prev, n, Hs, Ws, kDims[s - 1], w.merge_w[s], w.merge_b[s], C, 2, 2, 2, 0, 0, Hs / 2, Ws / 2, nullptr, xcur, 0, 0,
+                                   0, 0, w.zero_page));
             }
             Hs /= 2;
             Ws /= 2;
@@ -1164,6 +1275,31 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 REID_TRY(linear16(ctx, big16, T, 4 * C, 4 * C, h.fc2, k.fc2_b, C, 0, xcur, nullptr, xcur, C));
                 continue;
             }
+            if (ctx->precision == 2 && T >= 1024) {
+                // fp32-class mode: the five linears in three-product f16 arithmetic (linear()); LayerNorm, the attention kernel and
+                // fc1 write their results as [yh | yl'] f16 directly, so no linear input goes through a pack pass except to_out's
+                // output on its way into post_proj (the reference's two roundings are kept: no folded matrix in fp32)
+                f16* ln16 = (f16*)lnb;      // [T][2C]
+                f16* att16 = (f16*)att;     // [T][2C]
+                f16* big16 = (f16*)big;     // MLP hidden [T][8C] (same bytes as the fp32 [T][4C])
+                prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
+                launch_layernorm_packed(ctx, xin, T, C, k.ln1_g, k.ln1_b, ln16);
+                prof_end(ctx);
+                REID_TRY(linear(ctx, nullptr, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big, ln16));
+                prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 16);
+                hipLaunchKernelGGL(window_attn_kernel<float>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, 3 * C, n,
+                                   Hs, Ws, heads, shifted, k.pos, (float*)nullptr, att16);
+                prof_end(ctx);
+                LAUNCH_CHECK();
+                REID_TRY(linear(ctx, nullptr, T, C, k.out_w, k.out_b, C, 0, nullptr, tmp, att16));
+                REID_TRY(linear(ctx, tmp, T, C, k.post_w, k.post_b, C, 0, xin, xcur));
+                prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
+                launch_layernorm_packed(ctx, xcur, T, C, k.ln2_g, k.ln2_b, ln16);
+                prof_end(ctx);
+                REID_TRY(linear(ctx, nullptr, T, C, k.fc1_w, k.fc1_b, 4 * C, 1, nullptr, nullptr, ln16, big16));
+                REID_TRY(linear(ctx, nullptr, T, 4 * C, k.fc2_w, k.fc2_b, C, 0, xcur, xcur, big16));
+                continue;
+            }
             // x = x + post_proj(to_out(attn(LN(x))))
             prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
             launch_layernorm<float>(ctx, xin, T, C, k.ln1_g, k.ln1_b, lnb);
@@ -1211,13 +1347,13 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
         }
         fin = f1;
     } else {
-    REID_TRY(conv_bias(ctx, sfe, n, H1, W1, 96, w.img_w, w.img_b, 768, 8, 8, 8, 0, 0, H4, W4, xs[3], tmp));
+    REID_TRY(conv_bias(ctx, sfe, n, H1, W1, 96, w.img_w, w.img_b, 768, 8, 8, 8, 0, 0, H4, W4, xs[3], tmp, 0, 0, 0, 0, w.zero_page));
     fin = tmp;
     float* fouts[3] = {f3, f2, f1};
     int Hi = H4, Wi = W4;
     for (int t = 0; t < 3; ++t) {
         const int ci = kDims[3 - t], co = kDims[2 - t];
-        REID_TRY(conv_transpose_parities(ctx, fin, n, Hi, Wi, ci, w.t_w[t], w.t_b[t], co, xs[2 - t], fouts[t]));
+        REID_TRY(conv_transpose_parities(ctx, fin, n, Hi, Wi, ci, w.t_w[t], w.t_b[t], co, xs[2 - t], fouts[t], w.zero_page));
         fin = fouts[t];
         Hi *= 2;
         Wi *= 2;
