@@ -41,6 +41,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_BANK_FAST")) c->bank_fast = atoi(e);
     if (const char* e = getenv("REID_SIDE_COPY")) c->side_copy = atoi(e);
     if (const char* e = getenv("REID_F32_STEMPOOL")) c->f32_stem_pool = atoi(e);
+    if (const char* e = getenv("REID_STEM_SPLIT")) c->stem_split = atoi(e);
     if (const char* e = getenv("REID_F32_SPLITK")) c->f32_split_k = atoi(e);
     if (const char* e = getenv("REID_SWIN_FOLD")) c->swin_fold = atoi(e);
     if (const char* e = getenv("REID_SWIN_STOP")) c->swin_stop = atoi(e);
@@ -568,8 +569,16 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
     // stem: conv7x7 s2 p3 + BN, no ReLU (SERes18_IBN.py:251-253), then MaxPool2d(3,2,1) (:254)
     // stem_f32.hip: weights resident in LDS, A operand read from an fp32 LDS image of the input rows; the max-pool runs on its
     // accumulators unless the conv map itself is wanted (debug stage 0) or REID_F32_STEMPOOL=0
-    const bool pool_fused = ctx->f32_conv == 1 && ctx->f32_stem_pool && !ctx->debug_keep;
-    if (pool_fused) {
+    const bool pool_fused = ctx->f32_conv == 1 && ctx->f32_stem_pool && ctx->debug_keep != 1;   // debug_keep 2: production kernels, no stage 0
+    // precision 2: the block input as [xh | xl'] f16, written by the split stem (or packed from its fp32 output) and then by every
+    // block's SE tail; conv1 and the shortcut's 1x1 convolution both read it
+    _Float16* cur16 = nullptr;
+    const bool split_mode = ctx->precision == 2 && w.arch == 0 && ctx->f32_conv == 1;
+    if (split_mode) REID_TRY(ctx_ws(ctx, "split.cur", (size_t)n * per * 2 * 2, (void**)&cur16));
+    const bool stem_split = split_mode && pool_fused && ctx->stem_split;
+    if (stem_split) {
+        REID_TRY(launch_stem_split(ctx, x, is_u8, n, w.stem_w, w.stem_scale, w.stem_shift, b.pool, cur16));
+    } else if (pool_fused) {
         REID_TRY(launch_stem_f32(ctx, x, is_u8, n, w.stem_w, w.stem_scale, w.stem_shift, b.pool, true));
     } else if (ctx->f32_conv == 1) {
         REID_TRY(launch_stem_f32(ctx, x, is_u8, n, w.stem_w, w.stem_scale, w.stem_shift, b.stem, false));
@@ -583,13 +592,7 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
 
     const float* cur = b.pool;
     int H = 64, W = 32;
-    // precision 2: the block input as [xh | xl'] f16, packed once (the pooled stem output) or written by the previous block's
-    // SE tail; conv1 and the shortcut's 1x1 convolution both read it
-    _Float16* cur16 = nullptr;
-    if (ctx->precision == 2 && w.arch == 0 && ctx->f32_conv == 1) {
-        REID_TRY(ctx_ws(ctx, "split.cur", (size_t)n * per * 2 * 2, (void**)&cur16));
-        REID_TRY(launch_split_pack(ctx, b.pool, (long long)n * 64 * 32, 64, cur16));
-    }
+    if (split_mode && !stem_split) REID_TRY(launch_split_pack(ctx, b.pool, (long long)n * 64 * 32, 64, cur16));
     for (int i = 0; i < 8; ++i) {
         const Se18Block& k = w.blk[i];
         // four rotating buffers; in debug-keep mode every block gets its own four

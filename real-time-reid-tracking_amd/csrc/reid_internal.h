@@ -200,6 +200,8 @@ int launch_conv_w16_chunked(reid_ctx*, const float* w_f32, int cout, int rs, int
 int launch_gemm_f32(reid_ctx* ctx, int amode, int epi, const GemmParams& p, int kind, double flops, double bytes);
 int launch_ta_tail(reid_ctx* ctx, const float* y, const float* sc, int n_img, int H, int W, int C, const float* wts, float* out);
 int launch_ema_tail(reid_ctx* ctx, const float* y, const float* sc, int n_img, int H, int W, int C, const float* prm, float* out);
+int launch_stem_split(reid_ctx* ctx, const void* x, bool is_u8, int n, const float* wgt, const float* scale, const float* shift, float* out,
+                      _Float16* packed);   // precision 2: 7x7 stem + BN + max-pool on split f16 operands (stem_split.hip)
 int launch_stem_f32(reid_ctx* ctx, const void* x, bool is_u8, int n, const float* wgt, const float* scale, const float* shift,
                     float* out, bool pooled);   // stem_f32.hip: 7x7 s2 conv + BN (+ MaxPool(3,2,1) on the accumulators) of the fp32 path
 bool gemm_f32_dma_supported(int amode, int epi, const GemmParams& p);   // gemm_f32_dma.hip: dense GEMM with LDS-DMA staging
@@ -321,6 +323,7 @@ struct reid_ctx {
     int f32_conv = 1;        // fp32 path (REID_F32_CONV): 1 = conv_f32.hip LDS-DMA kernel, norms in the producer's epilogue / in_apply;
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
     int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
+    int stem_split = 1;      // precision 2: the 7x7 stem on split f16 operands (REID_STEM_SPLIT=0: the fp32-pipe stem + split_pack)
     int f32_stem_pool = 1;   // fp32 path: MaxPool(3,2,1) on the stem kernel's accumulators (REID_F32_STEMPOOL=0: separate kernel)
     int split_terms = 3;     // precision 2: f16 products per multiply (REID_SPLIT_TERMS=4 adds the low x low product)
     int select_two_pass = 0; // REID_SELECT_TWO_PASS=1: arg-min / k-NN through the full distance matrix (A/B against dist_select.hip)

@@ -74,12 +74,12 @@ def test_seres18_embed_matches_reference_fixture(eng, golden_dir, tag, crops_fn,
     and fp32 accumulation on the f16 matrix pipe; everything else is the exact-fp32 path): same thresholds, stage by stage."""
     eng.set_precision(precision)
     try:
-        _seres18_fixture_check(eng, golden_dir, tag, crops_fn)
+        _seres18_fixture_check(eng, golden_dir, tag, crops_fn, precision)
     finally:
         eng.set_precision(0)
 
 
-def _seres18_fixture_check(eng, golden_dir, tag, crops_fn):
+def _seres18_fixture_check(eng, golden_dir, tag, crops_fn, precision=0):
     g = np.load(os.path.join(golden_dir, "seres18_%s.npz" % tag))
     seed, n = int(g["seed"]), int(g["n"])
     sd = synth.seres18_state_dict(seed)
@@ -99,6 +99,19 @@ def _seres18_fixture_check(eng, golden_dir, tag, crops_fn):
             got = eng.debug_stage(s, n)
             err = np.abs(got - want).max() / max(1e-6, np.abs(want).max())
             assert err < 2e-5, "stage %d (%s): rel max err %g" % (s, name, err)
+        # debug_keep 2: the production kernels (stem with the max-pool on its accumulators - in precision 2 the split stem of
+        # stem_split.hip, from uint8 and from fp32 input), every stage but the conv map itself
+        eng.debug_keep(2)
+        for entry in ("u8", "f32"):
+            emb_p = eng.embed_u8(crops) if entry == "u8" else eng.embed_f32_nchw(seres18.preprocess_u8(crops).numpy())
+            for s, name in enumerate(names):
+                if s == 0:
+                    continue
+                t = taps[name]
+                want = t.permute(0, 2, 3, 1).contiguous().numpy().reshape(-1) if t.dim() == 4 else t.numpy().reshape(-1)
+                err = np.abs(eng.debug_stage(s, n) - want).max() / max(1e-6, np.abs(want).max())
+                assert err < 2e-5, "production kernels, %s entry, stage %d (%s): rel max err %g" % (entry, s, name, err)
+            assert np.abs(emb_p - g["emb"]).max() / np.abs(g["emb"]).max() < 5e-5
     finally:
         eng.debug_keep(False)
     for mine, ref in ((emb, g["emb"]), (emb, ref_emb.numpy()), (logits, g["logits"])):
@@ -109,7 +122,8 @@ def _seres18_fixture_check(eng, golden_dir, tag, crops_fn):
     emb1 = eng.embed_u8(crops[:1])
     np.testing.assert_allclose(emb1, g["emb_single0"], rtol=1e-4, atol=2e-4 * np.abs(g["emb"]).max())
     embf = eng.embed_f32_nchw(seres18.preprocess_u8(crops).numpy())
-    np.testing.assert_allclose(embf, emb, rtol=1e-6, atol=1e-6 * np.abs(emb).max())
+    # precision 2: the uint8 entry convolves the exact integers 2 v - 255, the fp32 entry the hi/lo split of the normalised values
+    np.testing.assert_allclose(embf, emb, rtol=1e-6, atol=(5e-6 if precision == 2 else 1e-6) * np.abs(emb).max())
     # rebatching does not change results beyond fp32 noise (chunked passes)
     eng.set_chunk(2)
     emb_c = eng.embed_u8(crops)
