@@ -80,6 +80,13 @@ int reid_ctx_set_chunk(reid_ctx* ctx, int crops_per_pass);
  *       dropped xl.wl term at 2^-22; held to mode 0's parity thresholds (tests/test_gpu_parity.py).  Operands must lie inside
  *       f16's range: |activation| < 65504, |weight| < 32 (any trained ResNet18-IBN-SE by a wide margin). */
 int reid_ctx_set_precision(reid_ctx* ctx, int mode);
+/* optional side information of the NEXT embed call(s): one index per image, consumed in order by the passes that follow (n images
+ * in total; n = 0 clears).  ResNet18-IBN-SE: the camera of every crop - SERse18_IBN.forward(x, cam) adds cam_factor *
+ * cam_bias[cam] to the BNNeck output before the classifier (reid/backbones/SERes18_IBN.py:269-270); Swin: the view of every
+ * image - SwinTransformer.forward(img, view_index) adds side_info_coeff * side_info_embedding[view] to the SFE output
+ * (reid/backbones/swin_transformer.py:301-302).  The weight blob must carry the table (cam.bias + cam.factor / sfe.side +
+ * sfe.side_coeff); an index outside it, or more images than indices, is REID_ERR_ARG. */
+int reid_ctx_set_side_index(reid_ctx* ctx, const int32_t* index, int n);
 
 /* device memory for hosts without torch */
 int reid_malloc(reid_ctx* ctx, size_t bytes, void** dptr);

@@ -213,15 +213,20 @@ def gen_factory():
     print("factory:", res["get_model_name"])
 
 
-def gen_swin():
-    """Reference swin_t (version v1) with a stubbed timm (only trunc_normal_ / Mlp are imported, swin_transformer.py:12-13)."""
-    from reid_amd import synth
+def _timm_stub():
+    """timm is absent: swin_transformer.py:12-13 imports only trunc_normal_ and Mlp from it."""
     tl = types.ModuleType("timm.models.layers")
     tl.trunc_normal_ = torch.nn.init.trunc_normal_
     tl.Mlp = type("Mlp", (nn.Module,), {"__init__": lambda self, *a, **k: nn.Module.__init__(self)})
     for n in ("timm", "timm.models"):
         sys.modules.setdefault(n, types.ModuleType(n))
     sys.modules["timm.models.layers"] = tl
+
+
+def gen_swin():
+    """Reference swin_t (version v1) with a stubbed timm (only trunc_normal_ / Mlp are imported, swin_transformer.py:12-13)."""
+    from reid_amd import synth
+    _timm_stub()
     from reid.backbones.swin_transformer import swin_t  # the reference's own class
 
     seed, n = 0, 2
@@ -543,6 +548,43 @@ def gen_renorm():
           sum(1 for k in sd_np if k.endswith(".gamma")))
 
 
+def gen_side():
+    """The optional side-information branches: SERse18_IBN.forward(x, cam) adds cam_factor * cam_bias[cam] to the BNNeck output
+    (SERes18_IBN.py:269-270, cam_factor = -1 by default :198); SwinTransformer.forward(img, view_index) adds
+    side_info_coeff * side_info_embedding[view] to the SFE output (swin_transformer.py:298-302, coefficient 1.5 :279) of a model
+    built with camera = 4 (:288-290).  Both from the reference's own classes in eval mode."""
+    from reid_amd import synth
+    _timm_stub()
+    from reid.backbones.SERes18_IBN import seres18_ibn
+    from reid.backbones.swin_transformer import swin_t
+    sd_np = synth.seres18_state_dict(3)
+    model = seres18_ibn(num_classes=751, loss="triplet")
+    res = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model.eval()
+    crops = synth.smooth_crops_u8(4, 11)
+    cam = np.asarray([5, 0, 3, 3], np.int64)
+    x = torch.from_numpy(crops).float().div(255.0).sub(0.5).div(0.5).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        emb, logits = model(x, torch.from_numpy(cam))
+        emb0, _ = model(x)
+    assert float((emb - emb0).abs().max()) > 1e-3
+    sw_np = synth.swin_state_dict(4, views=4)
+    sw = swin_t(num_classes=751, loss="triplet", camera=4)
+    res = sw.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sw_np.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    sw.eval()
+    view = np.asarray([2, 0, 3], np.int64)
+    img = torch.from_numpy(synth.images_f32(3, 4))
+    with torch.no_grad():
+        slog, semb = sw(img, torch.from_numpy(view))
+        _, semb0 = sw(img)
+    assert float((semb - semb0).abs().max()) > 1e-3
+    np.savez_compressed(os.path.join(OUT, "side.npz"), cam=cam, emb=emb.numpy(), logits=logits.numpy(), view=view,
+                        swin_emb=semb.numpy(), swin_logits=slog.numpy())
+    print("side: cam shift", float((emb - emb0).abs().max()), "view shift", float((semb - semb0).abs().max()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -559,3 +601,4 @@ if __name__ == "__main__":
     gen_siblings()
     gen_e2e()
     gen_renorm()
+    gen_side()

@@ -148,9 +148,10 @@ def preprocess_u8(crops_u8):
     return x.permute(0, 3, 1, 2).contiguous()
 
 
-def forward(sd, x, taps=None, arch="seres18_ibn"):
+def forward(sd, x, taps=None, arch="seres18_ibn", cam=None, cam_factor=-1.0):
     """x: float32[N,3,256,128] NCHW (normalised).  Returns (emb[N,512], logits[N,num_class]).  ``arch``: seres18_ibn (default),
-    cares18_ibn or emares18_ibn."""
+    cares18_ibn or emares18_ibn.  ``cam`` (camera index per image) adds cam_factor * cam_bias[cam] to the BNNeck output before the
+    classifier (SERes18_IBN.py:269-270; cam_factor is the constructor's, default -1, :198)."""
     with torch.no_grad():
         x = F.conv2d(x, _t(sd, "conv0.weight"), None, 2, 3)
         x = _bn(sd, "bn0", x)                                  # no ReLU (SERes18_IBN.py:253)
@@ -167,6 +168,8 @@ def forward(sd, x, taps=None, arch="seres18_ibn"):
             taps["gem"] = feat
         emb = F.batch_norm(feat, _t(sd, "bnneck.running_mean"), _t(sd, "bnneck.running_var"),
                            _t(sd, "bnneck.weight"), _t(sd, "bnneck.bias"), False, 0.0, BN_EPS)
+        if cam is not None:
+            emb = emb + cam_factor * _t(sd, "cam_bias")[torch.as_tensor(np.asarray(cam), dtype=torch.long)]
         logits = emb @ _t(sd, "classifier.0.weight").t()
     return emb, logits
 

@@ -70,8 +70,10 @@ def _block(sd, prefix, x, heads, shifted):
     return x + h
 
 
-def forward(sd, img, taps=None):
-    """img: float32[N,3,224,224] (or any size whose /4 grid is divisible by 7 down to /32).  -> (emb[N,96], logits)."""
+def forward(sd, img, taps=None, view_index=None, side_info_coeff=1.5):
+    """img: float32[N,3,224,224] (or any size whose /4 grid is divisible by 7 down to /32).  -> (emb[N,96], logits).
+    ``view_index`` (per image) adds side_info_coeff * side_info_embedding[view] to the SFE output (swin_transformer.py:298-302;
+    the coefficient is the constructor's, default 1.5, :279)."""
     with torch.no_grad():
         x = F.conv2d(img, _t(sd, "sfe.conv1.weight"), _t(sd, "sfe.conv1.bias"), 2)
         a = F.instance_norm(x[:, :6].contiguous(), None, None, _t(sd, "sfe.norm.instancenorm.weight"),
@@ -82,6 +84,8 @@ def forward(sd, img, taps=None):
         x = F.relu(torch.cat((a, bb), 1))
         x = F.relu(F.conv2d(x, _t(sd, "sfe.conv2.weight"), _t(sd, "sfe.conv2.bias"), 2))
         sfe = _lin(sd, "sfe.fc", x.permute(0, 2, 3, 1))                     # [N,56,56,96] NHWC
+        if view_index is not None:
+            sfe = sfe + side_info_coeff * _t(sd, "sfe.side_info_embedding")[torch.as_tensor(np.asarray(view_index), dtype=torch.long)]
         if taps is not None:
             taps["sfe"] = sfe
         outs = []

@@ -26,6 +26,7 @@ _SIGS = {
     "reid_ctx_sync": (_i, [_vp]),
     "reid_ctx_set_chunk": (_i, [_vp, _i]),
     "reid_ctx_set_precision": (_i, [_vp, _i]),
+    "reid_ctx_set_side_index": (_i, [_vp, _vp, _i]),
     "reid_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "reid_free": (_i, [_vp, _vp]),
     "reid_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),

@@ -64,6 +64,15 @@ def _torch_cuda_forward(x, embed_dev, engine, out_dims):
     return outs
 
 
+def _index_array(index, n):
+    """cam / view_index argument (sequence, numpy array or torch tensor, one entry per image) -> int32[n]."""
+    a = index.detach().cpu().numpy() if hasattr(index, "detach") else np.asarray(index)
+    a = a.reshape(-1).astype(np.int64)
+    if a.shape[0] != n:
+        raise ValueError("expected one index per image (%d), got %d" % (n, a.shape[0]))
+    return a.astype(np.int32)
+
+
 class SERes18IBN:
     """ResNet18-IBN-a + SE + GeM + BNNeck ("ResNet18-SE"), eval mode only.
 
@@ -76,16 +85,18 @@ class SERes18IBN:
     embed_dim = 512
     arch = "seres18_ibn"
 
-    def __init__(self, num_classes=751, loss="triplet", pretrained=False, use_gpu=True, seed=0, **_):
+    def __init__(self, num_classes=751, loss="triplet", pretrained=False, use_gpu=True, seed=0, num_cams=6, cam_factor=-1.0, **_):
         if loss not in ("triplet", "softmax"):
             raise NotImplementedError                      # seres18_ibn(), SERes18_IBN.py:279-285
         self.num_classes = num_classes
+        self.num_cams, self.cam_factor = num_cams, float(cam_factor)   # SERes18_IBN.py:193,198: cam_bias [num_cams,512] and its factor
         self.is_reid = loss == "softmax"
         self.training = False
         self._device = 0
         # held with SERse18_IBN's named keys; state_dict() hands out the reference's own key layout (positional for the siblings'
         # downsample blocks), load_state_dict() accepts both
-        self._sd = weights.normalize_state_dict(synth.seres18_state_dict(seed, num_class=num_classes, gem_p=3.0, arch=self.arch))
+        self._sd = weights.normalize_state_dict(synth.seres18_state_dict(seed, num_class=num_classes, num_cams=num_cams, gem_p=3.0,
+                                                                         arch=self.arch))
         self._dirty = True
         if pretrained:
             import warnings
@@ -147,7 +158,7 @@ class SERes18IBN:
     def _engine(self):
         eng = get_engine(self._device)
         if self._dirty or getattr(eng, "_owner", None) is not self:
-            blob, manifest, _ = weights.pack_seres18(self._sd)
+            blob, manifest, _ = weights.pack_seres18(self._sd, cam_factor=getattr(self, "cam_factor", -1.0))
             eng.load_seres18(blob, manifest)
             eng._owner = self
             self._dirty = False
@@ -159,8 +170,15 @@ class SERes18IBN:
         return self
 
     def __call__(self, x, cam=None, return_logits=False):
-        if cam is not None:
-            raise NotImplementedError("camera-bias term (SERes18_IBN.py:269-270) is never used by the extractor path")
+        """``cam``: camera index per image (int array / tensor) - adds cam_factor * cam_bias[cam] to the embedding before the
+        classifier, as SERse18_IBN.forward(x, cam) does (SERes18_IBN.py:269-271); the extractor path never passes it."""
+        try:
+            return self._forward(x, cam, return_logits)
+        finally:
+            if cam is not None:
+                get_engine(self._device).set_side_index(None)     # nothing pending after a failed call
+
+    def _forward(self, x, cam, return_logits):
         is_torch = hasattr(x, "detach")
         if not is_torch:
             x = np.asarray(x, np.float32)
@@ -170,12 +188,17 @@ class SERes18IBN:
             if x.device.index != self._device:
                 self.to(x.device.index)
             eng = self._engine()
+            if cam is not None:
+                eng.set_side_index(_index_array(cam, x.shape[0]))
             emb, logits = _torch_cuda_forward(
                 x, lambda xf, o: eng.embed_f32_nchw_dev(xf.data_ptr(), xf.shape[0], o[0].data_ptr(), o[1].data_ptr()), eng,
                 (self.embed_dim, self.num_classes))
         else:
             x_np = x.detach().float().cpu().numpy() if is_torch else np.asarray(x, np.float32)
-            emb, logits = self._engine().embed_f32_nchw(x_np, logits=True)
+            eng = self._engine()
+            if cam is not None:
+                eng.set_side_index(_index_array(cam, x_np.shape[0]))
+            emb, logits = eng.embed_f32_nchw(x_np, logits=True)
             if is_torch:
                 import torch
                 emb, logits = torch.from_numpy(emb), torch.from_numpy(logits)
@@ -228,12 +251,16 @@ class SwinT:
 
     embed_dim = 96
 
-    def __init__(self, num_classes=751, loss="softmax", pretrained=False, use_gpu=True, seed=0, **_):
+    def __init__(self, num_classes=751, loss="softmax", pretrained=False, use_gpu=True, seed=0, camera=0, sequence=0, side_info=True,
+                 side_info_coeff=1.5, **_):
         self.num_classes = num_classes
         self.loss = loss
         self.training = False
         self._device = 0
-        self._sd = synth.swin_state_dict(seed, num_class=num_classes)
+        # ShadowFeatureExtraction's side-information table (swin_transformer.py:285-293): camera * sequence, camera or sequence rows
+        self.views = camera * sequence if camera * sequence > 0 else camera if camera > 0 else max(sequence, 0)
+        self.side_info, self.side_info_coeff = bool(side_info), float(side_info_coeff)
+        self._sd = synth.swin_state_dict(seed, num_class=num_classes, views=self.views)
         self._dirty = True
         if pretrained:
             import warnings
@@ -266,7 +293,7 @@ class SwinT:
     def _engine(self):
         eng = get_engine(self._device)
         if self._dirty or getattr(eng, "_swin_owner", None) is not self:
-            blob, manifest, _ = weights.pack_swin(self._sd)
+            blob, manifest, _ = weights.pack_swin(self._sd, side_info_coeff=getattr(self, "side_info_coeff", 1.5))
             eng.load_swin(blob, manifest)
             eng._swin_owner = self
             self._dirty = False
@@ -277,8 +304,20 @@ class SwinT:
         return self
 
     def __call__(self, x, view_index=None, return_logits=False):
-        if view_index is not None:
-            raise NotImplementedError("side-information embedding (swin_transformer.py:301-302) is not used by the plugin path")
+        """``view_index``: view (camera / sequence) index per image - adds side_info_coeff * side_info_embedding[view] to the SFE
+        output when the model was built with side_info and camera / sequence > 0 (swin_transformer.py:301-302, which ignores
+        the argument otherwise - so does this)."""
+        if view_index is not None and not (self.side_info and self.views > 0):
+            if self.side_info:      # the reference would index a parameter that does not exist (AttributeError)
+                raise AttributeError("SwinTransformer was built without camera / sequence: no side_info_embedding")
+            view_index = None
+        try:
+            return self._forward(x, view_index, return_logits)
+        finally:
+            if view_index is not None:
+                get_engine(self._device).set_side_index(None)
+
+    def _forward(self, x, view_index, return_logits):
         is_torch = hasattr(x, "detach")
         if is_torch and x.is_cuda:
             if x.ndim != 4 or x.shape[1] != 3 or x.shape[2] % 224 or x.shape[3] % 224:
@@ -286,12 +325,17 @@ class SwinT:
             if x.device.index != self._device:
                 self.to(x.device.index)
             eng = self._engine()
+            if view_index is not None:
+                eng.set_side_index(_index_array(view_index, x.shape[0]))
             emb, logits = _torch_cuda_forward(
                 x, lambda xf, o: eng.swin_embed_dev(xf.data_ptr(), xf.shape[0], xf.shape[2], xf.shape[3], o[0].data_ptr(), o[1].data_ptr()),
                 eng, (self.embed_dim, self.num_classes))
         else:
             x_np = x.detach().float().cpu().numpy() if is_torch else np.asarray(x, np.float32)
-            emb, logits = self._engine().swin_embed_f32_nchw(x_np, logits=True)
+            eng = self._engine()
+            if view_index is not None:
+                eng.set_side_index(_index_array(view_index, x_np.shape[0]))
+            emb, logits = eng.swin_embed_f32_nchw(x_np, logits=True)
             if is_torch:
                 import torch
                 emb, logits = torch.from_numpy(emb), torch.from_numpy(logits)

@@ -134,6 +134,45 @@ extern "C" int reid_ctx_set_precision(reid_ctx* ctx, int mode) {
     return REID_OK;
 }
 
+extern "C" int reid_ctx_set_side_index(reid_ctx* ctx, const int32_t* index, int n) {
+    ARG_CHECK(ctx && n >= 0 && (index || n == 0));
+    CTX_GUARD(ctx);
+    for (int i = 0; i < n; ++i) ARG_CHECK(index[i] >= 0);
+    ctx->side_idx.assign(index, index + n);
+    ctx->side_cursor = 0;
+    return REID_OK;
+}
+
+int ctx_take_side(reid_ctx* ctx, int n, int rows, const char* what, const int32_t** d_idx) {
+    *d_idx = nullptr;
+    if (ctx->side_idx.empty()) return REID_OK;
+    if (rows <= 0) {
+        reid_set_error("%s: side indices are pending (reid_ctx_set_side_index) but the loaded weights carry no table for them", what);
+        ctx->side_idx.clear();
+        return REID_ERR_STATE;
+    }
+    if (ctx->side_cursor + (size_t)n > ctx->side_idx.size()) {
+        reid_set_error("%s: %d images but only %zu side indices are pending", what, n, ctx->side_idx.size() - ctx->side_cursor);
+        ctx->side_idx.clear();
+        return REID_ERR_ARG;
+    }
+    const int32_t* h = ctx->side_idx.data() + ctx->side_cursor;
+    for (int i = 0; i < n; ++i)
+        if (h[i] >= rows) {
+            reid_set_error("%s: side index %d of image %d is outside the table of %d rows", what, h[i], i, rows);
+            ctx->side_idx.clear();
+            return REID_ERR_ARG;
+        }
+    int32_t* d;
+    REID_TRY(ctx_ws(ctx, "side.idx", (size_t)n * 4, (void**)&d));
+    HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));      // h lives in a vector the next set call may reallocate
+    ctx->side_cursor += n;
+    if (ctx->side_cursor == ctx->side_idx.size()) ctx->side_idx.clear();
+    *d_idx = d;
+    return REID_OK;
+}
+
 extern "C" int reid_ctx_set_debug_keep(reid_ctx* ctx, int on) {
     ARG_CHECK(ctx);
     CTX_GUARD(ctx);
@@ -420,6 +459,16 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
         w.cls_w = nullptr;
         w.num_class = 0;
     }
+    // optional: the camera-bias table of SERse18_IBN.forward(x, cam) (SERes18_IBN.py:246-248, 269-270)
+    auto cb = tab.find("cam.bias");
+    auto cf = tab.find("cam.factor");
+    w.cam_bias = nullptr;
+    w.num_cams = 0;
+    if (cb != tab.end() && cf != tab.end() && cb->second.second % 512 == 0 && cf->second.second == 1) {
+        w.cam_bias = w.blob + cb->second.first;
+        w.num_cams = (int)(cb->second.second / 512);
+        w.cam_factor = blob[cf->second.first];
+    }
     if (missing) {
         reid_set_error("reid_seres18_load: manifest entry '%s' missing or of unexpected size", first_missing.c_str());
         HIP_TRY(hipFree(w.blob));
@@ -662,6 +711,11 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
         W = Wo;
     }
     REID_TRY(launch_gem_neck(ctx, cur, n, H * W, 512, w.gem_p, w.neck_scale, w.neck_shift, b.gem, d_emb));
+    {   // SERse18_IBN.forward(x, cam): + cam_factor * cam_bias[cam] on the BNNeck output, before the classifier (:269-271)
+        const int32_t* d_cam;
+        REID_TRY(ctx_take_side(ctx, n, w.num_cams, "reid_embed (camera bias)", &d_cam));
+        if (d_cam) REID_TRY(launch_add_indexed_rows(ctx, d_emb, n, 1, 512, w.cam_bias, d_cam, w.cam_factor));
+    }
     b.stage[10] = b.gem;
     if (d_logits) {
         if (!w.cls_w) {
@@ -829,6 +883,11 @@ static int seres18_forward_f16(reid_ctx* ctx, const void* x, bool is_u8, int n, 
         W = Wo;
     }
     REID_TRY(launch_gem_neck_f16(ctx, cur, n, H * W, 512, w.gem_p, w.neck_scale, w.neck_shift, gem, d_emb));
+    {
+        const int32_t* d_cam;
+        REID_TRY(ctx_take_side(ctx, n, w.num_cams, "reid_embed (camera bias)", &d_cam));
+        if (d_cam) REID_TRY(launch_add_indexed_rows(ctx, d_emb, n, 1, 512, w.cam_bias, d_cam, w.cam_factor));
+    }
     stage[10] = gem;
     if (d_logits) {
         if (!w.cls_w) {

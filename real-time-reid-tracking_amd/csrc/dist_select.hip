@@ -31,8 +31,8 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int ROWB = BK * 4;
-constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-constexpr int AJ = BM / 8 / 4, BJ = BN / 8 / 4;
+constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+[[maybe_unused]] constexpr int STAGE = A_BYTES + B_BYTES, AJ = BM / 8 / 4, BJ = BN / 8 / 4;   // device code only
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(uintptr_t)(p))
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 

@@ -514,3 +514,29 @@ int launch_row_sqnorm(reid_ctx* ctx, const float* x, int m, int d, long long ld,
     LAUNCH_CHECK();
     return REID_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// x[img][p][c] += coeff * table[idx[img]][c]: the optional side-information terms - SERse18_IBN's camera bias on the BNNeck
+// output (SERes18_IBN.py:269-270; hw = 1, C = 512) and Swin's view embedding on the SFE output (swin_transformer.py:301-302;
+// hw = H/4 * W/4, C = 96)
+namespace {
+__global__ void add_indexed_rows_kernel(float* __restrict__ x, long long per_img, int C, const float* __restrict__ table,
+                                        const int32_t* __restrict__ idx, float coeff) {
+    const int img = blockIdx.y;
+    const float* row = table + (long long)idx[img] * C;
+    float* xi = x + (long long)img * per_img;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_img; i += (long long)gridDim.x * blockDim.x)
+        xi[i] += coeff * row[i % C];
+}
+}  // namespace
+
+int launch_add_indexed_rows(reid_ctx* ctx, float* x, int n, long long hw, int C, const float* table, const int32_t* d_idx, float coeff) {
+    ARG_CHECK(x && table && d_idx && n >= 1 && hw >= 1 && C >= 1);
+    const long long per_img = hw * C;
+    const int gx = (int)((per_img + 256 * 8 - 1) / (256 * 8));
+    prof_begin(ctx, REID_K_ELEMENTWISE, (double)n * per_img * 2.0, (double)n * per_img * 8.0);
+    hipLaunchKernelGGL(add_indexed_rows_kernel, dim3(gx < 1 ? 1 : gx, n), dim3(256), 0, ctx->stream, x, per_img, C, table, d_idx, coeff);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}

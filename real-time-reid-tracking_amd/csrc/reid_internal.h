@@ -262,6 +262,9 @@ struct Se18Weights {
     const float *stem_w, *stem_scale, *stem_shift;
     Se18Block blk[8];
     const float *gem_p, *neck_scale, *neck_shift, *cls_w;
+    const float* cam_bias = nullptr;   // [num_cams][512] (cam.bias; optional) and the constructor's cam_factor (cam.factor)
+    int num_cams = 0;
+    float cam_factor = -1.0f;
     _Float16* blob16 = nullptr;   // fp16 copy of the whole blob (same element offsets) for the fp16 path
     _Float16* stem_w16 = nullptr; // [64][256] stem weights of the padded-NHWC4 formulation
     _Float16* l1_conv2_w16s[2] = {nullptr, nullptr};   // layer-1 conv2 weights x BN scale (conv3x3_c64_f16.hip)
@@ -340,6 +343,8 @@ struct reid_ctx {
     hipStream_t copy_stream = nullptr;   // uploads of the frame pipeline (beside the kernels of the previous frame)
     hipEvent_t copy_ev = nullptr;
     int side_copy = 1;                   // REID_SIDE_COPY=0: uploads in the compute stream
+    std::vector<int32_t> side_idx;       // reid_ctx_set_side_index: camera / view index per image of the following embed call(s)
+    size_t side_cursor = 0;              // how many of them the passes so far have consumed
     const char* frame_out[2] = {nullptr, nullptr};
     float* stage_ptr[11] = {nullptr};
     unsigned long long* conv_diag = nullptr;   // experiments (debug.hip): stamps of the loader-wave conv kernel
@@ -372,6 +377,11 @@ struct DeviceGuard {
 
 void swin_release(reid_ctx* ctx);   // frees the Swin weights held for this context (swin.hip)
 int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out);  // grow-only named workspace
+// pending side indices of the next n images (reid_ctx_set_side_index): *d_idx = device array of n entries, or nullptr when none are
+// pending; entries must be < rows (the table of the loaded weights, 0 = the weights have none)
+int ctx_take_side(reid_ctx* ctx, int n, int rows, const char* what, const int32_t** d_idx);
+// x[img][p][c] += coeff * table[idx[img]][c] (elementwise.hip)
+int launch_add_indexed_rows(reid_ctx* ctx, float* x, int n, long long hw, int C, const float* table, const int32_t* d_idx, float coeff);
 int ctx_pinned(reid_ctx* ctx, const char* name, size_t bytes, void** out);   // grow-only named pinned host buffer
 int embed_ragged_enqueue(reid_ctx* ctx, const char* tag, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
                          float** d_emb_out, float** d_log_out, bool side_copy);   // api.hip: upload + resize + forward, no synchronisation

@@ -935,6 +935,9 @@ struct SwinWeights {
     const float *merge_w[4], *merge_b[4];
     const float *img_w, *img_b, *t_w[3], *t_b[3];
     const float *tail_g, *tail_b, *tail_p, *neck_s, *neck_t, *cls_w;
+    const float* side = nullptr;   // [views][96] side-information table of the SFE (sfe.side; optional) and its coefficient
+    int views = 0;
+    float side_coeff = 1.5f;
 };
 
 // context -> its Swin weights.  Camera streams load / destroy contexts from several host threads: every access to the map itself
@@ -1043,6 +1046,14 @@ extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats,
         w.num_class = (int)(cls->second.second / 96);
     } else {
         w.cls_w = nullptr;
+    }
+    // optional: ShadowFeatureExtraction's side-information embedding (swin_transformer.py:285-293, 301-302)
+    auto sd = tab.find("sfe.side");
+    auto sc = tab.find("sfe.side_coeff");
+    if (sd != tab.end() && sc != tab.end() && sd->second.second % 96 == 0 && sc->second.second == 1) {
+        w.side = w.blob + sd->second.first;
+        w.views = (int)(sd->second.second / 96);
+        w.side_coeff = blob[sc->second.first];
     }
     if (missing) {
         reid_set_error("reid_swin_load: manifest entry '%s' missing or of unexpected size", first.c_str());
@@ -1202,6 +1213,11 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                        w.c2_b, w.fc_w, w.fc_b, sfe);
     prof_end(ctx);
     LAUNCH_CHECK();
+    {   // SwinTransformer.forward(img, view_index): + side_info_coeff * side_info_embedding[view] on the SFE output (:301-302)
+        const int32_t* d_view;
+        REID_TRY(ctx_take_side(ctx, n, w.views, "reid_swin_embed (view index)", &d_view));
+        if (d_view) REID_TRY(launch_add_indexed_rows(ctx, sfe, n, (long long)H1 * W1, 96, w.side, d_view, w.side_coeff));
+    }
 
     int bi = 0, Hs = H1, Ws = W1;
     const float* prev = sfe;

@@ -106,6 +106,12 @@ class Engine:
         stride-1 convolutions as three f16 matrix-core products per multiply on hi/lo-split operands (fp32 accumulate)."""
         check(self.lib.reid_ctx_set_precision(self.h, int(mode)))
 
+    def set_side_index(self, index):
+        """Camera (ResNet18-IBN-SE: SERes18_IBN.py:269-270) or view (Swin: swin_transformer.py:301-302) index of every image of
+        the following embed call; ``None`` / empty clears."""
+        idx = np.ascontiguousarray(np.asarray([] if index is None else index).reshape(-1), np.int32)
+        check(self.lib.reid_ctx_set_side_index(self.h, _ptr(idx) if idx.size else None, int(idx.size)))
+
     def malloc(self, nbytes):
         p = C.c_void_p()
         check(self.lib.reid_malloc(self.h, int(nbytes), C.byref(p)))

@@ -225,9 +225,11 @@ def _swin_mask(ws, disp, upper_lower):
     return m
 
 
-def swin_state_dict(seed=0, num_class=751):
+def swin_state_dict(seed=0, num_class=751, views=0):
     """numpy ``state_dict`` with exactly the keys/shapes of ``swin_t(version='v1').state_dict()``
-    (reid/backbones/swin_transformer.py:339-395,508-513; 40.8 M parameters)."""
+    (reid/backbones/swin_transformer.py:339-395,508-513; 40.8 M parameters).  ``views`` > 0 adds the side-information table
+    ``sfe.side_info_embedding`` [views,1,1,96] of a model built with camera / sequence (:285-293; views = camera * sequence, camera
+    or sequence), drawn from a generator of its own so that the other tensors do not depend on it."""
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
     sd["sfe.conv1.weight"] = rng.normal(0, np.sqrt(1.0 / 12), (12, 3, 2, 2)).astype(np.float32)
@@ -267,6 +269,9 @@ def swin_state_dict(seed=0, num_class=751):
         sd[name + ".weight"] = rng.normal(0, np.sqrt(0.5 / (ci * 4)), (ci, co, 4, 4)).astype(np.float32)
         sd[name + ".bias"] = rng.normal(0, 0.1, co).astype(np.float32)
     sd["avgpool.p"] = np.asarray([float(rng.uniform(2.5, 3.5))], np.float32)
+    if views > 0:
+        sd["sfe.side_info_embedding"] = np.random.default_rng(seed + 7919).normal(0.0, 0.5, (views, 1, 1, 96)).astype(np.float32)
+        sd.move_to_end("sfe.side_info_embedding", last=False)   # a Parameter of sfe: first in the reference's key order
     return sd
 
 

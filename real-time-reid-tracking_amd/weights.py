@@ -5,8 +5,9 @@ Weight-ingest contract of the reference (checkpoint row):
     ``module.`` prefix (image_reid_train.py:111,635); ``{'state_dict': ...}`` wrappers are accepted
     (reid_model_factory.py:172-175);
   * ``Extractor`` loads with ``strict=False`` (feature_extractor.py:18-19): unknown keys are ignored;
-  * tensors the forward pass never reads are dropped: ``cam_bias`` (only used when ``cam`` is passed,
-    SERes18_IBN.py:269-270), ``*.seblock.bn.*`` (SERes18_IBN.py:36 commented out), ``num_batches_tracked``;
+  * tensors the forward pass never reads are dropped: ``*.seblock.bn.*`` (SERes18_IBN.py:36 commented out),
+    ``num_batches_tracked``; ``cam_bias`` (read only when ``cam`` is passed, SERes18_IBN.py:269-270) and Swin's
+    ``sfe.side_info_embedding`` (swin_transformer.py:301-302) travel as optional tables with their constructor coefficient;
   * ``--renorm`` checkpoints hold BatchRenormalization2D layers (gamma/beta/running_avg_*), whose eval
     math is plain BN (batchrenorm.py:93-95).
 
@@ -114,8 +115,9 @@ class Packer:
         return np.concatenate(self.parts).astype(np.float32), "\n".join(self.lines) + "\n"
 
 
-def pack_seres18(state_dict):
-    """Returns (blob float32[n], manifest str, info dict) for reid_seres18_load."""
+def pack_seres18(state_dict, cam_factor=-1.0):
+    """Returns (blob float32[n], manifest str, info dict) for reid_seres18_load.  ``cam_factor``: the constructor argument of
+    SERse18_IBN (SERes18_IBN.py:198, not part of the state_dict) that scales the camera-bias term."""
     sd = normalize_state_dict(state_dict)
     required = ["conv0.weight", "basicBlock11.block_pre.conv1.weight", "bnneck.running_mean"]
     for k in required:
@@ -177,6 +179,9 @@ def pack_seres18(state_dict):
         w = np.asarray(sd["classifier.0.weight"], np.float32)
         num_class = w.shape[0]
         pk.add("cls.w", w)
+    if "cam_bias" in sd and np.asarray(sd["cam_bias"]).ndim == 2 and np.asarray(sd["cam_bias"]).shape[1] == 512:
+        pk.add("cam.bias", np.asarray(sd["cam_bias"], np.float32))
+        pk.add("cam.factor", np.asarray([cam_factor], np.float32))
     blob, manifest = pk.finish()
     return blob, manifest, {"arch": arch, "embed_dim": 512, "num_class": num_class}
 
@@ -197,8 +202,9 @@ def _convt_parity(w):
     return out
 
 
-def pack_swin(state_dict):
+def pack_swin(state_dict, side_info_coeff=1.5):
     """state_dict of swin_t(version='v1') (reid/backbones/swin_transformer.py) -> (blob, manifest, info) for reid_swin_load.
+    ``side_info_coeff``: ShadowFeatureExtraction's constructor argument (:279) that scales the side-information embedding.
     Dropped: stage1.patch_partition (never applied, patch_merge=False :357-359), the constant shift masks (recomputed in
     the attention kernel), num_batches_tracked."""
     sd = normalize_state_dict(state_dict)
@@ -261,5 +267,8 @@ def pack_swin(state_dict):
         w = f("mlp_head.0.weight")
         num_class = w.shape[0]
         pk.add("cls.w", w)
+    if "sfe.side_info_embedding" in sd:
+        pk.add("sfe.side", f("sfe.side_info_embedding").reshape(-1, 96))
+        pk.add("sfe.side_coeff", np.asarray([side_info_coeff], np.float32))
     blob, manifest = pk.finish()
     return blob, manifest, {"arch": "swin_transformer", "embed_dim": 96, "num_class": num_class}

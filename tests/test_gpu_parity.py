@@ -1442,6 +1442,66 @@ def test_renorm_checkpoint_matches_reference_fixture(eng, golden_dir):
     assert np.abs(out.numpy() - g["emb"]).max() / np.abs(g["emb"]).max() < 5e-5
 
 
+# ----------------------------------------------------------------------------- optional side-information branches
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_camera_bias_and_view_embedding_match_reference_fixture(eng, golden_dir, precision):
+    """SERse18_IBN.forward(x, cam) (SERes18_IBN.py:269-271) and SwinTransformer.forward(img, view_index) of a model built with
+    camera = 4 (swin_transformer.py:285-302), against what the reference's own classes returned (tests/golden/side.npz):
+    through the C ABI (reid_ctx_set_side_index + embed) and through the model objects; chunked passes consume the indices in
+    order; a bad index or a count mismatch is an error and leaves nothing pending."""
+    from reid_amd import models
+    g = np.load(os.path.join(golden_dir, "side.npz"))
+    tol, ctol = (5e-5, 1e-5) if precision != 1 else (2e-2, 1e-4)
+    sd = synth.seres18_state_dict(3)
+    crops = synth.smooth_crops_u8(4, 11)
+    eng.load_seres18(*weights.pack_seres18(sd)[:2])
+    eng.set_precision(precision)
+    try:
+        eng.set_chunk(3)                                   # two passes: 3 + 1 images
+        eng.set_side_index(g["cam"])
+        emb, logits = eng.embed_u8(crops, logits=True)
+        for mine, ref in ((emb, g["emb"]), (logits, g["logits"])):
+            assert np.abs(mine - ref).max() / np.abs(ref).max() < tol
+        plain = eng.embed_u8(crops)                        # the indices were consumed: no bias now
+        assert np.abs(plain - emb).max() > 1e-2
+        np.testing.assert_allclose(emb - plain, -1.0 * sd["cam_bias"][g["cam"]], atol=2e-5 * np.abs(emb).max())
+        eng.set_side_index([0, 1, 6, 2])                   # 6 cameras: index 6 is outside the table
+        with pytest.raises(_ffi.ReidHipError):
+            eng.embed_u8(crops)
+        eng.set_side_index([0, 1])                         # fewer indices than images
+        with pytest.raises(_ffi.ReidHipError):
+            eng.embed_u8(crops)
+        np.testing.assert_array_equal(eng.embed_u8(crops), plain)      # nothing left pending after the errors
+        eng.set_chunk(64)
+        m = models.build_model("seres18_ibn", num_classes=751, loss="triplet", pretrained=False).eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        out, lg = m(seres18.preprocess_u8(crops), cam=torch.from_numpy(g["cam"]), return_logits=True)
+        assert np.abs(out.numpy() - g["emb"]).max() / np.abs(g["emb"]).max() < tol
+        assert np.abs(lg.numpy() - g["logits"]).max() / np.abs(g["logits"]).max() < tol
+        # Swin with a side-information table of 4 views
+        ssd = synth.swin_state_dict(4, views=4)
+        img = synth.images_f32(3, 4)
+        eng.load_swin(*weights.pack_swin(ssd)[:2])
+        eng.set_side_index(g["view"])
+        semb, slog = eng.swin_embed_f32_nchw(img, logits=True)
+        assert np.abs(semb - g["swin_emb"]).max() / np.abs(g["swin_emb"]).max() < (2e-4 if precision != 1 else 2e-2)
+        assert np.abs(slog - g["swin_logits"]).max() / np.abs(g["swin_logits"]).max() < (2e-4 if precision != 1 else 2e-2)
+        cos = (semb * g["swin_emb"]).sum(1) / np.linalg.norm(semb, axis=1) / np.linalg.norm(g["swin_emb"], axis=1)
+        assert (1 - cos).max() < ctol
+        from reid_amd import backbone
+        sm = backbone.swin_t(num_classes=751, loss="triplet", pretrained=False, camera=4).eval()   # swin_t(**kwargs), swin_transformer.py:508-510
+        sm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ssd.items()}, strict=True)
+        e2 = sm(torch.from_numpy(img), view_index=torch.from_numpy(g["view"]))
+        assert np.abs(e2.numpy() - g["swin_emb"]).max() / np.abs(g["swin_emb"]).max() < (2e-4 if precision != 1 else 2e-2)
+        assert np.abs(sm(torch.from_numpy(img)).numpy() - e2.numpy()).max() > 1e-2        # and without the index: no embedding
+        with pytest.raises(AttributeError):                # a model built without camera / sequence has no table
+            models.build_model("swin_transformer", num_classes=751, loss="triplet", pretrained=False)(img, view_index=[0, 0, 0])
+    finally:
+        eng.set_side_index(None)
+        eng.set_chunk(64)
+        eng.set_precision(0)
+
+
 # ----------------------------------------------------------------------------- BASELINE configs[2] at its stated size
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("precision", [0, 1, 2])

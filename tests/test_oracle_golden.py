@@ -254,3 +254,19 @@ def test_renorm_checkpoint_oracle_matches_reference(golden_dir):
     emb, logits = seres18.forward(rsd, seres18.preprocess_u8(crops))
     np.testing.assert_allclose(emb.numpy(), g["emb"], rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=2e-4, atol=2e-3)
+
+
+def test_side_information_branches_oracle_matches_reference(golden_dir):
+    """tests/golden/side.npz: the reference's SERse18_IBN.forward(x, cam) (camera bias, SERes18_IBN.py:269-270) and
+    SwinTransformer.forward(img, view_index) of a model built with camera=4 (swin_transformer.py:298-302)."""
+    import torch
+    from oracle import swin
+    g = np.load(os.path.join(golden_dir, "side.npz"))
+    sd = synth.seres18_state_dict(3)
+    emb, logits = seres18.forward(sd, seres18.preprocess_u8(synth.smooth_crops_u8(4, 11)), cam=g["cam"])
+    np.testing.assert_allclose(emb.numpy(), g["emb"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=2e-4, atol=2e-3)
+    ssd = synth.swin_state_dict(4, views=4)
+    semb, slog = swin.forward(ssd, torch.from_numpy(synth.images_f32(3, 4)), view_index=g["view"])
+    assert np.abs(semb.numpy() - g["swin_emb"]).max() / np.abs(g["swin_emb"]).max() < 2e-4
+    assert np.abs(slog.numpy() - g["swin_logits"]).max() / np.abs(g["swin_logits"]).max() < 2e-4
