@@ -77,12 +77,19 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
     constexpr int BJ = BN / 64;                      // B DMA instructions per wave per tile (BN/8 instructions, 8 waves)
     constexpr int TN = BN / 64;                      // wave tile 64 x BN/2 -> TN 32-col MFMA tiles
     constexpr int TM = 2;
-    static_assert(2 * HALO_BYTES + 3 * B_BYTES <= 160 * 1024, "LDS budget");
+    // Cout = 64 tiles (layer 1) with loader waves: THREE taps per block barrier (a tile of 8 MFMAs per wave per barrier spent more
+    // time at the barrier than in the matrix pipe: 507 + 833 cycles per 256 of MFMA, tools/diag_conv_f16.py); the weight ring
+    // then holds three groups of three taps
+    // (Cout >= 128 tiles have LDS for a fourth weight tile only: TWO taps per barrier over a ring of two pairs ran 4-6 % faster
+    // in the 256-crop microbenchmark and 3 % slower in the 1024-crop pass - dropped.)
+    constexpr int TPB = (LW && BN == 64 && 2 * HALO_BYTES + 9 * B_BYTES <= 160 * 1024) ? 3 : 1;
+    constexpr int NSLOT = 3 * TPB;
+    static_assert(2 * HALO_BYTES + NSLOT * B_BYTES <= 160 * 1024, "LDS budget");
     static_assert(HPW <= 6, "halo pieces are issued one per tap");
     constexpr int NLW = 4;                            // loader waves (LW == 1): waves 8..11 issue every DMA piece
     constexpr int BPL = BN / 8 / NLW;                 // weight pieces per loader wave per tile
     static_assert(6 * 8 >= NPI, "halo pieces of the next chunk are issued over taps 0..7, six per tap");
-    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + 3 * B_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + NSLOT * B_BYTES];
     char* halo = lds;
     char* ring = lds + 2 * HALO_BYTES;
 
@@ -229,6 +236,65 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         // no longer sit in the instruction stream of the MFMA waves), waves 0..7 only read LDS and issue MFMAs.  One block
         // barrier per tile: a loader arrives once its pieces of the NEXT tile have landed, a compute wave once it has
         // finished the current tile, so after barrier t tile t is complete in LDS and the slot of tile t-1 is free.
+        if constexpr (TPB == 3) {
+            const int nu = nt / 3;                       // iterations: (chunk, group of three taps); nt = 9 * nchunk
+            if (is_loader) {
+                const int lw = wave - 8;
+                auto loader_group = [&](int u) {         // weights of taps 3g .. 3g+2 of chunk u / 3 into ring slots 3 (u % 3) + j
+                    const int ck = chunk0 + u / 3, g = u - (u / 3) * 3;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int k0 = (g * 3 + j) * p.Cin + ck * 64;
+                        const int slot = (u % 3) * 3 + j;
+#pragma unroll
+                        for (int jj = 0; jj < BPL; ++jj) {
+                            const int inst = lw * BPL + jj;
+                            const int row = inst * 8 + (lane >> 3);
+                            const int c = (lane & 7) ^ ((row >> 1) & 7);
+                            __builtin_amdgcn_global_load_lds(GPTR(p.B + (long long)(n_blk + row) * p.ldb + k0 + c * 8),
+                                                             LPTR(ring + slot * B_BYTES + inst * 1024), 16, 0, 0);
+                        }
+                    }
+                };
+                auto wait_all_but = [&](int n) {         // s_waitcnt takes an immediate
+                    switch (n) {
+                        case 0: WAIT_VMCNT(0); break;   case 1: WAIT_VMCNT(1); break;   case 2: WAIT_VMCNT(2); break;
+                        case 3: WAIT_VMCNT(3); break;   case 4: WAIT_VMCNT(4); break;   case 5: WAIT_VMCNT(5); break;
+                        case 6: WAIT_VMCNT(6); break;   case 7: WAIT_VMCNT(7); break;   case 8: WAIT_VMCNT(8); break;
+                        case 9: WAIT_VMCNT(9); break;   case 10: WAIT_VMCNT(10); break; case 11: WAIT_VMCNT(11); break;
+                        case 12: WAIT_VMCNT(12); break; case 13: WAIT_VMCNT(13); break; case 14: WAIT_VMCNT(14); break;
+                        default: WAIT_VMCNT(0); break;
+                    }
+                };
+                constexpr int HALF = (NPI + 1) / 2;      // halo pieces of the next chunk: half in each of a chunk's first two iterations
+                for (int q = lw; q < NPI; q += NLW) issue_halo_piece(q, chunk0, chunk0 & 1);
+                loader_group(0);
+                if (nu > 1) loader_group(1);
+                int last = nu > 1 ? 3 * BPL : 0;         // pieces in the most recently issued group
+                int chunk = chunk0, g = 0;
+                for (int u = 0; u < nu; ++u) {
+                    // all but the most recent group (the next iteration's weights, halo pieces issued beside them) have landed
+                    wait_all_but(last);
+                    RAW_BARRIER();
+                    last = 0;
+                    if (u + 2 < nu) { loader_group(u + 2); last += 3 * BPL; }
+                    if (g < 2 && chunk + 1 < chunk_end) {
+                        const int q1 = (g + 1) * HALF < NPI ? (g + 1) * HALF : NPI;
+                        for (int q = g * HALF + lw; q < q1; q += NLW) { issue_halo_piece(q, chunk + 1, (chunk + 1) & 1); ++last; }
+                    }
+                    if (++g == 3) { g = 0; ++chunk; }
+                }
+                return;
+            } else {
+                int chunk = chunk0, g = 0;
+                for (int u = 0; u < nu; ++u) {
+                    RAW_BARRIER();
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) compute_tile(chunk, g * 3 + j, g * 3 + j);     // u % 3 == g: nine taps per chunk
+                    if (++g == 3) { g = 0; ++chunk; }
+                }
+            }
+        } else {
         int slot_c = 0, slot_i = 2, chunk = chunk0, tap = 0;
         if (is_loader) {
             const int lw = wave - 8;
@@ -287,6 +353,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
                 d[0] = t_bar; d[1] = t_comp; d[2] = nt; d[3] = ta - t_entry;   // d[3]: kernel entry -> end of the K loop
                 t_loop_end = ta;
             }
+        }
         }
     }
     __syncthreads();
