@@ -278,7 +278,9 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
                     RAW_BARRIER();
                     last = 0;
                     if (u + 2 < nu) { loader_group(u + 2); last += 3 * BPL; }
-                    if (g < 2 && chunk + 1 < chunk_end) {
+                    // SPLIT with 64 real channels (layer 1): virtual chunk 2 is xh again - what chunk 0 left in the same buffer
+                    const bool resident = SPLIT && p.Cin == 192 && p.split_terms == 3 && chunk0 == 0 && chunk + 1 == 2;
+                    if (g < 2 && chunk + 1 < chunk_end && !resident) {
                         const int q1 = (g + 1) * HALF < NPI ? (g + 1) * HALF : NPI;
                         for (int q = g * HALF + lw; q < q1; q += NLW) { issue_halo_piece(q, chunk + 1, (chunk + 1) & 1); ++last; }
                     }
