@@ -202,8 +202,8 @@ def run_embed(job, args):
         eng.profile(False)
         f16 = precision == "f16"
         x3 = precision == "f16x3"
-        # f16x3: every multiply of the 3x3 stride-1 convolutions (91 % of the MACs) is three f16 matrix-core products, so the
-        # pipe's dense peak counts a third per ALGORITHMIC flop; the stride-2 / 1x1 convolutions and the stem stay on the fp32 pipe
+        # f16x3: every multiply of every convolution is three f16 matrix-core products, so the pipe's dense peak counts a third
+        # per ALGORITHMIC flop
         peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F16_MFMA_TFLOPS / 3.0 if x3 else PEAK_F32_MFMA_TFLOPS
         conv_tflops = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         return {
@@ -214,7 +214,7 @@ def run_embed(job, args):
             "whole_net_fraction_of_hbm_roofline": round(FUSED_BYTES_PER_CROP * (0.5 if f16 else 1.0) * n / (embed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": {
                 "kernel": ("convolution kernels of the fp16 path, v_mfma_f32_32x32x16_f16: conv3x3_f16 (LDS halo, layers 2-4), conv3x3_c64_f16 (layer 1, weights in registers), stem_pool_f16 (7x7 + BN + maxpool), gemm_f16 (strided / 1x1)" if f16 else
-                           "convolution kernels of the fp32-class path: conv3x3_f16 SPLIT build (3x3 stride-1, x.w = xh.wh + (xl.wh + xh.wl) with hi/lo-split f16 operands, three v_mfma_f32_32x32x16_f16 per multiply, fp32 accumulate; peak = 2.5 PF / 3 per algorithmic flop) + conv_f32_dma (stride-2, 1x1) + the 7x7 stem on the fp32 pipe" if x3 else
+                           "convolution kernels of the fp32-class path, every one on v_mfma_f32_32x32x16_f16 with hi/lo-split operands (x.w = xh.wh + (xl.wh + xh.wl), three products per multiply, fp32 accumulate; peak = 2.5 PF / 3 per algorithmic flop): conv3x3_f16 SPLIT build (3x3 stride-1, LDS halo), gemm_f16 SPLIT build (stride-2, 1x1), stem_split (7x7 + BN + max-pool)" if x3 else
                            "convolution kernels of the fp32 path, v_mfma_f32_32x32x2_f32 (exact fp32): conv_f32_dma_kernel (implicit GEMM, LDS-DMA staging, all 3x3 / 1x1 convs) + the 7x7 stem"),
                 "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile("conv_f16" if f16 else "conv_f16x3" if x3 else "conv_f32"),
@@ -251,7 +251,7 @@ def run_embed(job, args):
     f16 = args.precision == "f16"
     arith = {"f32": "exact fp32 (v_mfma_f32_32x32x2_f32), the reference's arithmetic",
              "f16": "fp16 storage, fp32 accumulate (north_star tolerance 1e-3 cosine; measured below)",
-             "f16x3": "fp32-class: fp32 storage; 3x3 stride-1 convolutions as three f16 matrix-core products per multiply on hi/lo-split "
+             "f16x3": "fp32-class: fp32 storage; every convolution as three f16 matrix-core products per multiply on hi/lo-split "
                       "operands, fp32 accumulate (held to the exact-fp32 mode's parity thresholds in tests/test_gpu_parity.py)"}
     out = {
         "metric": "crops/sec embedded + NxM distmat ms, ResNet18-SE 128x256",
@@ -734,7 +734,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="--workload tracking: one synchronous call per operation (A/B)")
     ap.add_argument("--single", action="store_true", help="measure only --precision (skip the other arithmetic)")
     ap.add_argument("--precision", choices=["f32", "f16", "f16x3"], default=os.environ.get("REID_PRECISION", "f16x3"),
-                    help="arithmetic of the headline: f16x3 (default) = fp32-class - fp32 storage, every convolution but the stem as "
+                    help="arithmetic of the headline: f16x3 (default) = fp32-class - fp32 storage, every convolution as "
                          "three f16 matrix-core products per multiply on hi/lo-split operands with fp32 accumulation; it meets the "
                          "exact-fp32 mode's parity bar (stage taps < 2e-5 of the reference, 1 - cos < 1e-5, 0 of 256 arg-mins differ on "
                          "both config-1 sets: tests/test_gpu_parity.py); f32 = exact fp32 MFMA (side run f32_path); f16 = fp16 storage / "

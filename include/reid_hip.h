@@ -75,8 +75,8 @@ int reid_ctx_set_chunk(reid_ctx* ctx, int crops_per_pass);
 /* arithmetic of the convolution GEMMs:
  *   0 = exact fp32 (v_mfma_f32_32x32x2_f32) - the reference's arithmetic, the default;
  *   1 = fp16 storage / fp32 accumulate (activations and weights live in HBM as f16; north_star's 1e-3 cosine tolerance);
- *   2 = "fp32-class": fp32 storage, every convolution but the 7x7 stem as three v_mfma_f32_32x32x16_f16 per multiply on
- *       hi/lo-split operands (x = xh + xl, xh = f16(x), xl' = f16((x - xh) 2^11)) with fp32 accumulation - 22-bit operands, the
+ *   2 = "fp32-class": fp32 storage, every convolution (and every Linear / convolution of the Swin trunk) as three
+ *       v_mfma_f32_32x32x16_f16 per multiply on hi/lo-split operands (x = xh + xl, xh = f16(x), xl' = f16((x - xh) 2^11)) with fp32 accumulation - 22-bit operands, the
  *       dropped xl.wl term at 2^-22; held to mode 0's parity thresholds (tests/test_gpu_parity.py).  Operands must lie inside
  *       f16's range: |activation| < 65504, |weight| < 32 (any trained ResNet18-IBN-SE by a wide margin). */
 int reid_ctx_set_precision(reid_ctx* ctx, int mode);
