@@ -585,24 +585,35 @@ int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
     const int nmt = (p.M + 255) / 256;
     const int threads = LW ? 768 : 512;
-    // few M tiles (a tracking frame): 64-wide N tiles put twice as many blocks on the chip
-    if (p.N % 128 == 0 && (long long)nmt * (p.N / 128) >= 128) {
-        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(nmt * (p.N / 128)), dim3(threads), 0, ctx->stream, p);
-    } else {
-        // ... and when even those leave CUs idle, split the input channels over 2 or 4 blocks per tile (the K loop is
-        // latency-bound at ~0.65 us per (chunk, tap) tile, so its length is what a small launch costs)
-        const int tiles = nmt * (p.N / 64), nchunk = p.Cin / 64;
-        int sk = 1;
-        if (ctx->f16_split_k) while (sk < 4 && tiles * sk * 2 <= 256 && nchunk % (sk * 2) == 0) sk *= 2;
+    // few M tiles (a tracking frame): 64-wide N tiles put twice as many blocks on the chip ...
+    const int nchunk = p.Cin / 64;
+    auto splitk = [&](int tiles, int bn, int sk) -> int {
         if (sk > 1) {
             float* ws;
             int* cnt;
             bool fresh = ctx->ws.find("conv16.splitk_cnt") == ctx->ws.end();
-            REID_TRY(ctx_ws(ctx, "conv16.splitk_ws", (size_t)tiles * sk * 256 * 64 * sizeof(float), (void**)&ws));
+            REID_TRY(ctx_ws(ctx, "conv16.splitk_ws", (size_t)tiles * sk * 256 * bn * sizeof(float), (void**)&ws));
             REID_TRY(ctx_ws(ctx, "conv16.splitk_cnt", 256 * sizeof(int), (void**)&cnt));
             if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, 256 * sizeof(int), ctx->stream));
             p.split_k = sk; p.splitk_ws = ws; p.splitk_cnt = cnt;
         }
+        return REID_OK;
+    };
+    const int tiles128 = p.N % 128 == 0 ? nmt * (p.N / 128) : 0;
+    if (tiles128 >= 128) {
+        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(tiles128), dim3(threads), 0, ctx->stream, p);
+    } else if (ctx->f16_split_k && ctx->f16_wide_splitk && tiles128 >= 48 && tiles128 * 4 <= 256 && nchunk % 4 == 0 && nchunk >= 16) {
+        // ... unless the K loop is long enough (layer 4) to split four ways over 128-wide tiles: the same block count with half
+        // the barriers and 1.0 instead of 1.5 LDS fragment reads per MFMA
+        REID_TRY(splitk(tiles128, 128, 4));
+        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(tiles128 * 4), dim3(threads), 0, ctx->stream, p);
+    } else {
+        // ... and when even those leave CUs idle, split the input channels over 2 or 4 blocks per tile (the K loop is
+        // latency-bound at ~0.65 us per (chunk, tap) tile, so its length is what a small launch costs)
+        const int tiles = nmt * (p.N / 64);
+        int sk = 1;
+        if (ctx->f16_split_k) while (sk < 4 && tiles * sk * 2 <= 256 && nchunk % (sk * 2) == 0) sk *= 2;
+        REID_TRY(splitk(tiles, 64, sk));
         hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64, LW, SPLIT>), dim3(tiles * sk), dim3(threads), 0, ctx->stream, p);
     }
     LAUNCH_CHECK();

@@ -450,8 +450,10 @@ int launch_in_apply(reid_ctx* ctx, float* x, const float* stats, int n_img, int 
 int launch_in_apply_pack(reid_ctx* ctx, const float* x, const float* stats, int n_img, int tiles, int c, int half, int hw,
                          const float* in_gamma, const float* in_beta, _Float16* packed) {
     ARG_CHECK(half >= 4 && half % 4 == 0 && c % 4 == 0 && c <= 512 && hw % 128 == 0 && packed);
+    int rows = 128;    // few images (a tracking frame): shorter slices, so that there are blocks for every CU
+    while ((long long)n_img * (hw / rows) < 512 && rows > 16) rows >>= 1;
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 8.0);
-    hipLaunchKernelGGL(in_apply_pack_kernel, dim3(hw / 128, n_img), dim3(256), 0, ctx->stream, x, stats, tiles, c, half, hw, 128,
+    hipLaunchKernelGGL(in_apply_pack_kernel, dim3(hw / rows, n_img), dim3(256), 0, ctx->stream, x, stats, tiles, c, half, hw, rows,
                        in_gamma, in_beta, packed);
     prof_end(ctx);
     LAUNCH_CHECK();

@@ -316,6 +316,7 @@ struct reid_ctx {
     int swin_last_n = 0, swin_last_tok = 0;   // images / stage-1 tokens per image of the last Swin pass (reid_debug_swin_stage)
     int debug_keep = 0;      // 0 off, 1 stage buffers + unfused kernels, 2 stage buffers + production kernels
     bool last_f16 = false;
+    int f16_wide_splitk = 1;  // LDS-halo kernel, small launches with a long K loop: 128-wide tiles split four ways (REID_F16_WIDE_SPLITK=0: 64-wide)
     int f16_loader_waves = 1; // LDS-halo kernel: 8 compute + 4 dedicated loader waves (REID_F16_LOADERS)
     int f16_halo = 1;        // 3x3 stride-1 convs of the fp16 path use the LDS-halo kernel (REID_F16_HALO=0: implicit GEMM)
     int f16_se_tail = 1;     // fp16 path: SE gate + combine in one launch per block (REID_F16_SETAIL=0: se_finalize + se_combine)
