@@ -117,7 +117,7 @@ extern "C" int reid_ctx_sync(reid_ctx* ctx) {
 }
 
 extern "C" int reid_ctx_set_chunk(reid_ctx* ctx, int n) {
-    ARG_CHECK(ctx && n >= 1 && n <= 1024);
+    ARG_CHECK(ctx && n >= 1 && n <= 4096);
     CTX_GUARD(ctx);
     ctx->chunk = n;
     return REID_OK;
