@@ -50,9 +50,10 @@ class NearestNeighborDistanceMetric:
             self._eng.unregister_bank(self)
 
     def __del__(self):
+        # engine and bank reference each other: the collector may finalise either first, and the engine's close() closes its
+        # banks - so this must leave the bank marked as gone (close() does), or it is destroyed twice
         try:
-            if self._bank is not None and self._eng.h:     # a closed engine has taken its context (and device) with it
-                self._eng.lib.reid_bank_destroy(self._bank)
+            self.close()
         except Exception:
             pass
 

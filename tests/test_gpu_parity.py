@@ -1692,3 +1692,30 @@ def test_fp32_class_mode_small_and_odd_batches(eng_w0, n):
     assert np.abs(got - ref).max() <= 2e-5 * scale
     assert np.abs(again[:n] - got).max() <= 2e-5 * scale and np.abs(again[n:][::-1] - got).max() <= 2e-5 * scale
     assert np.abs(ragged - ragged_ref).max() <= 2e-5 * np.abs(ragged_ref).max()
+
+
+# ----------------------------------------------------------------------------- object lifetime
+@pytest.mark.parametrize("first", ["engine", "bank", "cycle"])
+def test_engine_and_bank_can_be_collected_in_any_order(first):
+    """An engine and the feature banks created on it reference each other; whichever goes first - an explicit close of either, or
+    the cycle collector finalising them in its own order at interpreter exit (bench.py's camera streams) - the device bank is
+    destroyed exactly once (a second reid_bank_destroy is a use-after-free)."""
+    import gc
+    from reid_amd.engine import Engine
+    from reid_amd.nn_matching import NearestNeighborDistanceMetric
+    e = Engine(0)
+    m = NearestNeighborDistanceMetric("cosine", 0.2, 10, max_tracks=8, engine=e)
+    m.partial_fit(np.random.default_rng(0).normal(size=(3, 512)).astype(np.float32), np.asarray([1, 2, 3]), [1, 2, 3])
+    assert m._bank is not None
+    if first == "engine":
+        e.close()
+        m.close()
+    elif first == "bank":
+        m.close()
+        e.close()
+    else:
+        m.__del__()           # what the collector may do first ...
+        e.__del__()           # ... and then: the engine must not destroy the bank again
+        m.__del__()
+    del m, e
+    gc.collect()
