@@ -1292,9 +1292,9 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 continue;
             }
             if (ctx->precision == 2 && T >= 1024) {
-                // fp32-class mode: the five linears in three-product f16 arithmetic (linear()); LayerNorm, the attention kernel and
-                // fc1 write their results as [yh | yl'] f16 directly, so no linear input goes through a pack pass except to_out's
-                // output on its way into post_proj (the reference's two roundings are kept: no folded matrix in fp32)
+                // fp32-class mode: the five linears in three-product f16 arithmetic (linear()); LayerNorm, the attention kernel, to_out
+                // and fc1 write their results as [yh | yl'] f16 directly, so no linear input goes through a pack pass (the
+                // reference's two roundings to_out -> post_proj are kept: no folded matrix in fp32)
                 f16* ln16 = (f16*)lnb;      // [T][2C]
                 f16* att16 = (f16*)att;     // [T][2C]
                 f16* big16 = (f16*)big;     // MLP hidden [T][8C] (same bytes as the fp32 [T][4C])
@@ -1307,8 +1307,8 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                                    Hs, Ws, heads, shifted, k.pos, (float*)nullptr, att16);
                 prof_end(ctx);
                 LAUNCH_CHECK();
-                REID_TRY(linear(ctx, nullptr, T, C, k.out_w, k.out_b, C, 0, nullptr, tmp, att16));
-                REID_TRY(linear(ctx, tmp, T, C, k.post_w, k.post_b, C, 0, xin, xcur));
+                REID_TRY(linear(ctx, nullptr, T, C, k.out_w, k.out_b, C, 0, nullptr, nullptr, att16, (f16*)tmp));   // [T][2C] = tmp's bytes
+                REID_TRY(linear(ctx, nullptr, T, C, k.post_w, k.post_b, C, 0, xin, xcur, (const f16*)tmp));
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
                 launch_layernorm_packed(ctx, xcur, T, C, k.ln2_g, k.ln2_b, ln16);
                 prof_end(ctx);
