@@ -666,7 +666,7 @@ def run_all(job, args):
             if dl is not None and time.monotonic() > dl:
                 if job.rank == 0 and state["out"] is not None:
                     state["out"][state["current"]] = {"error": "no answer within the time limit (watchdog)"}
-                    print(json.dumps(state["out"]), flush=True)
+                    emit(json.dumps(state["out"]))
                 os._exit(0)
 
     out = run_embed(job, args)
@@ -712,13 +712,31 @@ def run_all(job, args):
     except Exception as e:     # noqa: BLE001 - multi-rank job out of step: print what there is and leave
         print("[bench rank %d] sub-workload failed: %r" % (job.rank, e), file=sys.stderr, flush=True)
         if job.rank == 0 and out is not None:
-            print(json.dumps(out), flush=True)
+            emit(json.dumps(out))
         os._exit(0)
     state["deadline"] = None
     return out
 
 
+_RESULT_FD = None
+
+
+def emit(line):
+    """The ONE line of the contract goes to the process's original stdout; everything else any library prints to fd 1 (RCCL's
+    version banner at NCCL_DEBUG=WARN, ROCm notices) was redirected to stderr in main()."""
+    data = (line + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
+
+
 def main():
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)                      # native libraries that write to fd 1 now write to stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -749,7 +767,7 @@ def main():
               "market": run_market}[args.workload]
         out = fn(job, args)
         if out is not None:
-            print(json.dumps(out), flush=True)
+            emit(json.dumps(out))
         job.barrier()
     finally:
         job.close()

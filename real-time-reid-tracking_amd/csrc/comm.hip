@@ -148,6 +148,7 @@ extern "C" int reid_comm_init(reid_ctx* ctx, int rank, int world, const void* id
         ncclUniqueId id;
         memcpy(&id, id128, sizeof(id));
         setenv("NCCL_DEBUG", "WARN", 0);   // a failed bring-up must say why (RCCL prints the cause at WARN); never overrides the user
+        setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);   // ... and its version banner and warnings go to stderr: a host's stdout may be parsed
         ncclComm_t nc = nullptr;
         ncclResult_t r = g_rccl.CommInitRank(&nc, world, id, rank);
         if (r != ncclSuccess) {

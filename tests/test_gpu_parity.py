@@ -1719,3 +1719,24 @@ def test_engine_and_bank_can_be_collected_in_any_order(first):
         m.__del__()
     del m, e
     gc.collect()
+
+
+# ----------------------------------------------------------------------------- bench contract
+@pytest.mark.timeout(600)
+def test_bench_prints_one_json_line_and_exits_cleanly():
+    """`python bench.py` (here: a small embed workload over a REAL 1-rank RCCL communicator, REID_BENCH_COMM1=1) writes exactly one
+    line to stdout - the JSON of the contract, with `roofline` - and exits 0: RCCL's version banner and any other native print go
+    to stderr, and the interpreter's shutdown (engine / bank finalisers) does not crash."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, REID_BENCH_COMM1="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "embed", "--crops", "256", "--steps", "1",
+                        "--warmup", "1", "--no-cpu", "--single"], capture_output=True, text=True, env=env, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["unit"] == "crops/s" and d["n_gpus"] == 1 and d["value"] > 0 and d["dtype"] == "f16x3"
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
