@@ -734,6 +734,9 @@ def emit(line):
 
 def main():
     global _RESULT_FD
+    # dmabuf IPC for RCCL between the ranks of a node (the pool's driver has no legacy IPC: hipIpcGetMemHandle fails without it);
+    # must be in the environment before the first HIP call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.stdout.flush()
     _RESULT_FD = os.dup(1)
     os.dup2(2, 1)                      # native libraries that write to fd 1 now write to stderr
