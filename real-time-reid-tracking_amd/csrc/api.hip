@@ -42,6 +42,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_SIDE_COPY")) c->side_copy = atoi(e);
     if (const char* e = getenv("REID_F32_STEMPOOL")) c->f32_stem_pool = atoi(e);
     if (const char* e = getenv("REID_STEM_SPLIT")) c->stem_split = atoi(e);
+    if (const char* e = getenv("REID_PACK_EPILOGUE")) c->pack_epilogue = atoi(e);
     if (const char* e = getenv("REID_F16_WIDE_SPLITK")) c->f16_wide_splitk = atoi(e);
     if (const char* e = getenv("REID_F32_SPLITK")) c->f32_split_k = atoi(e);
     if (const char* e = getenv("REID_SWIN_FOLD")) c->swin_fold = atoi(e);
@@ -525,7 +526,8 @@ static const int IMG_H = 256, IMG_W = 128;
 int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
                      int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
                      const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats,
-                     float* out, int relu_from, const _Float16* x_packed) {
+                     float* out, int relu_from, const _Float16* x_packed, _Float16* out_packed, int pack_from, bool* packed_written) {
+    if (packed_written) *packed_written = false;
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x;
@@ -581,6 +583,11 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
             q.stats = stats;
             q.acc_scale = 1.0f / 2048.0f;
             q.zero_page = ctx->se18.zero_page;
+            if (out_packed && packed_written && pack_from % 32 == 0) {   // the consumer reads [yh | yl']: written by this epilogue
+                q.pack16 = out_packed;
+                q.pack_from = pack_from;
+                *packed_written = true;
+            }
             return halo ? launch_conv3x3_split(ctx, q, REID_K_CONV_GEMM, flops, bytes)
                         : launch_gemm_f16_split(ctx, q, REID_K_CONV_GEMM, flops, bytes);
         }
@@ -663,18 +670,25 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
         if (ctx->f32_conv == 1) {
             // LDS-DMA conv kernel (conv_f32.hip): its loader copies, so bn1 is finished by the producer - the BatchNorm channels
             // (+ ReLU) in conv1's epilogue, the InstanceNorm half (statistics of the whole image) by one in-place pass
+            // precision 2: conv2 (c1's only reader) loads [xh | xl'] - conv1's epilogue writes that form itself for the columns that
+            // are finished there (the BatchNorm half of an IBN layer, everything in layer 4), the InstanceNorm half follows in one
+            // pass (in_apply_pack); a conv1 that fell back to the fp32 kernel (strided, small launch) leaves fp32 only
+            bool packed_c1 = false;
+            if (cur16 && !keep && ctx->pack_epilogue) REID_TRY(ctx_ws(ctx, "split.c1", (size_t)n * hw * k.c * 2 * 2, (void**)&c1_16));
             if (k.ibn) {
                 REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr,
-                                   0, w.ep + (size_t)i * 1024, w.ep + (size_t)i * 1024 + 512, nullptr, 1, b.stats, c1, half, cur16));
-                if (cur16 && !keep) {   // precision 2: InstanceNorm finish + [xh | xl'] in one pass (conv2 is c1's only reader)
-                    REID_TRY(ctx_ws(ctx, "split.c1", (size_t)n * hw * k.c * 2 * 2, (void**)&c1_16));
-                    REID_TRY(launch_in_apply_pack(ctx, c1, b.stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, c1_16));
+                                   0, w.ep + (size_t)i * 1024, w.ep + (size_t)i * 1024 + 512, nullptr, 1, b.stats, c1, half, cur16,
+                                   c1_16, half, &packed_c1));
+                if (cur16 && !keep) {   // InstanceNorm finish + [xh | xl'] in one pass
+                    if (!c1_16) REID_TRY(ctx_ws(ctx, "split.c1", (size_t)n * hw * k.c * 2 * 2, (void**)&c1_16));
+                    REID_TRY(launch_in_apply_pack(ctx, c1, b.stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta, c1_16, packed_c1));
                 } else {
                     REID_TRY(launch_in_apply(ctx, c1, b.stats, n, tiles, k.c, half, hw, k.in_gamma, k.in_beta));
                 }
             } else {
                 REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.conv1_w, k.c, 3, 3, k.stride, 1, 9 * k.cin, nullptr, nullptr,
-                                   0, k.bn1_scale, k.bn1_shift, nullptr, 1, nullptr, c1, 0, cur16));
+                                   0, k.bn1_scale, k.bn1_shift, nullptr, 1, nullptr, c1, 0, cur16, c1_16, 0, &packed_c1));
+                if (!packed_c1) c1_16 = nullptr;      // conv2 packs its fp32 input itself
             }
             REID_TRY(conv_gemm(ctx, A_IM2COL, c1, n, Ho, Wo, k.c, k.conv2_w, k.c, 3, 3, 1, 1, 9 * k.c, nullptr, nullptr, 0,
                                k.bn2_scale, k.bn2_shift, k.ds ? nullptr : cur, k.ds ? 0 : 1, b.stats, y, 0, c1_16));

@@ -419,6 +419,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
             const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
             const float sh = p.col_scale ? p.col_shift[col] : 0.f;
             const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+            const bool pk = p.pack16 && col >= p.pack_from;
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
@@ -438,7 +439,14 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
                     if (rowv[e] < m_valid) {
                         t1 += v;
                         t2 += v * v;
-                        p.C32[(long long)(m_blk + rowv[e]) * ldc + col] = v;
+                        if (pk) {   // [yh | yl'] for the next convolution's loader (uniform per 32-column tile: pack_from % 32 == 0)
+                            const f16 hv = (f16)v;
+                            f16* dst = p.pack16 + (long long)(m_blk + rowv[e]) * 2 * p.N + col;
+                            dst[0] = hv;
+                            dst[p.N] = (f16)((v - (float)hv) * 2048.0f);
+                        } else {
+                            p.C32[(long long)(m_blk + rowv[e]) * ldc + col] = v;
+                        }
                     }
                 }
             }

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(float* __restrict__ x, co
 // written back in fp32 (conv2 is the only reader of this tensor).  One pass instead of in_apply + split_pack.
 __global__ __launch_bounds__(256) void in_apply_pack_kernel(const float* __restrict__ x, const float* __restrict__ stats, int tiles, int c,
                                                             int half, int hw, int rows, const float* __restrict__ in_gamma,
-                                                            const float* __restrict__ in_beta, _Float16* __restrict__ packed) {
+                                                            const float* __restrict__ in_beta, _Float16* __restrict__ packed, int in_only) {
     __shared__ float sa[512], sb[512];
     const int img = blockIdx.y, tid = threadIdx.x;
     for (int ch = tid; ch < c; ch += 256) {
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void in_apply_pack_kernel(const float* __restr
         sb[ch] = (float)((double)in_beta[ch] - mean * inv * (double)in_gamma[ch]);
     }
     __syncthreads();
-    const int q = c >> 2;
+    // in_only: the BatchNorm half left the conv epilogue as [yh | yl'] already - only the InstanceNorm channels pass through here
+    const int q = (in_only ? half : c) >> 2;
     const long long pix0 = (long long)img * hw + (long long)blockIdx.x * rows;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     for (int i = tid; i < rows * q; i += 256) {
@@ -448,13 +449,13 @@ int launch_in_apply(reid_ctx* ctx, float* x, const float* stats, int n_img, int 
 }
 
 int launch_in_apply_pack(reid_ctx* ctx, const float* x, const float* stats, int n_img, int tiles, int c, int half, int hw,
-                         const float* in_gamma, const float* in_beta, _Float16* packed) {
+                         const float* in_gamma, const float* in_beta, _Float16* packed, bool in_half_only) {
     ARG_CHECK(half >= 4 && half % 4 == 0 && c % 4 == 0 && c <= 512 && hw % 128 == 0 && packed);
     int rows = 128;    // few images (a tracking frame): shorter slices, so that there are blocks for every CU
     while ((long long)n_img * (hw / rows) < 512 && rows > 16) rows >>= 1;
-    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 8.0);
+    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * (in_half_only ? half : c) * 8.0);
     hipLaunchKernelGGL(in_apply_pack_kernel, dim3(hw / rows, n_img), dim3(256), 0, ctx->stream, x, stats, tiles, c, half, hw, rows,
-                       in_gamma, in_beta, packed);
+                       in_gamma, in_beta, packed, in_half_only ? 1 : 0);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

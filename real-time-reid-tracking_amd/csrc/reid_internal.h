@@ -147,6 +147,8 @@ struct Gemm16Params {
     // pixel (2C f16 = the bytes of fp32), the weights [wh * 2^11 | wh | wl'] per tap (Cin = 3C "virtual" channels: the third
     // third re-reads xh), so ONE fp32 accumulator collects 2^11 times the product; acc_scale = 2^-11 goes into the BN scale.
     // Output fp32 (C32), residual fp32 (res32), ReLU from column relu_from on.
+    _Float16* pack16;        // SPLIT builds: columns >= pack_from leave as [yh | yl'] f16 [M][2N] here instead of fp32 in C32
+    int pack_from;
     float acc_scale;
     int relu_from;
     int split_terms;            // 3 (default) or 4 (adds the xl.wl product)
@@ -228,7 +230,8 @@ int launch_se_tail(reid_ctx*, const float* stats, int n_img, int tiles, int c, i
                    const float* y, const float* sc, float* out, _Float16* packed = nullptr);   // packed: also [oh | ol'] f16 [.., 2c]
 int launch_se_combine(reid_ctx*, const float* y, const float* sc, const float* s, int n_img, int hw, int c, float* out);
 int launch_in_apply_pack(reid_ctx*, const float* x, const float* stats, int n_img, int tiles, int c, int half, int hw,
-                         const float* in_gamma, const float* in_beta, _Float16* packed);   // precision 2: IBN finish -> [xh | xl']
+                         const float* in_gamma, const float* in_beta, _Float16* packed,   // precision 2: IBN finish -> [xh | xl']
+                         bool in_half_only = false);   // the BatchNorm half was packed by the conv epilogue already
 int launch_gem_neck(reid_ctx*, const float* x, int n_img, int hw, int c, const float* p, const float* scale,
                     const float* shift, float* gem_out, float* emb);
 int launch_row_sqnorm(reid_ctx*, const float* x, int m, int d, long long ld, float* out);
@@ -327,6 +330,7 @@ struct reid_ctx {
     int f32_conv = 1;        // fp32 path (REID_F32_CONV): 1 = conv_f32.hip LDS-DMA kernel, norms in the producer's epilogue / in_apply;
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
     int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
+    int pack_epilogue = 1;   // precision 2: conv1 epilogues write [yh | yl'] for conv2 themselves (REID_PACK_EPILOGUE=0: fp32 + pack passes)
     int stem_split = 1;      // precision 2: the 7x7 stem on split f16 operands (REID_STEM_SPLIT=0: the fp32-pipe stem + split_pack)
     int f32_stem_pool = 1;   // fp32 path: MaxPool(3,2,1) on the stem kernel's accumulators (REID_F32_STEMPOOL=0: separate kernel)
     int split_terms = 3;     // precision 2: f16 products per multiply (REID_SPLIT_TERMS=4 adds the low x low product)
@@ -355,7 +359,8 @@ struct reid_ctx {
 int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
               int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
               const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats, float* out,
-              int relu_from = 0, const _Float16* x_packed = nullptr);   // x_packed (precision 2): x already as [xh | xl']
+              int relu_from = 0, const _Float16* x_packed = nullptr,
+              _Float16* out_packed = nullptr, int pack_from = 0, bool* packed_written = nullptr);   // x_packed (precision 2): x already as [xh | xl']
 int conv_gemm16(reid_ctx* ctx, int amode, const _Float16* x, int n, int H, int W, int Cin, const _Float16* wgt, int Cout,
                 int R, int S, int stride, int pad, int K, const float* col_scale, const float* col_shift,
                 const _Float16* residual, int relu, float* stats, _Float16* out, int Hp = 0, int Wp = 0);
