@@ -523,6 +523,22 @@ extern "C" int reid_seres18_dims(reid_ctx* ctx, int* embed_dim, int* num_class) 
 // ------------------------------------------------------------------------------------------------ forward
 static const int IMG_H = 256, IMG_W = 128;
 
+// precision 2: does this convolution run in split arithmetic (conv_gemm below), i.e. read the packed [xh | xl'] input only?
+// 3x3 stride-1 convolutions always do (LDS-halo kernel); strided / 1x1 ones when there are enough 128-wide tiles for the SPLIT GEMM
+// (no split-K form) - a tracking-sized batch leaves them on the exact-fp32 kernel, which splits K for small launches.
+static bool conv_split_path(reid_ctx* ctx, int n, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
+    if (ctx->precision != 2 || Cin % 64 != 0 || Cout % 64 != 0 || !ctx->se18.zero_page) return false;
+    Gemm16Params q;
+    memset(&q, 0, sizeof(q));
+    q.H = H; q.W = W; q.Cin = ctx->split_terms * Cin; q.R = R; q.S = S; q.stride = stride; q.pad = pad;
+    q.Ho = (H + 2 * pad - R) / stride + 1;
+    q.Wo = (W + 2 * pad - S) / stride + 1;
+    q.M = n * q.Ho * q.Wo; q.N = Cout;
+    const bool halo = R == 3 && S == 3 && stride == 1 && pad == 1 && conv3x3_f16_supported(q);
+    const bool enough = halo || (Cout % 128 == 0 && (long long)(q.M / 256) * (Cout / 128) >= 128);
+    return q.M % 128 == 0 && enough;
+}
+
 int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
                      int S, int stride, int pad, int Kpad, const float* a_scale, const float* a_shift, int a_relu,
                      const float* col_scale, const float* col_shift, const float* residual, int relu, float* stats,
@@ -545,7 +561,7 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
     const double flops = 2.0 * p.M * Cout * ktrue;
     const double in_bytes = (double)n * H * W * Cin * (amode == A_STEM_U8 ? 1.0 : 4.0);
     const double bytes = in_bytes + ((double)p.M * Cout + (double)Cout * ktrue) * 4.0 + (residual ? (double)p.M * Cout * 4.0 : 0.0);
-    if (ctx->precision == 2 && amode == A_IM2COL && !a_scale && Cin % 64 == 0 && Cout % 64 == 0 && ctx->se18.zero_page) {
+    if (amode == A_IM2COL && !a_scale && conv_split_path(ctx, n, H, W, Cin, Cout, R, S, stride, pad)) {
         // "fp32-class" arithmetic on the f16 matrix pipe (Gemm16Params, SPLIT builds of conv3x3_f16.hip / gemm_f16.hip): the fp32
         // activations are packed to [xh | xl'] f16, the weights were split once; three f16 products per multiply, fp32 accumulate,
         // fp32 in / out - the layers around the convolution (IBN, SE, residual stream) are the exact-fp32 path's, untouched
@@ -557,10 +573,7 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
         q.Ho = p.Ho; q.Wo = p.Wo;
         q.M = p.M; q.N = Cout; q.K = R * S * T * Cin; q.ldb = q.K;
         const bool halo = R == 3 && S == 3 && stride == 1 && pad == 1 && conv3x3_f16_supported(q);
-        // strided / 1x1 convolutions of a tracking-sized batch: too few 128-wide tiles for the SPLIT GEMM (no split-K form) - they
-        // stay on the exact-fp32 kernel, which splits K for small launches
-        const bool enough = halo || (Cout % 128 == 0 && (long long)(q.M / 256) * (Cout / 128) >= 128);
-        if (q.M % 128 == 0 && enough) {
+        {
             const _Float16* a16 = x_packed;
             if (!a16) {
                 _Float16* buf;
@@ -715,7 +728,17 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
         } else if (w.arch == 2) {   // EMARes18_IBN: EMA + shortcut + ReLU (EMA_Res18.py:79-86)
             REID_TRY(launch_ema_tail(ctx, y, shortcut, n, Ho, Wo, k.c, k.ema, out));
         } else if (ctx->f32_conv == 1) {   // SE gate + combine in one launch
-            REID_TRY(launch_se_tail(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, y, shortcut, out, i < 7 ? cur16 : nullptr));
+            // precision 2: the next block reads this one's output as [oh | ol'] (conv1, shortcut conv) and, when it has no shortcut
+            // conv, as the fp32 identity too; in front of a downsampling block whose two convolutions take the split path nobody
+            // reads the fp32 form, so it is not written (debug-keep does: the stage taps)
+            bool fp32_read = true;
+            if (cur16 && !keep && i < 7 && w.blk[i + 1].ds && ctx->pack_epilogue) {
+                const Se18Block& nx = w.blk[i + 1];
+                fp32_read = !(conv_split_path(ctx, n, Ho, Wo, nx.cin, nx.c, 3, 3, nx.stride, 1) &&
+                              conv_split_path(ctx, n, Ho, Wo, nx.cin, nx.c, 1, 1, nx.stride, 0));
+            }
+            REID_TRY(launch_se_tail(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, y, shortcut, fp32_read ? out : nullptr,
+                                    i < 7 ? cur16 : nullptr));
         } else {
             REID_TRY(launch_se_finalize(ctx, b.stats, n, tiles, k.c, k.mid, hw, k.se_w1, k.se_w2, b.se));
             REID_TRY(launch_se_combine(ctx, y, shortcut, b.se, n, hw, k.c, out));

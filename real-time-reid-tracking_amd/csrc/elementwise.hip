@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
         const f32x4 ss = *(const f32x4*)&gate[cc * 4];
         f32x4 o = ss * yy + rr;
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-        *(f32x4*)(out + base + (long long)i * 4) = o;
+        if (out) *(f32x4*)(out + base + (long long)i * 4) = o;
         if (packed) {   // precision 2: the next block's convolutions read [oh | ol'] (ol' = f16((o - oh) 2^11)): written here, not by a pass of its own
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             const h4 hi = {(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
@@ -490,7 +490,7 @@ int tail_slices(int n_img, int hw) {
 
 int launch_se_tail(reid_ctx* ctx, const float* stats, int n_img, int tiles, int c, int mid, int hw, const float* w1, const float* w2,
                    const float* y, const float* sc, float* out, _Float16* packed) {
-    ARG_CHECK(c % 4 == 0 && c <= 512 && mid <= 64);
+    ARG_CHECK(c % 4 == 0 && c <= 512 && mid <= 64 && (out || packed));
     const int slices = tail_slices(n_img, hw);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 12.0);
     hipLaunchKernelGGL(se_tail_kernel, dim3(slices, n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2, y, sc,
