@@ -708,7 +708,7 @@ def run_all(job, args):
         sub("batch256", run_embed, 240, crops=256, steps=20, warmup=3, no_cpu=True)
         sub("swin", run_swin, 300, crops=4096, steps=2, warmup=1)
         sub("market", run_market, 240, steps=20, warmup=3)
-        sub("tracking", tracking_both, 300, cameras=2 if job.world == 1 else 0)
+        sub("tracking", tracking_both, 300, cameras=4 if job.world == 1 else 0)
     except Exception as e:     # noqa: BLE001 - multi-rank job out of step: print what there is and leave
         print("[bench rank %d] sub-workload failed: %r" % (job.rank, e), file=sys.stderr, flush=True)
         if job.rank == 0 and out is not None:
