@@ -109,7 +109,8 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
     // ---- DMA descriptors: one wave-instruction fills RPI rows; wave w issues A instructions w*AJ + j
     int a_chunk[AJ], a_img[AJ], a_iy0[AJ], a_ix0[AJ];
     bool a_ok[AJ];
-    long long a_base[AJ];
+    long long a_base[AJ], a_pixc[AJ];    // a_pixc: A16_IM2COL, element offset of the row's tap-(0,0) input pixel (may point before it: pad)
+    const int im_acin = (p.split_terms > 0) ? p.Cin / p.split_terms * 2 : p.Cin;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int row = (wave * AJ + j) * RPI + lane / CH;
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
             a_iy0[j] = oy * p.stride - ((LIN && p.asym) ? p.pad_y : p.pad);
             a_ix0[j] = ox * p.stride - ((LIN && p.asym) ? p.pad_x : p.pad);
             a_img[j] = img;
+            a_pixc[j] = (((long long)img * p.H + a_iy0[j]) * p.W + a_ix0[j]) * im_acin;
         }
     }
     int b_chunk[BJ], b_row[BJ];
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
         b_base[j] = (long long)(n_blk + row) * p.ldb;
     }
 
+    int im_r = 0, im_s = 0, im_c0 = 0;     // A16_IM2COL: kernel row / column / first channel of the next K-tile to be staged
     // one DMA piece (wave-instruction) of K-tile kt: q < AJ -> A piece q, else B piece q - AJ
     auto stage_piece = [&](int kt, int slot, int q) {
         char* As = lds + slot * STAGE;
@@ -160,20 +163,26 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
             __builtin_amdgcn_global_load_lds(GPTR(p.A + a_base[j] + ka + a_chunk[j] * 8), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
         } else if constexpr (AMODE == A16_IM2COL) {
             // K order (tap, channel); Cin % BK == 0.  (A channel-chunk-major order that lets the nine taps re-read the same
-            // lines back to back was measured: no change.)
-            const int tap = k0 / p.Cin;
-            int c0 = k0 - tap * p.Cin;
+            // lines back to back was measured: no change.)  The K-tiles are staged in order, so (kernel row, kernel column,
+            // first channel) of tile kt are counters that stage() advances - k0 / Cin, tap / S and the fold's modulo used to be
+            // three run-time integer divisions per DMA piece, ~300 vector instructions per wave and K-tile beside 16 MFMAs: the
+            // Swin trunk's convolutions (K loops of 12-48 tiles) spent their time there.
+            int c0 = im_c0;
             int a_cin = p.Cin;
             if constexpr (SPLIT || LIN) {   // p.Cin virtual channels over a tensor of 2C: [xh | xl' | xh (| xl')]
                 if (SPLIT || p.split_terms) {
-                    a_cin = p.Cin / p.split_terms * 2;
-                    c0 = c0 % a_cin;
+                    a_cin = im_acin;
+                    if (c0 >= a_cin) c0 -= a_cin;          // Cin <= 2 a_cin
                 }
             }
-            const int r = tap / p.S, s = tap - r * p.S;
+            const int r = im_r, s = im_s;
             const int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
             const bool ok = a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const f16* src = ok ? p.A + (((long long)a_img[j] * p.H + iy) * p.W + ix) * a_cin + c0 + a_chunk[j] * 8 : p.zero_page;
+            // element offset = (pixel of tap (0,0), made once per lane) + (tap offset and channel: wave-uniform) - the 64-bit
+            // multiplies of ((img H + iy) W + ix) a_cin per DMA piece were quarter-rate vector instructions, ~500 cycles per wave
+            // and K-tile beside 128-512 of MFMA
+            const long long uni = (long long)(r * p.W + s) * a_cin + c0;
+            const f16* src = ok ? p.A + a_pixc[j] + uni + a_chunk[j] * 8 : p.zero_page;
             __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(As + (wave * AJ + j) * 1024), 16, 0, 0);
         } else {  // A16_STEM: zero-padded NHWC4 image, k = r*32 + s*4 + c; a 16-B chunk = one pixel pair of one kernel row
             const int kq = kt * CH + a_chunk[j];   // chunk index along K: kernel row = kq / 4, pixel pair = kq % 4
@@ -184,6 +193,13 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
     auto stage = [&](int kt, int slot) {
 #pragma unroll
         for (int q = 0; q < G; ++q) stage_piece(kt, slot, q);
+        if constexpr (AMODE == A16_IM2COL) {      // the next tile's position in the (kernel row, kernel column, channel) walk
+            im_c0 += BK;
+            if (im_c0 == p.Cin) {
+                im_c0 = 0;
+                if (++im_s == p.S) { im_s = 0; ++im_r; }
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
