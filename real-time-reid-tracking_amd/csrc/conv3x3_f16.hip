@@ -239,6 +239,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         if constexpr (TPB == 3) {
             const int nu = nt / 3;                       // iterations: (chunk, group of three taps); nt = 9 * nchunk
             if (is_loader) {
+                if (p.loader_prio) __builtin_amdgcn_s_setprio(3);
                 const int lw = wave - 8;
                 auto loader_group = [&](int u) {         // weights of taps 3g .. 3g+2 of chunk u / 3 into ring slots 3 (u % 3) + j
                     const int ck = chunk0 + u / 3, g = u - (u / 3) * 3;
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         } else {
         int slot_c = 0, slot_i = 2, chunk = chunk0, tap = 0;
         if (is_loader) {
+            if (p.loader_prio) __builtin_amdgcn_s_setprio(3);
             const int lw = wave - 8;
             auto loader_b = [&](int t, int slot) {   // this loader's BPL pieces of weight tile t
                 const int ck = chunk0 + t / 9, tp = t - (t / 9) * 9;
@@ -591,6 +593,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
 template <int TW, int IMGS, int LW, bool SPLIT = false>
 int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
+    p.loader_prio = ctx->f16_loader_prio == 2 || (ctx->f16_loader_prio == 1 && SPLIT);
     const int nmt = (p.M + 255) / 256;
     const int threads = LW ? 768 : 512;
     // few M tiles (a tracking frame): 64-wide N tiles put twice as many blocks on the chip ...
