@@ -191,18 +191,26 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
             a_off[a] = hp * 128;
             a_swz[a] = (hp >> 1) & 7;
         }
+        // the fragments of k-step kk + 1 are read before the MFMAs of step kk are issued (two register sets, the order pinned):
+        // left to itself the compiler reads three of the four fragments right before the s_waitcnt of the step that needs them
+        half8 af[2][TM], bf[2][TN];
+        auto read_step = [&](int kk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[buf][a] = *(const half8*)(As + a_off[a] + (((kk * 2 + lh) ^ a_swz[a]) * 16));
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[buf][b] = *(const half8*)(Bs + b_row_off + b * 32 * 128 + (((kk * 2 + lh) ^ b_swz) * 16));
+        };
+        read_step(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            half8 af[TM], bf[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *(const half8*)(As + a_off[a] + (((kk * 2 + lh) ^ a_swz[a]) * 16));
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = *(const half8*)(Bs + b_row_off + b * 32 * 128 + (((kk * 2 + lh) ^ b_swz) * 16));
+            if (kk < 3) read_step(kk + 1, (kk + 1) & 1);
+            if (p.frag_ahead) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][a], bf[kk & 1][b], acc[a][b], 0, 0, 0);
+            if (p.frag_ahead) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -594,6 +602,7 @@ template <int TW, int IMGS, int LW, bool SPLIT = false>
 int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
     p.loader_prio = ctx->f16_loader_prio == 2 || (ctx->f16_loader_prio == 1 && SPLIT);
+    p.frag_ahead = ctx->f16_frag_ahead;
     const int nmt = (p.M + 255) / 256;
     const int threads = LW ? 768 : 512;
     // few M tiles (a tracking frame): 64-wide N tiles put twice as many blocks on the chip ...

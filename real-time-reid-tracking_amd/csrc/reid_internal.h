@@ -150,6 +150,7 @@ struct Gemm16Params {
     _Float16* pack16;        // SPLIT builds: columns >= pack_from leave as [yh | yl'] f16 [M][2N] here instead of fp32 in C32
     int pack_from;
     int loader_prio;         // LDS-halo kernel: loader waves at raised issue priority
+    int frag_ahead;          // LDS-halo kernel: fragment reads pinned one k-step ahead of their MFMAs
     float acc_scale;
     int relu_from;
     int split_terms;            // 3 (default) or 4 (adds the xl.wl product)
@@ -321,6 +322,7 @@ struct reid_ctx {
     int debug_keep = 0;      // 0 off, 1 stage buffers + unfused kernels, 2 stage buffers + production kernels
     bool last_f16 = false;
     int f16_wide_splitk = 1;  // LDS-halo kernel, small launches with a long K loop: 128-wide tiles split four ways (REID_F16_WIDE_SPLITK=0: 64-wide)
+    int f16_frag_ahead = 1;   // LDS-halo kernel: fragments of k-step kk + 1 read before the MFMAs of kk (REID_F16_FRAG_AHEAD=0: compiler's order)
     int f16_loader_prio = 1;  // loader waves of the LDS-halo kernel at s_setprio 3: 1 = SPLIT builds (mode 2: 15.25 -> 15.10 ms per 1024 crops;
                               // the plain f16 build loses 0.6 %), 2 = all, 0 = none (REID_F16_LOADER_PRIO)
     int f16_loader_waves = 1; // LDS-halo kernel: 8 compute + 4 dedicated loader waves (REID_F16_LOADERS)
