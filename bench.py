@@ -102,26 +102,30 @@ def cpu_baseline_embed(sd, budget_s=12.0):
 
 
 class Job:
-    """Engine + stream + communicator of this rank, and the timing protocol of the bench contract."""
+    """Engine + stream + communicator of this rank, and the timing protocol of the bench contract.  Device, stream and every
+    synchronisation go through the C ABI (reid_ctx_create on LOCAL_RANK's device, the context's own non-blocking HIP stream,
+    reid_ctx_sync / reid_device_sync); torch is not imported on this path (parallel.RcclComm.from_env uses torch.distributed over
+    gloo once, to carry the 128-byte communicator id from rank 0 to the others)."""
 
     def __init__(self, args):
-        import torch
         from reid_amd import parallel
         from reid_amd.engine import get_engine
-        self.torch = torch
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != args.gpus:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, self.world, args.gpus))
+        if self.world != args.gpus:    # main() launches the ranks itself when WORLD_SIZE is unset; a launcher that disagrees is an error
+            print("[bench] FATAL: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world), file=sys.stderr, flush=True)
+            raise SystemExit(2)
         self.device = self.local_rank      # one rank per device: RCCL rejects two ranks on one GPU ("Duplicate GPU detected")
-        torch.cuda.set_device(self.device)
-        self.eng = get_engine(self.device)
-        # one explicit (non-null) HIP stream shared by torch (synchronize) and the C ABI launches + RCCL calls
-        self.stream = torch.cuda.Stream()
-        torch.cuda.set_stream(self.stream)
-        self.eng.set_stream(self.stream.cuda_stream)
+        if self.world > 1:
+            # ONE HIP runtime and ONE librccl per process.  torch.distributed (gloo) carries the communicator id between the ranks,
+            # and torch brings its own bundled libamdhip64 / librccl: imported AFTER libreid_hip.so they are loaded beside /opt/rocm's
+            # copies and the process aborts in the exit handlers (measured: "double free or corruption", rc -6).  Imported FIRST,
+            # libreid_hip.so and its dlopen("librccl.so.1") bind to the copies torch has already loaded - the stack every
+            # torch.distributed job on this pool runs on.  A single-rank run never imports torch.
+            import torch                    # noqa: F401
+            import torch.distributed        # noqa: F401
+        self.eng = get_engine(self.device)  # launches + RCCL calls run on the context's own (non-null, non-blocking) HIP stream
         # RCCL communicator behind the C ABI (reid_comm_init) - the only transport: if it cannot be brought up the RCCL error is
         # printed and the job exits non-zero.  REID_BENCH_COMM1=1: a real 1-rank communicator on one GPU
         try:
@@ -132,7 +136,7 @@ class Job:
 
     def barrier(self):
         self.comm.barrier()                  # RCCL all-reduce of one double + stream sync (local sync when world == 1)
-        self.torch.cuda.synchronize()
+        self.eng.device_sync()               # hipDeviceSynchronize through the C ABI: every stream of this rank's device
 
     def timed(self, step, steps, warmup):
         """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; MAX over ranks."""
@@ -148,9 +152,12 @@ class Job:
 
     def close(self):
         self.comm.close()
+        # the gloo group RcclComm.from_env made (world > 1).  Only if torch.distributed is ALREADY loaded: importing torch here,
+        # after libreid_hip.so has brought in /opt/rocm's HIP runtime and librccl, loads torch's bundled copies of both beside
+        # them and the process aborts in the libraries' exit handlers ("double free or corruption", rc -6)
+        dist = sys.modules.get("torch.distributed")
         try:
-            import torch.distributed as dist
-            if dist.is_initialized():
+            if dist is not None and dist.is_initialized():
                 dist.destroy_process_group()
         except Exception:
             pass
@@ -239,8 +246,8 @@ def run_embed(job, args):
     e = {}
     for mode, name in ((1, "f16"), (2, "f16x3"), (0, "f32")):
         eng.set_precision(mode)
-        eng.embed_u8_dev(crops.ptr, 256, emb_local.ptr)
-        e[name] = emb_local.numpy()[:256]
+        eng.embed_u8_dev(crops.ptr, min(256, n), emb_local.ptr)
+        e[name] = emb_local.numpy()[:min(256, n)]
     cos = (e["f16"] * e["f32"]).sum(1) / np.linalg.norm(e["f16"], axis=1) / np.linalg.norm(e["f32"], axis=1)
     cos_err = float((1 - cos).max())
     cos3 = (e["f16x3"] * e["f32"]).sum(1) / np.linalg.norm(e["f16x3"], axis=1) / np.linalg.norm(e["f32"], axis=1)
@@ -654,7 +661,8 @@ def run_all(job, args):
     `batch256` (configs[0]'s size: 256 crops + 256 x 256 distmat), `swin` (configs[2]), `market` (configs[4]), `tracking`
     (configs[3] stand-in, exact fp32 with the fp16-storage run nested as f16_path).  A sub-workload that raises is reported as
     {"error": ...}; one that does not come back within its time limit (a collective some rank never entered) ends the job
-    from a watchdog thread: rank 0 prints the line with what it has, every rank leaves with exit code 0."""
+    from a watchdog thread: rank 0 prints the line with what it has and EVERY rank leaves with a non-zero exit code (3), so the
+    launcher and the driver see the failure.  REID_BENCH_LIMIT_SCALE scales the time limits (tests)."""
     import copy
     import threading
     state = {"out": None, "current": None, "deadline": None}
@@ -667,7 +675,9 @@ def run_all(job, args):
                 if job.rank == 0 and state["out"] is not None:
                     state["out"][state["current"]] = {"error": "no answer within the time limit (watchdog)"}
                     emit(json.dumps(state["out"]))
-                os._exit(0)
+                print("[bench rank %d] watchdog: %s did not come back within its time limit" % (job.rank, state["current"]),
+                      file=sys.stderr, flush=True)
+                os._exit(3)                   # a lost collective / hung sub-workload is a FAILED run
 
     out = run_embed(job, args)
     state["out"] = out
@@ -677,7 +687,7 @@ def run_all(job, args):
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
-        state["current"], state["deadline"] = name, time.monotonic() + limit_s
+        state["current"], state["deadline"] = name, time.monotonic() + limit_s * float(os.environ.get("REID_BENCH_LIMIT_SCALE", "1"))
         try:
             res = fn(job, a)
             if res is not None:
@@ -713,7 +723,7 @@ def run_all(job, args):
         print("[bench rank %d] sub-workload failed: %r" % (job.rank, e), file=sys.stderr, flush=True)
         if job.rank == 0 and out is not None:
             emit(json.dumps(out))
-        os._exit(0)
+        os._exit(3)                           # ranks out of step: never report success
     state["deadline"] = None
     return out
 
@@ -732,14 +742,34 @@ def emit(line):
         os.write(_RESULT_FD, data)
 
 
-def main():
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a CHILD process
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), pass its stdout (the one JSON line of rank 0)
+    and stderr through, and return its exit code.  Runs before this process has touched torch, HIP or the library - nothing is
+    exec'ed or restarted in place.  The reference's own multi-GPU entry points are single commands too (reid/faiss_utils.py:121-135
+    IndexShards, image_reid_inference.py:211 DataParallel)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] --gpus %d without a launcher environment: starting %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def has_error(obj):
+    return isinstance(obj, dict) and ("error" in obj or any(has_error(v) for v in obj.values()))
+
+
+def main(argv=None):
     global _RESULT_FD
-    # dmabuf IPC for RCCL between the ranks of a node (the pool's driver has no legacy IPC: hipIpcGetMemHandle fails without it);
-    # must be in the environment before the first HIP call
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    sys.stdout.flush()
-    _RESULT_FD = os.dup(1)
-    os.dup2(2, 1)                      # native libraries that write to fd 1 now write to stderr
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -760,21 +790,36 @@ def main():
                          "exact-fp32 mode's parity bar (stage taps < 2e-5 of the reference, 1 - cos < 1e-5, 0 of 256 arg-mins differ on "
                          "both config-1 sets: tests/test_gpu_parity.py); f32 = exact fp32 MFMA (side run f32_path); f16 = fp16 storage / "
                          "fp32 accumulate (side run f16_path, north_star's 1e-3 cosine tolerance)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(argv, args.gpus)
     if args.workload == "batch256":
         args.crops = 256
 
+    # dmabuf IPC for RCCL between the ranks of a node (the pool's driver has no legacy IPC: hipIpcGetMemHandle fails without it);
+    # must be in the environment before the first HIP call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)                      # native libraries that write to fd 1 now write to stderr
+
     job = Job(args)
+    rc = 0
     try:
         fn = {"all": run_all, "embed": run_embed, "batch256": run_embed, "swin": run_swin, "tracking": run_tracking,
               "market": run_market}[args.workload]
         out = fn(job, args)
         if out is not None:
             emit(json.dumps(out))
+            if has_error(out):         # a sub-workload that raised is in the line as {"error": ...}: the run did not succeed
+                rc = 4
         job.barrier()
     finally:
         job.close()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -70,6 +70,15 @@ int reid_ctx_set_stream(reid_ctx* ctx, void* hip_stream);
 /* run on the HIP null (legacy default) stream - torch's default stream; its handle 0 means "own stream" to reid_ctx_set_stream */
 int reid_ctx_set_null_stream(reid_ctx* ctx);
 int reid_ctx_sync(reid_ctx* ctx);
+/* hipDeviceSynchronize on the context's device: every stream, not only the context's (the timing bracket of bench.py; replaces
+ * the torch.cuda.synchronize() a torch host would call around track_yolov5.py:178-253's loop) */
+int reid_device_sync(reid_ctx* ctx);
+/* The context's sticky fault word.  Kernels raise it when (a) in mode 2 an activation outside f16's range (or a NaN) reaches a
+ * site that splits operands into [xh | xl'], or (b) in any mode a non-finite embedding leaves the neck - a checkpoint that
+ * load_pretrained_weights (modification_tracking/reid_model_factory.py:158-210) accepted but this arithmetic cannot run.  While it
+ * is set, every embed / frame entry point, reid_ctx_sync and reid_device_sync return REID_ERR_STATE (the synchronising embed
+ * calls report a fault raised by their own work); reid_ctx_clear_fault drains the stream and resets it. */
+int reid_ctx_clear_fault(reid_ctx* ctx);
 /* crops per pass through the network (activation working set = chunk * 3.2 MB, kept inside the 256 MiB Infinity Cache) */
 int reid_ctx_set_chunk(reid_ctx* ctx, int crops_per_pass);
 /* arithmetic of the convolution GEMMs:
@@ -78,7 +87,10 @@ int reid_ctx_set_chunk(reid_ctx* ctx, int crops_per_pass);
  *   2 = "fp32-class": fp32 storage, every convolution (and every Linear / convolution of the Swin trunk) as three
  *       v_mfma_f32_32x32x16_f16 per multiply on hi/lo-split operands (x = xh + xl, xh = f16(x), xl' = f16((x - xh) 2^11)) with fp32 accumulation - 22-bit operands, the
  *       dropped xl.wl term at 2^-22; held to mode 0's parity thresholds (tests/test_gpu_parity.py).  Operands must lie inside
- *       f16's range: |activation| < 65504, |weight| < 32 (any trained ResNet18-IBN-SE by a wide margin). */
+ *       f16's range: |activation| < 65504, |weight| 2^11 < 65504 (any trained ResNet18-IBN-SE by a wide margin).  ENFORCED: mode 2
+ *       is refused (REID_ERR_ARG naming the tensor) when the loaded checkpoint has a convolution / Linear weight outside the
+ *       range, and so is loading such a checkpoint into a context already in mode 2; an activation outside the range raises the
+ *       context's fault word (reid_ctx_clear_fault below). */
 int reid_ctx_set_precision(reid_ctx* ctx, int mode);
 /* optional side information of the NEXT embed call(s): one index per image, consumed in order by the passes that follow (n images
  * in total; n = 0 clears).  ResNet18-IBN-SE: the camera of every crop - SERse18_IBN.forward(x, cam) adds cam_factor *

@@ -26,6 +26,15 @@ int reid_debug_gemm_f16(reid_ctx* ctx, int m, int n, int k, int cfg, int iters, 
 /* Times one Swin Linear layer [m][k] x [n][k]^T on random device data: mode bit 0 = fp16-storage GEMM (else exact fp32),
  * bits 1-2 = epilogue (0 bias, 1 bias + erf-GELU, 2 bias + fp32 residual into the fp32 stream). */
 int reid_debug_linear(reid_ctx* ctx, int m, int n, int k, int mode, int iters, float* ms_per_launch);
+/* One Swin Linear layer on host operands through the f16 linear build (correctness harness: identical input rows must give
+ * bit-identical output rows wherever they sit in a tile).  mode 1 = fp16 storage, 2 = fp32-class (split operands); flags bit 0 =
+ * erf-GELU, bit 1 = f16 output through the LDS-staged epilogue (mode 2: [yh | yl'], returned as yh + yl' / 2^11), else fp32
+ * output (+ res) through the buffer-store epilogue. */
+int reid_debug_linear_rows(reid_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, int m, int n, int k,
+                           int mode, int flags, float* out);
+/* Experiment switch of the fused distance + selection kernel: 0 product behaviour, 1 / 2 skip phases (INCOMPLETE results: timing
+ * only), 4 print candidate-list statistics. */
+int reid_debug_select_exp(reid_ctx* ctx, int mode);
 /* Switches the s_memtime stamps of the loader-wave conv kernel on / off (out_host [64*8*5] when disabling). */
 int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long long* out_host);
 /* Bare MFMA loop with fragments re-read from LDS (shape 32 = 32x32x16 f16, 16 = 16x16x32 f16). */

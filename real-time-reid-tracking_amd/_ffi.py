@@ -24,6 +24,8 @@ _SIGS = {
     "reid_ctx_set_stream": (_i, [_vp, _vp]),
     "reid_ctx_set_null_stream": (_i, [_vp]),
     "reid_ctx_sync": (_i, [_vp]),
+    "reid_device_sync": (_i, [_vp]),
+    "reid_ctx_clear_fault": (_i, [_vp]),
     "reid_ctx_set_chunk": (_i, [_vp, _i]),
     "reid_ctx_set_precision": (_i, [_vp, _i]),
     "reid_ctx_set_side_index": (_i, [_vp, _vp, _i]),
@@ -100,7 +102,7 @@ EXPORTS = tuple(sorted(_SIGS))
 
 DEBUG_LIB_PATH = os.path.join(_HERE, "libreid_hip_debug.so")
 DEBUG_EXPORTS = ("reid_debug_coissue", "reid_debug_comm_loopback", "reid_debug_conv_c64", "reid_debug_conv_diag", "reid_debug_conv_f16", "reid_debug_conv_f32",
-                 "reid_debug_feed", "reid_debug_gemm_f16", "reid_debug_knn_merge", "reid_debug_linear", "reid_debug_mfma_shape")   # include/reid_hip_debug.h
+                 "reid_debug_feed", "reid_debug_gemm_f16", "reid_debug_knn_merge", "reid_debug_linear", "reid_debug_linear_rows", "reid_debug_mfma_shape", "reid_debug_select_exp")   # include/reid_hip_debug.h
 
 _lib = None
 _dbg = None

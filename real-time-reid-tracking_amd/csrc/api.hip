@@ -60,6 +60,8 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F16_C64")) c->f16_c64 = atoi(e);   // 0 implicit GEMM, 1 layer-1 kernel, 2 + fused SE tail
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    HIP_TRY(hipHostMalloc((void**)&c->fault, 64, hipHostMallocMapped));   // the fault word kernels raise (reid_internal.h)
+    memset(c->fault, 0, 64);
     HIP_TRY(hipEventCreate(&c->t0));
     HIP_TRY(hipEventCreate(&c->t1));
     *out = c;
@@ -92,6 +94,7 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     hipEventDestroy(ctx->t0);
     hipEventDestroy(ctx->t1);
     hipStreamDestroy(ctx->own_stream);
+    if (ctx->fault) hipHostFree(ctx->fault);
     delete ctx;
     return REID_OK;
 }
@@ -112,11 +115,44 @@ extern "C" int reid_ctx_set_null_stream(reid_ctx* ctx) {
     return REID_OK;
 }
 
+// The sticky fault word (reid_internal.h): set by kernels, read here.  Every entry point that starts work calls this first
+// (CTX_ENTER) and the synchronising ones once more after their wait, so the call that produced a fault - or the next one - fails.
+int ctx_fault_status(reid_ctx* ctx) {
+    if (!ctx->fault) return REID_OK;
+    const volatile int* f = ctx->fault;
+    if (f[0]) {
+        reid_set_error("fp32-class arithmetic (reid_ctx_set_precision 2): an activation outside f16's range (|x| >= 65504, or NaN) reached a "
+                       "split-operand site; results since the last reid_ctx_clear_fault are invalid - run this checkpoint in mode 0");
+        return REID_ERR_STATE;
+    }
+    if (f[1]) {
+        reid_set_error("a non-finite embedding left the neck (overflow upstream); results since the last reid_ctx_clear_fault are invalid");
+        return REID_ERR_STATE;
+    }
+    return REID_OK;
+}
+
+extern "C" int reid_ctx_clear_fault(reid_ctx* ctx) {
+    ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->fault) ctx->fault[0] = ctx->fault[1] = 0;
+    return REID_OK;
+}
+
 extern "C" int reid_ctx_sync(reid_ctx* ctx) {
     ARG_CHECK(ctx);
     CTX_GUARD(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return REID_OK;
+    return ctx_fault_status(ctx);
+}
+
+// every stream of the context's device (bench.py's timing bracket: barrier + device-wide synchronise)
+extern "C" int reid_device_sync(reid_ctx* ctx) {
+    ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
+    HIP_TRY(hipDeviceSynchronize());
+    return ctx_fault_status(ctx);
 }
 
 extern "C" int reid_ctx_set_chunk(reid_ctx* ctx, int n) {
@@ -133,6 +169,14 @@ extern "C" int reid_ctx_set_precision(reid_ctx* ctx, int mode) {
         reid_set_error("reid_ctx_set_precision: mode must be 0 (exact fp32 MFMA), 1 (fp16 storage / fp32 accumulate) or "
                        "2 (fp32-class: hi/lo-split operands on the f16 matrix pipe, fp32 storage)");
         return REID_ERR_ARG;
+    }
+    if (mode == 2) {   // the split form [wh 2^11 | wh | wl'] needs |w| 2^11 inside f16: a checkpoint outside it stays on modes 0 / 1
+        const std::string& bad = !ctx->split_bad_se18.empty() ? ctx->split_bad_se18 : ctx->split_bad_swin;
+        if (!bad.empty()) {
+            reid_set_error("reid_ctx_set_precision(2): weight tensor %s of the loaded checkpoint is outside the range the fp32-class "
+                           "arithmetic can split (|w| 2^11 < 65504); use mode 0", bad.c_str());
+            return REID_ERR_ARG;
+        }
     }
     ctx->precision = mode;
     return REID_OK;
@@ -391,6 +435,17 @@ extern "C" int reid_seres18_load(reid_ctx* ctx, const float* blob, size_t n_floa
             tab[name] = {off, cnt};
         }
     }
+    // precision 2 operand range (include/reid_hip.h): convolution weights are split as [wh 2^11 | wh | wl'] f16, the stem's as
+    // [wh | wl' | wll']; reid_model_factory.load_pretrained_weights accepts any shape-compatible checkpoint
+    // (modification_tracking/reid_model_factory.py:158-210), so the range is checked here, on the host copy
+    const std::string bad = split_range_violation(blob, tab, {{".conv1.w", 65504.0f / 2048.0f}, {".conv2.w", 65504.0f / 2048.0f},
+                                                              {".ds.w", 65504.0f / 2048.0f}, {"stem.w", 65504.0f}});
+    if (!bad.empty() && ctx->precision == 2) {
+        reid_set_error("reid_seres18_load: weight tensor %s cannot be split for the fp32-class arithmetic selected on this context "
+                       "(reid_ctx_set_precision 2 needs |w| 2^11 < 65504); load it in mode 0", bad.c_str());
+        return REID_ERR_ARG;
+    }
+    ctx->split_bad_se18 = bad;
     Se18Weights& w = ctx->se18;
     if (w.blob) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -983,7 +1038,7 @@ extern "C" int reid_debug_stage(reid_ctx* ctx, int stage, float* out, size_t max
 
 extern "C" int reid_embed_u8_dev(reid_ctx* ctx, const uint8_t* d_crops, int n, float* d_emb, float* d_logits) {
     ARG_CHECK(ctx && d_crops && d_emb && n >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     const int nc = ctx->se18.num_class;
     for (int i = 0; i < n; i += ctx->chunk) {
         const int m = n - i < ctx->chunk ? n - i : ctx->chunk;
@@ -995,7 +1050,7 @@ extern "C" int reid_embed_u8_dev(reid_ctx* ctx, const uint8_t* d_crops, int n, f
 
 extern "C" int reid_embed_u8(reid_ctx* ctx, const uint8_t* crops, int n, float* emb, float* logits) {
     ARG_CHECK(ctx && crops && emb && n >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     if (n == 0) return REID_OK;
     const int nc = ctx->se18.num_class;
     uint8_t* d_in;
@@ -1009,12 +1064,12 @@ extern "C" int reid_embed_u8(reid_ctx* ctx, const uint8_t* crops, int n, float* 
     HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return REID_OK;
+    return ctx_fault_status(ctx);
 }
 
 extern "C" int reid_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, float* d_emb, float* d_logits) {
     ARG_CHECK(ctx && d_x && d_emb && n >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     const int nc = ctx->se18.num_class;
     const size_t img = (size_t)IMG_H * IMG_W * 3;
     for (int i = 0; i < n; i += ctx->chunk) {
@@ -1029,7 +1084,7 @@ extern "C" int reid_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, f
 
 extern "C" int reid_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, float* emb, float* logits) {
     ARG_CHECK(ctx && x && emb && n >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     if (n == 0) return REID_OK;
     const int nc = ctx->se18.num_class;
     const size_t img = (size_t)IMG_H * IMG_W * 3;
@@ -1042,7 +1097,7 @@ extern "C" int reid_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, float* 
     HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return REID_OK;
+    return ctx_fault_status(ctx);
 }
 
 // Enqueue only (no synchronisation): upload of the ragged crops, device-side resize + normalise, forward.  `tag` names the
@@ -1100,7 +1155,7 @@ int embed_ragged_enqueue(reid_ctx* ctx, const char* tag, const uint8_t* packed, 
 extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
                                     float* emb, float* logits) {
     ARG_CHECK(ctx && packed && offsets && hw && emb && n >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     if (n == 0) return REID_OK;
     const int nc = ctx->se18.num_class;
     float *d_emb, *d_log = nullptr;
@@ -1108,7 +1163,7 @@ extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const 
     HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return REID_OK;
+    return ctx_fault_status(ctx);
 }
 
 // Crops given as windows of ONE frame: DeepSort._get_features ([external] deep_sort.py) slices ori_img[y1:y2, x1:x2] per box
@@ -1117,7 +1172,7 @@ extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const 
 extern "C" int reid_embed_frame_u8(reid_ctx* ctx, const uint8_t* frame, int fh, int fw, const int32_t* boxes_xyxy, int n,
                                    float* emb, float* logits) {
     ARG_CHECK(ctx && frame && boxes_xyxy && emb && fh >= 1 && fw >= 1 && n >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     if (n == 0) return REID_OK;
     const int nc = ctx->se18.num_class;
     std::vector<long long> off(n);
@@ -1154,7 +1209,7 @@ extern "C" int reid_embed_frame_u8(reid_ctx* ctx, const uint8_t* frame, int fh, 
     HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return REID_OK;
+    return ctx_fault_status(ctx);
 }
 
 // ------------------------------------------------------------------------------------------------ matching
@@ -1265,7 +1320,7 @@ static int select_fused_dev(reid_ctx* ctx, const float* d_x, int m, const float*
     p.B = yp; p.ldb = ldy;
     p.M = m; p.N = n; p.K = ldx;
     p.metric = metric; p.k = k;
-    if (const char* e = getenv("REID_SELECT_EXP")) p.exp_skip = atoi(e);
+    p.exp_skip = ctx->select_exp;   // 0 in the product; experiments set it through libreid_hip_debug.so (reid_debug_select_exp)
     if (!dist_select_supported(p)) return 1;
     if (metric != REID_METRIC_DOT) {
         float *xx, *yy;

@@ -453,7 +453,7 @@ extern "C" int reid_bank_cost(reid_ctx* ctx, reid_bank* b, const int32_t* slots,
 // would block the caller until everything queued before it has finished.
 extern "C" int reid_frame_submit(reid_ctx* ctx, int slot, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int m) {
     ARG_CHECK(ctx && (slot == 0 || slot == 1) && m >= 0 && (m == 0 || (packed && offsets && hw)));
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     if (ctx->frame_pending[slot]) HIP_TRY(hipStreamSynchronize(ctx->stream));   // resubmitted without reid_frame_fetch: its staging is still in use
     ctx->frame_has[slot] = 0;
     ctx->frame_pending[slot] = 0;
@@ -477,7 +477,7 @@ extern "C" int reid_frame_submit(reid_ctx* ctx, int slot, const uint8_t* packed,
 extern "C" int reid_frame_cost(reid_ctx* ctx, int slot, reid_bank* b, const int32_t* slots, int t, int metric, float max_dist,
                                const double* tracks_t4, const double* dets_m4, int want_emb) {
     ARG_CHECK(ctx && (slot == 0 || slot == 1) && t >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     const int m = ctx->frame_m[slot];
     const bool want_cost = b && slots && t > 0 && m > 0, want_iou = tracks_t4 && dets_m4 && t > 0 && m > 0;
     if (want_cost) {
@@ -521,7 +521,7 @@ extern "C" int reid_frame_cost(reid_ctx* ctx, int slot, reid_bank* b, const int3
 
 extern "C" int reid_frame_fetch(reid_ctx* ctx, int slot, float* emb, float* cost_tm, double* iou_tm) {
     ARG_CHECK(ctx && (slot == 0 || slot == 1));
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     if (!(ctx->frame_has[slot] & 8)) {
         reid_set_error("reid_frame_fetch: no reid_frame_cost pending on slot %d", slot);
         return REID_ERR_STATE;
@@ -536,7 +536,7 @@ extern "C" int reid_frame_fetch(reid_ctx* ctx, int slot, float* emb, float* cost
     if (iou_tm) memcpy(iou_tm, pin_out, tm * 8);
     if (cost_tm) memcpy(cost_tm, pin_out + tm * 8, tm * 4);
     if (emb && (has & 4)) memcpy(emb, pin_out + tm * 12, (size_t)ctx->frame_m[slot] * 2048);
-    return REID_OK;
+    return ctx_fault_status(ctx);   // the frame's forward has completed: a fault it raised is reported with its results
 }
 
 extern "C" int reid_frame_update(reid_ctx* ctx, int slot, reid_bank* b, const int32_t* rows, const int32_t* slots, int n) {

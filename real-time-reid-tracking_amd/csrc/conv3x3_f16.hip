@@ -422,6 +422,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         const int m_blk = mtile * 256;
         const int m_valid = p.M - m_blk;
         float s1[TN], s2[TN];
+        float vmax = 0.f;   // largest packed magnitude (range guard: the accumulators cannot hold a NaN that did not start as an inf)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int lcol = wn * (BN / 2) + b * 32 + li;
@@ -450,6 +451,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
                         t1 += v;
                         t2 += v * v;
                         if (pk) {   // [yh | yl'] for the next convolution's loader (uniform per 32-column tile: pack_from % 32 == 0)
+                            vmax = fmaxf(vmax, fabsf(v));
                             const f16 hv = (f16)v;
                             f16* dst = p.pack16 + (long long)(m_blk + rowv[e]) * 2 * p.N + col;
                             dst[0] = hv;
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
             s1[b] = t1;
             s2[b] = t2;
         }
+        if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;   // a packed activation f16 cannot hold: the context reports it
         if (p.stats) {   // per 128 natural rows: waves wm 0,1 own rows 0..127, wm 2,3 rows 128..255 in every geometry
             float* stat_lds = (float*)lds;  // [4][BN][2]
 #pragma unroll
@@ -601,6 +604,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
 template <int TW, int IMGS, int LW, bool SPLIT = false>
 int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
+    p.fault = ctx->fault;
     p.loader_prio = ctx->f16_loader_prio == 2 || (ctx->f16_loader_prio == 1 && SPLIT);
     p.frag_ahead = ctx->f16_frag_ahead;
     const int nmt = (p.M + 255) / 256;
@@ -668,7 +672,8 @@ int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double fl
 // ---- "fp32-class" convolutions on the f16 matrix pipe (Gemm16Params: SPLIT build) ---------------------------------------------
 namespace {
 // fp32 [rows][C] -> f16 [rows][2C]: [xh | xl'], xh = f16(x), xl' = f16((x - xh) * 2^11); eight channels per thread
-__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ x, long long rows, int C, f16* __restrict__ out) {
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ x, long long rows, int C, f16* __restrict__ out,
+                                                         int* __restrict__ fault) {
     const int c8 = C >> 3;
     const long long i = blockIdx.x * 256LL + threadIdx.x;
     if (i >= rows * c8) return;
@@ -678,11 +683,14 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
     const f32x4 a = *(const f32x4*)(x + row * C + c), b = *(const f32x4*)(x + row * C + c + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     half8 hi, lo;
+    unsigned vm = 0u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+        vm = range_acc(vm, v[j]);
         hi[j] = (f16)v[j];
         lo[j] = (f16)((v[j] - (float)hi[j]) * 2048.0f);
     }
+    range_raise(fault, vm);
     *(half8*)(out + row * 2 * C + c) = hi;
     *(half8*)(out + row * 2 * C + C + c) = lo;
 }
@@ -706,7 +714,8 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out) {
     ARG_CHECK(C % 8 == 0);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)rows * C * 8.0);
-    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((rows * (C / 8) + 255) / 256)), dim3(256), 0, ctx->stream, x, rows, C, out);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((rows * (C / 8) + 255) / 256)), dim3(256), 0, ctx->stream, x, rows, C, out,
+                       ctx->fault);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

@@ -273,6 +273,80 @@ extern "C" int reid_debug_linear(reid_ctx* ctx, int m, int n, int k, int mode, i
     return st;
 }
 
+// Experiment switch of the fused distance + selection kernel (dist_select.hip: 1 = no filter phase, 2 = no list writes - both
+// leave results incomplete -, 4 = print candidate-list statistics).  Lives here so that no environment variable can thin out the
+// product's k-NN.
+extern "C" int reid_debug_select_exp(reid_ctx* ctx, int mode) {
+    ARG_CHECK(ctx && mode >= 0 && mode <= 4);
+    ctx->select_exp = mode;
+    return REID_OK;
+}
+
+// One Swin Linear layer on HOST operands through the f16 linear build of gemm_f16.hip, results back on the host (correctness
+// harness: row-position invariance, tests/test_gpu_parity.py).  mode 1 = fp16 storage (operands rounded to f16), 2 = fp32-class
+// (x packed to [xh | xl'], weights to [wh 2^11 | wh | wl'], K = 3 k virtual columns).  flags bit 0 = erf-GELU; bit 1 = f16 output
+// through the LDS-staged epilogue (mode 1: plain f16; mode 2: [yh | yl'], returned as yh + yl' / 2^11), else fp32 output through
+// the buffer-store epilogue with `res` (may be null) added.  out: [m][n] fp32.
+extern "C" int reid_debug_linear_rows(reid_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, int m, int n,
+                                      int k, int mode, int flags, float* out) {
+    ARG_CHECK(ctx && x && w && out && m > 0 && n > 0 && k > 0 && k % 32 == 0 && (mode == 1 || mode == 2) && ctx->se18.zero_page);
+    CTX_GUARD(ctx);
+    typedef _Float16 f16;
+    const bool act = flags & 1, f16out = flags & 2;
+    const int npad = (n + 63) / 64 * 64;
+    float *x32, *w32, *b32, *r32, *c32;
+    f16 *a16, *w16, *c16;
+    REID_TRY(ctx_ws(ctx, "dbgr.x", (size_t)m * k * 4, (void**)&x32));
+    REID_TRY(ctx_ws(ctx, "dbgr.w", (size_t)npad * k * 4, (void**)&w32));
+    REID_TRY(ctx_ws(ctx, "dbgr.bias", (size_t)npad * 4, (void**)&b32));
+    REID_TRY(ctx_ws(ctx, "dbgr.res", (size_t)m * n * 4, (void**)&r32));
+    REID_TRY(ctx_ws(ctx, "dbgr.out", (size_t)m * n * 4, (void**)&c32));
+    REID_TRY(ctx_ws(ctx, "dbgr.a16", (size_t)m * 2 * k * 2, (void**)&a16));
+    REID_TRY(ctx_ws(ctx, "dbgr.w16", (size_t)npad * 3 * k * 2, (void**)&w16));
+    REID_TRY(ctx_ws(ctx, "dbgr.c16", (size_t)m * 2 * n * 2, (void**)&c16));
+    HIP_TRY(hipMemsetAsync(w32, 0, (size_t)npad * k * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(b32, 0, (size_t)npad * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(w16, 0, (size_t)npad * 3 * k * 2, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(x32, x, (size_t)m * k * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(w32, w, (size_t)n * k * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (bias) HIP_TRY(hipMemcpyAsync(b32, bias, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (res) HIP_TRY(hipMemcpyAsync(r32, res, (size_t)m * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    Gemm16Params q;
+    memset(&q, 0, sizeof(q));
+    q.M = m; q.N = npad; q.n_real = n; q.lin = 1; q.act = act; q.col_shift = b32; q.zero_page = ctx->se18.zero_page;
+    if (mode == 1) {
+        REID_TRY(launch_f32_to_f16(ctx, x32, (size_t)m * k, a16));
+        REID_TRY(launch_f32_to_f16(ctx, w32, (size_t)npad * k, w16));
+        q.A = a16; q.lda = k; q.B = w16; q.ldb = k; q.K = k;
+    } else {
+        REID_TRY(launch_split_pack(ctx, x32, m, k, a16));
+        REID_TRY(launch_split_weights(ctx, w32, n, 1, k, 3, w16));
+        q.A = a16; q.lda = 2 * k; q.B = w16; q.ldb = 3 * k; q.K = 3 * k;
+        q.split_terms = 3; q.a_k = 2 * k; q.acc_scale = 1.0f / 2048.0f;
+    }
+    if (f16out) {
+        q.C = c16;
+        q.ldc = mode == 2 ? 2 * n : n;
+        q.pack_out = mode == 2;
+    } else {
+        q.C32 = c32; q.ldc = n; q.res32 = res ? r32 : nullptr;
+    }
+    REID_TRY(launch_gemm_f16(ctx, A16_DENSE, q, REID_K_CONV_GEMM, 0, 0));
+    if (!f16out) {
+        HIP_TRY(hipMemcpyAsync(out, c32, (size_t)m * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return REID_OK;
+    }
+    const size_t cols = mode == 2 ? 2 * (size_t)n : (size_t)n;
+    std::vector<f16> h((size_t)m * cols);
+    HIP_TRY(hipMemcpyAsync(h.data(), c16, h.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j)
+            out[(size_t)i * n + j] = mode == 2 ? (float)h[i * cols + j] + (float)h[i * cols + n + j] * (1.0f / 2048.0f) : (float)h[i * cols + j];
+    return REID_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ loop-back communicator (tests)
 // Several contexts of THIS process on ONE device act as the ranks of a job: every collective of csrc/comm.hip
 // (reid_allgather_dev and what is built on it - ragged row gathers, reid_frame_gather, reid_knn_gallery_sharded_dev -

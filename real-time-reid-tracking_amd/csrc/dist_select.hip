@@ -49,8 +49,8 @@ __device__ __forceinline__ float unpack_val(unsigned long long k) {
 
 template <int METRIC>
 __device__ __forceinline__ float dist_of(float dot, float rs, float cq) {   // the arithmetic of gemm_f32_dma.hip's dist_epilogue
-    if (METRIC == REID_METRIC_L2) return sqrtf(fmaxf((rs + cq) - 2.0f * dot, 1e-12f));
-    if (METRIC == REID_METRIC_L2SQR) return (rs + cq) - 2.0f * dot;
+    if (METRIC == REID_METRIC_L2) return sqrtf(fmaxf(l2sqr_of(dot, rs, cq), 1e-12f));
+    if (METRIC == REID_METRIC_L2SQR) return l2sqr_of(dot, rs, cq);
     if (METRIC == REID_METRIC_COS_HALF) return (1.0f - dot / (sqrtf(rs) * cq)) / 2.0f;
     if (METRIC == REID_METRIC_COS) return 1.0f - dot / (sqrtf(rs) * cq);
     return dot;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void dist_select_kernel(const SelectParams 
                     unsigned pass = 0;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const float w = METRIC == REID_METRIC_L2 ? (rs[e] + cq) - 2.0f * acc[a][b][e] : dist_of<METRIC>(acc[a][b][e], rs[e], cq);
+                        const float w = METRIC == REID_METRIC_L2 ? l2sqr_of(acc[a][b][e], rs[e], cq) : dist_of<METRIC>(acc[a][b][e], rs[e], cq);
                         v[e] = w;
                         const int row = rbase + (e & 3) + 8 * (e >> 2);
                         pass |= (colok && row < rows_a && w <= th[e]) ? (1u << e) : 0u;

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(float* __restrict__ x, co
 // written back in fp32 (conv2 is the only reader of this tensor).  One pass instead of in_apply + split_pack.
 __global__ __launch_bounds__(256) void in_apply_pack_kernel(const float* __restrict__ x, const float* __restrict__ stats, int tiles, int c,
                                                             int half, int hw, int rows, const float* __restrict__ in_gamma,
-                                                            const float* __restrict__ in_beta, _Float16* __restrict__ packed, int in_only) {
+                                                            const float* __restrict__ in_beta, _Float16* __restrict__ packed, int in_only,
+                                                            int* __restrict__ fault) {
     __shared__ float sa[512], sb[512];
     const int img = blockIdx.y, tid = threadIdx.x;
     for (int ch = tid; ch < c; ch += 256) {
@@ -205,13 +206,17 @@ __global__ __launch_bounds__(256) void in_apply_pack_kernel(const float* __restr
     const int q = (in_only ? half : c) >> 2;
     const long long pix0 = (long long)img * hw + (long long)blockIdx.x * rows;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    unsigned vm = 0u;
     for (int i = tid; i < rows * q; i += 256) {
         const int row = i / q, cc = i - row * q;
         f32x4 v = *(const f32x4*)(x + (pix0 + row) * c + cc * 4);
         if (cc * 4 < half) {   // half % 4 == 0: a chunk is entirely InstanceNorm or entirely BatchNorm
             const f32x4 a = *(const f32x4*)&sa[cc * 4], b = *(const f32x4*)&sb[cc * 4];
             v = v * a + b;
+            vm = range_acc(range_acc(range_acc(range_acc(vm, v.x), v.y), v.z), v.w);   // before the ReLU: max(NaN, 0) is 0
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else {
+            vm = range_acc(range_acc(range_acc(range_acc(vm, v.x), v.y), v.z), v.w);
         }
         const h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         const h4 lo = {(_Float16)((v.x - (float)hi.x) * 2048.0f), (_Float16)((v.y - (float)hi.y) * 2048.0f),
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(256) void in_apply_pack_kernel(const float* __restr
         *(h4*)(packed + (pix0 + row) * 2 * c + cc * 4) = hi;
         *(h4*)(packed + (pix0 + row) * 2 * c + c + cc * 4) = lo;
     }
+    range_raise(fault, vm);
 }
 
 // ---- SEBlock (SERes18_IBN.py:32-41): s = sigmoid(W2 . relu(W1 . avgpool(y))), no bias, norm layer disabled (:36).
@@ -272,7 +278,7 @@ __global__ void se_combine_kernel(const float* __restrict__ y, const float* __re
 __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ stats, int tiles, int c, int mid, int hw,
                                                       const float* __restrict__ w1, const float* __restrict__ w2,
                                                       const float* __restrict__ y, const float* __restrict__ sc, int rows,
-                                                      float* __restrict__ out, _Float16* __restrict__ packed) {
+                                                      float* __restrict__ out, _Float16* __restrict__ packed, int* __restrict__ fault) {
     __shared__ __attribute__((aligned(16))) float pooled[512];
     __shared__ float hid[64];
     __shared__ __attribute__((aligned(16))) float gate[512];
@@ -320,12 +326,14 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
     const int c4n = c >> 2;
     const long long base = ((long long)img * hw + (long long)blockIdx.x * rows) * c;
     const int total4 = rows * c4n;
+    unsigned vm = 0u;
     for (int i = tid; i < total4; i += 256) {
         const int cc = i % c4n;
         const f32x4 yy = *(const f32x4*)(y + base + (long long)i * 4);
         const f32x4 rr = *(const f32x4*)(sc + base + (long long)i * 4);
         const f32x4 ss = *(const f32x4*)&gate[cc * 4];
         f32x4 o = ss * yy + rr;
+        if (packed) vm = range_acc(range_acc(range_acc(range_acc(vm, o.x), o.y), o.z), o.w);   // before the ReLU: max(NaN, 0) is 0
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         if (out) *(f32x4*)(out + base + (long long)i * 4) = o;
         if (packed) {   // precision 2: the next block's convolutions read [oh | ol'] (ol' = f16((o - oh) 2^11)): written here, not by a pass of its own
@@ -338,6 +346,7 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
             *(h4*)(packed + pix * 2 * c + c + cc * 4) = lo;
         }
     }
+    range_raise(fault, vm);
 }
 
 // ---- GeM (attention_pooling.py:58-60) + BNNeck (SERes18_IBN.py:268).  grid (c / 64, images); 256 threads = 16 channel quads x
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void gem_neck_kernel(const float* __restrict__ x, int hw, int c,
                                                        const float* __restrict__ p_ptr, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float* __restrict__ gem_out,
-                                                       float* __restrict__ emb) {
+                                                       float* __restrict__ emb, int* __restrict__ fault) {
     __shared__ float part[16][64 + 1];
     const int img = blockIdx.y, c0 = blockIdx.x * 64;
     const int quad = threadIdx.x & 15, pg = threadIdx.x >> 4;
@@ -372,7 +381,9 @@ __global__ __launch_bounds__(256) void gem_neck_kernel(const float* __restrict__
         const float m = t / (float)hw;
         const float g = cube ? cbrtf(m) : powf(m, 1.0f / p);
         if (gem_out) gem_out[(long long)img * c + ch] = g;
-        emb[(long long)img * c + ch] = g * scale[ch] + shift[ch];
+        const float ev = g * scale[ch] + shift[ch];
+        emb[(long long)img * c + ch] = ev;
+        if (fault && !(fabsf(ev) < INFINITY)) fault[1] = 1;   // a non-finite embedding: the context reports it (reid_ctx.fault)
     }
 }
 
@@ -455,7 +466,7 @@ int launch_in_apply_pack(reid_ctx* ctx, const float* x, const float* stats, int 
     while ((long long)n_img * (hw / rows) < 512 && rows > 16) rows >>= 1;
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * (in_half_only ? half : c) * 8.0);
     hipLaunchKernelGGL(in_apply_pack_kernel, dim3(hw / rows, n_img), dim3(256), 0, ctx->stream, x, stats, tiles, c, half, hw, rows,
-                       in_gamma, in_beta, packed, in_half_only ? 1 : 0);
+                       in_gamma, in_beta, packed, in_half_only ? 1 : 0, ctx->fault);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
@@ -494,7 +505,7 @@ int launch_se_tail(reid_ctx* ctx, const float* stats, int n_img, int tiles, int 
     const int slices = tail_slices(n_img, hw);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 12.0);
     hipLaunchKernelGGL(se_tail_kernel, dim3(slices, n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2, y, sc,
-                       hw / slices, out, packed);
+                       hw / slices, out, packed, ctx->fault);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
@@ -504,7 +515,8 @@ int launch_gem_neck(reid_ctx* ctx, const float* x, int n_img, int hw, int c, con
                     const float* shift, float* gem_out, float* emb) {
     ARG_CHECK(c % 64 == 0);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 4.0);
-    hipLaunchKernelGGL(gem_neck_kernel, dim3(c / 64, n_img), dim3(256), 0, ctx->stream, x, hw, c, p, scale, shift, gem_out, emb);
+    hipLaunchKernelGGL(gem_neck_kernel, dim3(c / 64, n_img), dim3(256), 0, ctx->stream, x, hw, c, p, scale, shift, gem_out, emb,
+                       ctx->fault);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

@@ -117,7 +117,7 @@ __global__ void se_combine_f16_kernel(const f16* __restrict__ y, const f16* __re
 __global__ __launch_bounds__(256) void gem_neck_f16_kernel(const f16* __restrict__ x, int hw, int c,
                                                            const float* __restrict__ p_ptr, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float* __restrict__ gem_out,
-                                                           float* __restrict__ emb) {
+                                                           float* __restrict__ emb, int* __restrict__ fault) {
     __shared__ float part[32][64 + 1];
     const int img = blockIdx.y, c0 = blockIdx.x * 64;
     const int oct = threadIdx.x & 7, pg = threadIdx.x >> 3;
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void gem_neck_f16_kernel(const f16* __restrict
         const float m = t / (float)hw;
         const float g = cube ? cbrtf(m) : powf(m, 1.0f / p);
         if (gem_out) gem_out[(long long)img * c + ch] = g;
-        emb[(long long)img * c + ch] = g * scale[ch] + shift[ch];
+        const float ev = g * scale[ch] + shift[ch];
+        emb[(long long)img * c + ch] = ev;
+        if (fault && !(fabsf(ev) < INFINITY)) fault[1] = 1;   // a non-finite embedding (f16 overflow upstream): reid_ctx.fault
     }
 }
 
@@ -353,7 +355,7 @@ int launch_gem_neck_f16(reid_ctx* ctx, const f16* x, int n_img, int hw, int c, c
     ARG_CHECK(c % 64 == 0);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 2.0);
     hipLaunchKernelGGL(gem_neck_f16_kernel, dim3(c / 64, n_img), dim3(256), 0, ctx->stream, x, hw, c, p, scale, shift, gem_out,
-                       emb);
+                       emb, ctx->fault);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

@@ -55,6 +55,20 @@ __device__ __forceinline__ float gelu_f16_storage(float v) {
     return fmaf(h, copysignf(erfz, v), h);
 }
 
+// fp32 -> f16 with the fp32 value MATERIALISED first.  Without the (empty) asm the compiler folds the conversion into the
+// instruction that produced the value - v_fma_mixlo_f16 computes fma(a, b, c) and rounds the exact result ONCE to f16 - and it
+// does so per unrolled instance: in the round-3 build 63 of the 64 GELU instances of the 128-wide linear kernel ended in
+// v_fma_mixlo_f16 and one (the element whose conversion was sunk below the loop's back edge) in v_fmac_f32 + v_cvt_f16_f32, which
+// rounds twice (fp32, then f16).  The two differ by one f16 ulp whenever the fp32 rounding lands on an f16 tie (2^-13 of the
+// values), so 1/64 of a tile's rows - the rows of that accumulator register - disagreed with the others on ~2e-6 of their
+// elements: an image's Swin embedding depended on the tile row its tokens landed on (tests/test_gpu_parity.py,
+// test_full_size_config2_swin_properties; tools/linear_row_check.py, tools/swin_position_probe.py).  Every f16 result of the
+// linear epilogues goes through here: fp32 arithmetic, then one v_cvt_f16_f32, in every instance of every instantiation.
+__device__ __forceinline__ f16 cvt_f16_rn(float v) {
+    asm("" : "+v"(v));
+    return (f16)v;
+}
+
 // LIN: the linear-layer epilogue (Swin) instead of the convolution epilogue - a template parameter, not a run-time branch:
 // carrying both epilogues cost the 256-wide conv instantiations 66 more spilled VGPRs (72 -> 214 us per launch)
 // (launch bound = waves per SIMD: the linear builds up to 128 columns must stay within 128 VGPRs so that TWO blocks share a CU)
@@ -344,6 +358,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
 
     if constexpr (SPLIT) {   // fp32 epilogue straight from the accumulators (see conv3x3_f16.hip, SPLIT build)
         float s1[TN], s2[TN];
+        float vmax = 0.f;   // largest packed magnitude (range guard, conv3x3_f16.hip)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int lcol = wn * WTN + b * 32 + li;
@@ -372,6 +387,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
                         t1 += v;
                         t2 += v * v;
                         if (pk) {   // [yh | yl'] for the next convolution's loader (uniform per 32-column tile: pack_from % 32 == 0)
+                            vmax = fmaxf(vmax, fabsf(v));
                             const f16 hv = (f16)v;
                             f16* dst = p.pack16 + (long long)(m_blk + rl) * 2 * p.N + col;
                             dst[0] = hv;
@@ -385,6 +401,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
             s1[b] = t1;
             s2[b] = t2;
         }
+        if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;
         if (p.stats) {   // per 128-row tile: the block covers two of them
             float* stat_lds = (float*)lds;  // [WM][BN][2]
 #pragma unroll
@@ -436,10 +453,10 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
-                            float v = acc[a][b][e] * asc + bias;
+                            float v = fmaf(acc[a][b][e], asc, bias);
                             if constexpr (ACT) v = gelu_f16_storage(v);
                             acc[a][b][e] = v;   // kept for the low tile of a packed output
-                            tile[(row0 + a * 32 + (e & 3) + 8 * (e >> 2)) * BN + lcol] = (f16)v;
+                            tile[(row0 + a * 32 + (e & 3) + 8 * (e >> 2)) * BN + lcol] = cvt_f16_rn(v);
                         }
                 }
             };
@@ -454,6 +471,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
             }
             if (p.pack_out) {   // [yh | yl']: the low tile (yl' = f16((y - yh) 2^11)) goes n_real columns further
                 __syncthreads();
+                float vmax = 0.f;
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     const int lcol = wn * WTN + b * 32 + li;
@@ -462,9 +480,11 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const float v = acc[a][b][e];
-                            tile[(row0 + a * 32 + (e & 3) + 8 * (e >> 2)) * BN + lcol] = (f16)((v - (float)(f16)v) * 2048.0f);
+                            vmax = fmaxf(vmax, fabsf(v));
+                            tile[(row0 + a * 32 + (e & 3) + 8 * (e >> 2)) * BN + lcol] = cvt_f16_rn((v - (float)cvt_f16_rn(v)) * 2048.0f);
                         }
                 }
+                if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;   // range guard (rows past M hold finite zeros-input results)
                 __syncthreads();
                 for (int idx = tid; idx < BM * C8; idx += 512) {
                     const int row = idx / C8, c8 = idx - row * C8;
@@ -502,7 +522,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
                         }
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
-                            float v = acc[a][b][e] * asc + bias;
+                            float v = fmaf(acc[a][b][e], asc, bias);
                             if constexpr (ACT) v = gelu_f16_storage(v);
                             if constexpr (RES) v += res[e];
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff, (a * 32 + (e & 3) + 8 * (e >> 2)) * ldc * 4, 0);
@@ -548,12 +568,12 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
                         if (colv[b] >= n_real) continue;
-                        float v = acc[a][b][e] * asc + bias[b];
-                        if (p.act == 1) v = gelu_f16_storage(v);
+                        float v = fmaf(acc[a][b][e], asc, bias[b]);   // the same explicit operations as the two fast forms: a ragged last
+                        if (p.act == 1) v = gelu_f16_storage(v);        // tile must give its rows what a full tile would
                         const long long o = obase + colv[b];
                         if (p.res32) v += p.res32[o];
                         if (p.C32) p.C32[o] = v;
-                        else p.C[o] = (f16)v;
+                        else p.C[o] = cvt_f16_rn(v);
                     }
                 }
         };
@@ -765,7 +785,9 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
 }  // namespace
 
 // strided 3x3 and 1x1 convolutions of the "fp32-class" mode: one build (128-wide tile, BK 32, three stages: two blocks per CU)
-int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes) {
+int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p_in, int kind, double flops, double bytes) {
+    Gemm16Params p = p_in;
+    p.fault = ctx->fault;
     ARG_CHECK(p.M > 0 && p.M % 128 == 0 && p.N % 128 == 0 && p.K % 32 == 0 && p.ldb % 8 == 0 && p.C32 && p.zero_page &&
               (p.split_terms == 3 || p.split_terms == 4) && p.Cin % (64 * p.split_terms) == 0 && p.K == p.R * p.S * p.Cin);
     prof_begin(ctx, kind, flops, bytes);
@@ -776,7 +798,9 @@ int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double
     return REID_OK;
 }
 
-int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, double flops, double bytes) {
+int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p_in, int kind, double flops, double bytes) {
+    Gemm16Params p = p_in;
+    p.fault = ctx->fault;
     ARG_CHECK(p.M > 0 && (p.lin || p.M % 128 == 0) && p.N % 64 == 0 && p.K % 32 == 0 && p.ldb % 8 == 0);
     if (amode == A16_IM2COL) ARG_CHECK(p.Cin % 32 == 0 && p.K == p.R * p.S * p.Cin && p.zero_page);
     if (amode == A16_STEM) ARG_CHECK((p.K == 256 || p.K == 224) && p.Hp >= p.H + 6 && p.Wp >= p.W + 8);

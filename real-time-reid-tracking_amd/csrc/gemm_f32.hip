@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
                     float rs = 0.f;
                     if (ok && p.row_sq) rs = p.row_sq[row];
                     switch (p.metric) {
-                        case REID_METRIC_L2: v = sqrtf(fmaxf((rs + cq) - 2.0f * v, 1e-12f)); break;
-                        case REID_METRIC_L2SQR: v = (rs + cq) - 2.0f * v; break;
+                        case REID_METRIC_L2: v = sqrtf(fmaxf(l2sqr_of(v, rs, cq), 1e-12f)); break;
+                        case REID_METRIC_L2SQR: v = l2sqr_of(v, rs, cq); break;
                         case REID_METRIC_COS_HALF: v = (1.0f - v / (sqrtf(rs) * cq)) / 2.0f; break;
                         case REID_METRIC_COS: v = 1.0f - v / (sqrtf(rs) * cq); break;
                         default: break;

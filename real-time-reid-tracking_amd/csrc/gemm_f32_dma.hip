@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                 for (int e = 0; e < 16; ++e) {
                     float v = acc[a][b][e];
                     const float rs = rsq[e];
-                    if (METRIC == REID_METRIC_L2) v = sqrtf(fmaxf((rs + cq) - 2.0f * v, 1e-12f));
-                    else if (METRIC == REID_METRIC_L2SQR) v = (rs + cq) - 2.0f * v;
+                    if (METRIC == REID_METRIC_L2) v = sqrtf(fmaxf(l2sqr_of(v, rs, cq), 1e-12f));
+                    else if (METRIC == REID_METRIC_L2SQR) v = l2sqr_of(v, rs, cq);
                     else if (METRIC == REID_METRIC_COS_HALF) v = (1.0f - v / (sqrtf(rs) * cq)) / 2.0f;
                     else if (METRIC == REID_METRIC_COS) v = 1.0f - v / (sqrtf(rs) * cq);
                     if (full) {

@@ -183,7 +183,7 @@ int gemm_nt_dev(reid_ctx* ctx, const float* a, int m, const float* b, int n, int
 // data_transforms.py:56-130); out: [n][512 + num_class].  flip_tta != 0 averages the descriptor of the mirrored image.
 extern "C" int reid_descriptor_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int flip_tta, float* d_out) {
     ARG_CHECK(ctx && d_x && d_out && n >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     if (n == 0) return REID_OK;
     int de = 0, nc = 0;
     REID_TRY(reid_seres18_dims(ctx, &de, &nc));
@@ -219,7 +219,7 @@ extern "C" int reid_descriptor_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int
 
 extern "C" int reid_descriptor_f32_nchw(reid_ctx* ctx, const float* x, int n, int flip_tta, float* out) {
     ARG_CHECK(ctx && x && out && n >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     if (n == 0) return REID_OK;
     int de = 0, nc = 0;
     REID_TRY(reid_seres18_dims(ctx, &de, &nc));
@@ -231,7 +231,7 @@ extern "C" int reid_descriptor_f32_nchw(reid_ctx* ctx, const float* x, int n, in
     REID_TRY(reid_descriptor_f32_nchw_dev(ctx, dx, n, flip_tta, dout));
     HIP_TRY(hipMemcpyAsync(out, dout, (size_t)n * (de + nc) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return REID_OK;
+    return ctx_fault_status(ctx);
 }
 
 // d_x [n][d] is updated in place; cams is a HOST array of camera ids >= 0 (ids without rows are skipped: the reference's

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdio.h>
 #include <string>
 #include <map>
 #include <tuple>
@@ -156,7 +157,24 @@ struct Gemm16Params {
     int split_terms;            // 3 (default) or 4 (adds the xl.wl product)
     int pack_out;               // LIN staged epilogue: C is [yh | yl'] f16 [M][2 n_real] (hi tile at column n_blk, low tile n_real further)
     int a_k;                    // LIN dense build with split_terms != 0: columns of A ([xh | xl'] = 2 K); K-tile k0 reads column k0 % a_k
+    int* fault;                 // reid_ctx.fault (may be null): [0] raised when a value packed as [yh | yl'] lies outside f16's range
 };
+
+// |x - y|^2 from the dot product and the squared norms: ONE explicit form for every kernel that computes or bounds a distance
+// (gemm_f32.hip, gemm_f32_dma.hip, dist_select.hip's bound pass and sweep).  Left as (rs + cq) - 2 * dot the multiply-add is
+// contracted or not per call site by the compiler, and a bound computed one way need not bound a value computed the other way.
+__device__ __forceinline__ float l2sqr_of(float dot, float rs, float cq) { return fmaf(-2.0f, dot, rs + cq); }
+
+// precision 2 range guard (reid_ctx.fault; include/reid_hip.h, reid_ctx_set_precision): every site that writes a split operand
+// [xh | xl'] keeps the largest magnitude it packed - as bits, so that NaN > inf > every finite value - and raises fault[0] when f16
+// cannot hold it.  fault[1]: a non-finite embedding left the neck.
+__device__ __forceinline__ unsigned range_acc(unsigned m, float v) {
+    const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+    return b > m ? b : m;
+}
+__device__ __forceinline__ void range_raise(int* fault, unsigned m) {
+    if (fault && m >= 0x477fe000u) fault[0] = 1;   // 65504.0f
+}
 
 // reciprocals for the scatter epilogues: floor(x / d) == umulhi(x, ceil(2^32 / d)) for x < 2^32 / d (rows of one pass: < 2^20)
 template <class P>
@@ -339,6 +357,8 @@ struct reid_ctx {
     int stem_split = 1;      // precision 2: the 7x7 stem on split f16 operands (REID_STEM_SPLIT=0: the fp32-pipe stem + split_pack)
     int f32_stem_pool = 1;   // fp32 path: MaxPool(3,2,1) on the stem kernel's accumulators (REID_F32_STEMPOOL=0: separate kernel)
     int split_terms = 3;     // precision 2: f16 products per multiply (REID_SPLIT_TERMS=4 adds the low x low product)
+    int select_exp = 0;      // experiments only (reid_debug_select_exp, debug.hip): 1 / 2 skip phases of the fused selection (results
+                             // are then incomplete), 4 prints candidate-list statistics
     int select_two_pass = 0; // REID_SELECT_TWO_PASS=1: arg-min / k-NN through the full distance matrix (A/B against dist_select.hip)
     int swin_stop = -1;      // diagnostics (REID_SWIN_STOP = block * 10 + phase): skip the rest of the Swin blocks after that point
     int swin_fold = 1;       // Swin, fp16-storage mode: to_out and post_proj folded into one Linear (REID_SWIN_FOLD=0: two launches)
@@ -358,7 +378,40 @@ struct reid_ctx {
     const char* frame_out[2] = {nullptr, nullptr};
     float* stage_ptr[11] = {nullptr};
     unsigned long long* conv_diag = nullptr;   // experiments (debug.hip): stamps of the loader-wave conv kernel
+    // precision 2 guards (include/reid_hip.h, reid_ctx_set_precision): the first conv / linear weight of the loaded checkpoint that
+    // cannot be split ([wh 2^11 | wh | wl'] needs |w| 2^11 < 65504), empty when all can ...
+    std::string split_bad_se18, split_bad_swin;
+    // ... and a sticky fault word in pinned host memory that kernels raise: REID_FAULT_RANGE = an activation outside f16's range
+    // reached a split ([xh | xl']) site, REID_FAULT_NONFINITE = a non-finite embedding left the neck.  Every entry point returns
+    // REID_ERR_STATE while it is set (ctx_fault_status); reid_ctx_clear_fault resets it.
+    int* fault = nullptr;
 };
+enum { REID_FAULT_RANGE = 1, REID_FAULT_NONFINITE = 2 };
+int ctx_fault_status(reid_ctx* ctx);   // api.hip: REID_OK, or REID_ERR_STATE + message when the fault word is set
+
+// precision 2: largest |w| of the named tensors against the bound their split form allows; returns "" or "name (max |w| = v)"
+inline std::string split_range_violation(const float* blob, const std::map<std::string, std::pair<size_t, size_t>>& tab,
+                                         const std::vector<std::pair<std::string, float>>& suffix_bound) {
+    for (const auto& kv : tab) {
+        for (const auto& sb : suffix_bound) {
+            const std::string& suf = sb.first;
+            if (kv.first.size() < suf.size() || kv.first.compare(kv.first.size() - suf.size(), suf.size(), suf) != 0) continue;
+            float mx = 0.f;
+            const float* w = blob + kv.second.first;
+            for (size_t i = 0; i < kv.second.second; ++i) {
+                const float a = w[i] < 0 ? -w[i] : w[i];
+                if (!(a <= mx)) mx = a;        // NaN counts as a violation
+            }
+            if (!(mx < sb.second)) {
+                char buf[160];
+                snprintf(buf, sizeof(buf), "%s (max |w| = %g, limit %g)", kv.first.c_str(), (double)mx, (double)sb.second);
+                return buf;
+            }
+            break;
+        }
+    }
+    return std::string();
+}
 
 // convolution launchers of the two arithmetic modes (api.hip); also used by the experiment harnesses in debug.hip
 int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
@@ -385,6 +438,10 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 #define CTX_GUARD(ctx) DeviceGuard _dev_guard((ctx)->device)
+// entry points that start new work: device guard + the sticky fault word (a raised fault makes every later call fail loudly)
+#define CTX_ENTER(ctx)            \
+    CTX_GUARD(ctx);               \
+    REID_TRY(ctx_fault_status(ctx))
 
 void swin_release(reid_ctx* ctx);   // frees the Swin weights held for this context (swin.hip)
 int ctx_ws(reid_ctx* ctx, const char* name, size_t bytes, void** out);  // grow-only named workspace

@@ -46,7 +46,8 @@ __device__ __forceinline__ unsigned split_pair(float x) {     // low 16 bits: xh
 template <bool U8>
 __global__ __launch_bounds__(512, 1) void stem_split_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            int tiles_per_block, float* __restrict__ out, f16* __restrict__ packed) {
+                                                            int tiles_per_block, float* __restrict__ out, f16* __restrict__ packed,
+                                                            int* __restrict__ fault) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const img_h = smem;                            // [RING][144] pixels of 4 f16
     unsigned char* const img_l = img_h + RING * PITCH;
@@ -134,10 +135,12 @@ __global__ __launch_bounds__(512, 1) void stem_split_kernel(const void* __restri
     for (int e = 0; e < 8; ++e) prev[e] = -INFINITY;                 // row -1 of the image: MaxPool2d pads with -inf
     float* const pool_img = out + (long long)img * (OUT_H / 2) * (OUT_W / 2) * 64;
     f16* const pack_img = packed ? packed + (long long)img * (OUT_H / 2) * (OUT_W / 2) * 128 : nullptr;
+    unsigned vmag = 0u;   // range guard (reid_ctx.fault): largest magnitude packed by this lane
     auto store = [&](int t, int col, float v) __attribute__((always_inline)) {                      // pooled pixel (t, col), this lane's channel
         const long long pix = (long long)t * (OUT_W / 2) + col;
         pool_img[pix * 64 + cb * 32 + li] = v;
         if (pack_img) {
+            vmag = range_acc(vmag, v);
             const unsigned hl = split_pair(v);
             *(unsigned short*)(pack_img + pix * 128 + cb * 32 + li) = (unsigned short)hl;
             *(unsigned short*)(pack_img + pix * 128 + 64 + cb * 32 + li) = (unsigned short)(hl >> 16);
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(512, 1) void stem_split_kernel(const void* __restri
     if (defer) epilogue(t_last, vkeep);
     __syncthreads();
     finish_first_column(t0 + tiles_per_block - 1);
+    range_raise(fault, vmag);
 }
 
 constexpr int SMEM = 2 * RING * PITCH + 2 * 64 * WROW + 2 * 4 * 64 * 4;
@@ -274,8 +278,9 @@ int launch_stem_split(reid_ctx* ctx, const void* x, bool is_u8, int n, const flo
     const double flops = 2.0 * n * OUT_H * OUT_W * 64 * 147.0;
     const double bytes = (double)n * IMG_H * IMG_W * 3 * (is_u8 ? 1.0 : 4.0) + (double)n * OUT_H * OUT_W * 64 * (packed ? 2.0 : 1.0) + 64 * 147 * 4.0;
     prof_begin(ctx, REID_K_CONV_GEMM, flops, bytes);
-    if (is_u8) hipLaunchKernelGGL((stem_split_kernel<true>), dim3(grid), dim3(512), SMEM, ctx->stream, x, wgt, scale, shift, tpb, out, packed);
-    else hipLaunchKernelGGL((stem_split_kernel<false>), dim3(grid), dim3(512), SMEM, ctx->stream, x, wgt, scale, shift, tpb, out, packed);
+    if (is_u8) hipLaunchKernelGGL((stem_split_kernel<true>), dim3(grid), dim3(512), SMEM, ctx->stream, x, wgt, scale, shift, tpb, out, packed,
+                                  ctx->fault);
+    else hipLaunchKernelGGL((stem_split_kernel<false>), dim3(grid), dim3(512), SMEM, ctx->stream, x, wgt, scale, shift, tpb, out, packed, ctx->fault);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

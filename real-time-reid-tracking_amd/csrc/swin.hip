@@ -200,7 +200,7 @@ __device__ __forceinline__ void st4(f16* p, f32x4 v) {
 template <typename T>
 __global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ qkv, int ldq, int n_img, int H, int W, int heads,
                                                           int shifted, const float* __restrict__ pos, T* __restrict__ out,
-                                                          f16* __restrict__ packed = nullptr) {
+                                                          f16* __restrict__ packed = nullptr, int* __restrict__ fault = nullptr) {
     __shared__ float kv[4][2][49 * 32];
     __shared__ float spos[169];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -278,6 +278,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ 
     }
     if (packed) {
         f16* ph = packed + tok * 2 * C + head * 32;
+        unsigned vm = 0u;   // range guard (reid_ctx.fault)
+#pragma unroll
+        for (int d = 0; d < 32; ++d) vm = range_acc(vm, o[d]);
+        range_raise(fault, vm);
 #pragma unroll
         for (int d = 0; d < 32; d += 4) {
             half4 hi = {(f16)o[d], (f16)o[d + 1], (f16)o[d + 2], (f16)o[d + 3]};
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ 
 template <typename OUT, int LPT, bool PACK = false>
 __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restrict__ x, long long ntok, int c, float eps,
                                                            const float* __restrict__ g, const float* __restrict__ b,
-                                                           OUT* __restrict__ out) {
+                                                           OUT* __restrict__ out, int* __restrict__ fault = nullptr) {
     constexpr int TPW = 64 / LPT;                  // tokens per wave
     constexpr int MAXJ = LPT == 32 ? 1 : 3;        // chunks per lane: C <= 128 (LPT 32) or C <= 768 (LPT 64)
     const int lane = threadIdx.x & 63, sub = lane & (LPT - 1);
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
             const f32x4 gg = *(const f32x4*)(g + ch * 4), bb = *(const f32x4*)(b + ch * 4);
             const f32x4 y = (v[j] - mean) * rstd * gg + bb;
             if constexpr (PACK) {
+                range_raise(fault, range_acc(range_acc(range_acc(range_acc(0u, y.x), y.y), y.z), y.w));   // range guard (reid_ctx.fault)
                 half4 hi = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
                 half4 lo = {(f16)((y.x - (float)hi[0]) * 2048.0f), (f16)((y.y - (float)hi[1]) * 2048.0f),
                             (f16)((y.z - (float)hi[2]) * 2048.0f), (f16)((y.w - (float)hi[3]) * 2048.0f)};
@@ -355,8 +360,8 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
 }
 
 void launch_layernorm_packed(reid_ctx* ctx, const float* x, long long T, int C, const float* g, const float* b, f16* out) {
-    if (C <= 128) hipLaunchKernelGGL((layernorm_v4_kernel<f16, 32, true>), dim3((unsigned)((T + 7) / 8)), dim3(256), 0, ctx->stream, x, T, C, 1e-5f, g, b, out);
-    else hipLaunchKernelGGL((layernorm_v4_kernel<f16, 64, true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, x, T, C, 1e-5f, g, b, out);
+    if (C <= 128) hipLaunchKernelGGL((layernorm_v4_kernel<f16, 32, true>), dim3((unsigned)((T + 7) / 8)), dim3(256), 0, ctx->stream, x, T, C, 1e-5f, g, b, out, ctx->fault);
+    else hipLaunchKernelGGL((layernorm_v4_kernel<f16, 64, true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, x, T, C, 1e-5f, g, b, out, ctx->fault);
 }
 
 template <typename OUT>
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(256) void swin_tail_partial_kernel(const float* __r
 // Stage 2: mean over the tokens, ^(1/p), BatchNorm1d
 __global__ void swin_tail_final_kernel(const float* __restrict__ partial, int n, int ntok, const float* __restrict__ p_ptr,
                                        const float* __restrict__ bn_s, const float* __restrict__ bn_t,
-                                       float* __restrict__ gem_out, float* __restrict__ emb) {
+                                       float* __restrict__ gem_out, float* __restrict__ emb, int* __restrict__ fault) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * 96) return;
     const int img = i / 96, c = i - img * 96;
@@ -723,7 +728,9 @@ __global__ void swin_tail_final_kernel(const float* __restrict__ partial, int n,
     for (int k = 0; k < TAIL_SLICES; ++k) s += partial[((long long)img * TAIL_SLICES + k) * 96 + c];
     const float gm = powf(s / (float)ntok, 1.0f / p_ptr[0]);
     if (gem_out) gem_out[i] = gm;
-    emb[i] = gm * bn_s[c] + bn_t[c];
+    const float ev = gm * bn_s[c] + bn_t[c];
+    emb[i] = ev;
+    if (fault && !(fabsf(ev) < INFINITY)) fault[1] = 1;   // a non-finite embedding: the context reports it (reid_ctx.fault)
 }
 
 inline int grid_for(long long work, int block) {
@@ -990,6 +997,18 @@ extern "C" int reid_swin_load(reid_ctx* ctx, const float* blob, size_t n_floats,
             }
             tab[name] = {off, cnt};
         }
+    }
+    {   // precision 2 operand range, as in reid_seres18_load: every Linear / convolution weight of the trunk is split
+        const float lim = 65504.0f / 2048.0f;
+        const std::string bad = split_range_violation(blob, tab, {{".qkv.w", lim}, {".out.w", lim}, {".post.w", lim}, {".fc1.w", lim},
+                                                                  {".fc2.w", lim}, {".merge.w", lim}, {"align.img.w", lim},
+                                                                  {"align.t0.w", lim}, {"align.t1.w", lim}, {"align.t2.w", lim}});
+        if (!bad.empty() && ctx->precision == 2) {
+            reid_set_error("reid_swin_load: weight tensor %s cannot be split for the fp32-class arithmetic selected on this context "
+                           "(reid_ctx_set_precision 2 needs |w| 2^11 < 65504); load it in mode 0", bad.c_str());
+            return REID_ERR_ARG;
+        }
+        ctx->split_bad_swin = bad;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     swin_release(ctx);
@@ -1304,7 +1323,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 REID_TRY(linear(ctx, nullptr, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big, ln16));
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 16);
                 hipLaunchKernelGGL(window_attn_kernel<float>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, 3 * C, n,
-                                   Hs, Ws, heads, shifted, k.pos, (float*)nullptr, att16);
+                                   Hs, Ws, heads, shifted, k.pos, (float*)nullptr, att16, ctx->fault);
                 prof_end(ctx);
                 LAUNCH_CHECK();
                 REID_TRY(linear(ctx, nullptr, T, C, k.out_w, k.out_b, C, 0, nullptr, nullptr, att16, (f16*)tmp));   // [T][2C] = tmp's bytes
@@ -1381,7 +1400,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
     hipLaunchKernelGGL(swin_tail_partial_kernel, dim3(n, TAIL_SLICES), dim3(256), 0, ctx->stream, fin, H1 * W1, w.tail_g, w.tail_b,
                        w.tail_p, tail_part);
     hipLaunchKernelGGL(swin_tail_final_kernel, dim3((n * 96 + 255) / 256), dim3(256), 0, ctx->stream, tail_part, n, H1 * W1, w.tail_p,
-                       w.neck_s, w.neck_t, gem, d_emb);
+                       w.neck_s, w.neck_t, gem, d_emb, ctx->fault);
     prof_end(ctx);
     LAUNCH_CHECK();
     if (d_logits) {
@@ -1421,7 +1440,7 @@ extern "C" int reid_debug_swin_stage(reid_ctx* ctx, int stage, float* out, size_
 
 extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int n, int h, int w, float* d_emb, float* d_logits) {
     ARG_CHECK(ctx && d_x && d_emb && n >= 0 && h > 0 && w > 0 && h % 224 == 0 && w % 224 == 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     const SwinWeights* swp = swin_find(ctx);
     if (!swp || !swp->loaded) {
         reid_set_error("reid_swin_embed_*: call reid_swin_load first");
@@ -1440,7 +1459,7 @@ extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int
 
 extern "C" int reid_swin_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, int h, int w, float* emb, float* logits) {
     ARG_CHECK(ctx && x && emb && n >= 0);
-    CTX_GUARD(ctx);
+    CTX_ENTER(ctx);
     if (n == 0) return REID_OK;
     const SwinWeights* swp = swin_find(ctx);
     if (!swp) {
@@ -1458,5 +1477,5 @@ extern "C" int reid_swin_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, in
     HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 96 * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return REID_OK;
+    return ctx_fault_status(ctx);
 }

@@ -63,6 +63,14 @@ class Engine:
     def sync(self):
         check(self.lib.reid_ctx_sync(self.h))
 
+    def device_sync(self):
+        """hipDeviceSynchronize on this engine's device (every stream); raises if the context's fault word is set."""
+        check(self.lib.reid_device_sync(self.h))
+
+    def clear_fault(self):
+        """Resets the sticky fault word (an activation outside f16's range in mode 2 / a non-finite embedding)."""
+        check(self.lib.reid_ctx_clear_fault(self.h))
+
     def set_stream(self, hip_stream):
         """Run on another HIP stream (0 / None = the context's own).  Work already enqueued on the old stream shares the
         context's workspaces with what follows, so a switch drains the old stream first."""

@@ -126,6 +126,13 @@ class RcclComm:
         rank = int(os.environ.get("RANK", "0"))
         if world == 1:
             return cls(engine, 0, 1, cls.unique_id() if single_rank_communicator else None)
+        import sys
+        if "torch" not in sys.modules and _ffi._lib is not None and not os.environ.get("REID_ALLOW_LATE_TORCH"):
+            # torch bundles its own HIP runtime and librccl; loaded after libreid_hip.so they sit BESIDE the system copies the
+            # library has already bound to (two runtimes in one process: aborts at exit, undefined before).  Loaded first, both
+            # bind to torch's copies.
+            raise RuntimeError("RcclComm.from_env: `import torch` must come before the first reid_amd engine is created in a "
+                               "multi-rank process (one HIP runtime / librccl per process); bench.py does this")
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1,0 +1,59 @@
+"""bench.py's launch and exit-code contract on a CPU-only box (gloo, world 2), on the stand-in library (tests/standin_lib.py
+through tests/standin/sitecustomize.py):
+* `python bench.py --gpus 2 ...` WITHOUT a launcher environment starts its own ranks (python -m torch.distributed.run as a child
+  process), relays rank 0's one JSON line and exits with the child's code - the reference's multi-GPU entry points are single
+  commands too (reid/faiss_utils.py:121-135, image_reid_inference.py:211);
+* a sub-workload that never comes back (a rank lost in a collective) ends the job through the watchdog with a NON-ZERO exit code
+  after the partial line has been printed - at one rank and at two."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STANDIN = os.path.join(ROOT, "tests", "standin")
+SMALL = ["--crops", "8", "--steps", "1", "--warmup", "0", "--no-cpu", "--single"]
+
+
+def _bench(args, timeout, **env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(REID_TEST_STANDIN="1", PYTHONPATH=STANDIN + os.pathsep + env.get("PYTHONPATH", ""), OMP_NUM_THREADS="2")
+    env.update({k: str(v) for k, v in env_extra.items()})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def _one_line(r):
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    r = _bench(["--gpus", "2", "--workload", "embed"] + SMALL, 280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _one_line(r)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert "RCCL all-gather" in out["config"]["sharding"]
+    assert "torch.distributed.run" in r.stderr            # the self-launch notice
+
+
+@pytest.mark.timeout(300)
+def test_bench_refuses_a_launcher_that_disagrees_with_gpus():
+    r = _bench(["--gpus", "2", "--workload", "embed"] + SMALL, 120, WORLD_SIZE=1, RANK=0, LOCAL_RANK=0)
+    assert r.returncode == 2 and r.stdout.strip() == ""
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_lost_sub_workload_ends_the_job_with_a_nonzero_exit_code(gpus):
+    """batch256 (the second weight load of the default line) never returns on the last rank: the watchdog prints what the headline
+    measured, with the failure recorded in the sub-object, and every rank leaves with status 3."""
+    r = _bench(["--gpus", str(gpus)] + SMALL, 280, REID_STANDIN_HANG_AT_LOAD=2, REID_STANDIN_HANG_RANK=gpus - 1, REID_BENCH_LIMIT_SCALE=0.03)
+    assert r.returncode != 0, (r.stdout, r.stderr[-3000:])
+    out = _one_line(r)
+    assert out["value"] > 0 and "error" in out["batch256"]
+    if gpus == 1:
+        assert r.returncode == 3
