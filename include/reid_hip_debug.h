@@ -13,6 +13,9 @@ extern "C" {
  * data; cfg = BN*1000 + BK*10 + NST, 2000000 / 2000001 = LDS-halo kernel without / with loader waves. */
 int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int cfg, int iters,
                         float* ms_per_launch);
+/* Times one fp32-class 3x3 stride-1 convolution (SPLIT build of the LDS-halo kernel) on random device data; ablate != 0 switches
+ * phases of its main loop off (1 weight DMA, 2 halo DMA, 4 MFMAs, 8 fragment reads, 16 barriers): timing experiments, wrong results. */
+int reid_debug_conv_split(reid_ctx* ctx, int n, int h, int w, int c, int cout, int ablate, int iters, float* ms_per_launch);
 /* The same for the exact-fp32 convolutions.  flags: 1 fused input affine + ReLU, 2 BN epilogue, 4 residual + ReLU,
  * 8 statistics; variant 0 = gemm_f32_kernel<A_IM2COL>, 1 = conv_f32.hip. */
 int reid_debug_conv_f32(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int flags,

@@ -65,8 +65,11 @@ __device__ __forceinline__ int c_row_natural(int wm, int a, int e, int lh) {
     else return ((wm >> 1) * 16 + (wm & 1) * 8 + a * 2 + g + 4 * (e >> 3)) * 8 + (e & 7);
 }
 
-template <int TW, int IMGS, int BN, int LW, bool SPLIT = false>
+// PAIR (SPLIT builds with loader waves, 128-wide tiles): the three products of the fp32-class arithmetic in an order that shares
+// operands - see the PAIR branch of the main loop.
+template <int TW, int IMGS, int BN, int LW, bool SPLIT = false, bool PAIR = false>
 __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm16Params p) {
+    static_assert(!PAIR || (SPLIT && LW == 1 && BN == 128), "PAIR: fp32-class build, loader waves, 128-wide tiles");
     constexpr int TH = 256 / (IMGS * TW);            // tile rows per image
     constexpr int WP = TW + 2, HP = TH + 2;          // halo pitch / rows
     constexpr int NPX = IMGS * HP * WP;              // halo pixels per block
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
     // (Cout >= 128 tiles have LDS for a fourth weight tile only: TWO taps per barrier over a ring of two pairs ran 4-6 % faster
     // in the 256-crop microbenchmark and 3 % slower in the 1024-crop pass - dropped.)
     constexpr int TPB = (LW && BN == 64 && 2 * HALO_BYTES + 9 * B_BYTES <= 160 * 1024) ? 3 : 1;
-    constexpr int NSLOT = 3 * TPB;
+    constexpr int NSLOT = PAIR ? 4 : 3 * TPB;
     static_assert(2 * HALO_BYTES + NSLOT * B_BYTES <= 160 * 1024, "LDS budget");
     static_assert(HPW <= 6, "halo pieces are issued one per tap");
     constexpr int NLW = 4;                            // loader waves (LW == 1): waves 8..11 issue every DMA piece
@@ -214,7 +217,189 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         }
     };
 
-    if constexpr (LW == 0) {
+    if constexpr (PAIR) {
+        // fp32-class arithmetic, operand-sharing order.  x.w = xh.wh + (xl'.wh + xh.wl') 2^-11 as ONE accumulation over the weight
+        // parts [wh 2^11 | wh | wl'] (Gemm16Params) - but instead of three passes over the virtual channels (xh, xl', xh again: three
+        // halo loads per 64 real channels, one weight tile and 16 MFMAs per wave and barrier) every real chunk c is two PHASES:
+        //   phase X, halo = xh_c : nine steps, step = tap t against BOTH the wh 2^11 and the wl' tile (the A fragments are read once
+        //                          for the two: 6 fragment reads per 8 MFMAs instead of 8);
+        //   phase L, halo = xl'_c: five steps, step = taps (2j, 2j+1) against their wh tiles (the ninth tap alone).
+        // 14 barriers per real chunk instead of 27, 32 MFMAs per wave between two barriers instead of 16, two halo loads instead of
+        // three.  LDS: xh in halo buffer 0, xl' in buffer 1, the weight ring = two stages of two tiles (the step being computed /
+        // the step being loaded).
+        // What was measured on the way (round 4, tools/conv_split_ablate.py, layer 4 at 1024 crops, 1.85 ms in the three-pass order):
+        // with all-zero operands the three-pass kernel takes 1.48 ms - a fifth of its time is the chip holding its clock down under
+        // load; a variant of this loop whose weight ring ran THREE steps ahead (32-channel tiles, counted vmcnt) was 13 % slower:
+        // the cost of the DMA stream (0.4-0.6 ms, the same with one step or three steps of lead) is not its latency.
+        const int Creal = p.Cin / 3;                       // weights per tap: [wh 2^11 (Creal) | wh | wl']
+        const int C64 = Creal / 64;
+        const int ncr = C64 / SK, cr0 = ksplit * ncr, cr_end = cr0 + ncr;
+        const int nsteps = ncr * 14;
+        if (is_loader) {
+            if (p.loader_prio) __builtin_amdgcn_s_setprio(3);
+            const int lw = wave - 8;
+            auto issue_tile = [&](int c, int tap, int part, int slot) {
+                const int k0 = tap * p.Cin + part * Creal + c * 64;
+#pragma unroll
+                for (int j = 0; j < BPL; ++j) {
+                    const int inst = lw * BPL + j;
+                    const int row = inst * 8 + (lane >> 3);
+                    const int cc = (lane & 7) ^ ((row >> 1) & 7);
+                    __builtin_amdgcn_global_load_lds(GPTR(p.B + (long long)(n_blk + row) * p.ldb + k0 + cc * 8),
+                                                     LPTR(ring + slot * B_BYTES + inst * 1024), 16, 0, 0);
+                }
+            };
+            auto issue_step = [&](int u) {
+                const int c = cr0 + u / 14, st = u - (u / 14) * 14, base = (u & 1) * 2;
+                if (st < 9) {
+                    issue_tile(c, st, 0, base);
+                    issue_tile(c, st, 2, base + 1);
+                } else {
+                    const int t0 = 2 * (st - 9);
+                    issue_tile(c, t0, 1, base);
+                    if (t0 + 1 < 9) issue_tile(c, t0 + 1, 1, base + 1);
+                }
+            };
+            constexpr int PX = (NPI + 8) / 9, PL = (NPI + 4) / 5;      // halo pieces of the next phase per step of this one
+            for (int q = lw; q < NPI; q += NLW) issue_halo_piece(q, cr0, 0);
+            issue_step(0);
+            const int abl = p.ablate;   // experiments (reid_debug_conv_split): 1 no weight DMA, 2 no halo DMA after the prologue
+            for (int u = 0; u < nsteps; ++u) {
+                WAIT_VMCNT(0);        // everything this loader issued one step ago (the step's weights, halo pieces) has landed
+                RAW_BARRIER();
+                if (u + 1 < nsteps && !(abl & 1)) issue_step(u + 1);
+                const int c = cr0 + u / 14, st = u - (u / 14) * 14;
+                if (abl & 2) continue;
+                if (st < 9) {         // xl'_c into buffer 1 (last read in phase L of chunk c - 1: every wave is past it)
+                    const int q1 = (st + 1) * PX < NPI ? (st + 1) * PX : NPI;
+                    for (int q = st * PX + lw; q < q1; q += NLW) issue_halo_piece(q, C64 + c, 1);
+                } else if (c + 1 < cr_end) {   // xh_{c+1} into buffer 0 (last read in step 8 of this chunk)
+                    const int j = st - 9, q1 = (j + 1) * PL < NPI ? (j + 1) * PL : NPI;
+                    for (int q = j * PL + lw; q < q1; q += NLW) issue_halo_piece(q, c + 1, 0);
+                }
+            }
+            return;
+        }
+        // compute waves.  The fragment reads are inline asm and their waits are counted by hand: left to hipcc the waits in this loop
+        // come out as s_waitcnt lgkmcnt(0) (the wait in front of the MFMAs of k-step kk then also waits for the fragments just
+        // requested for kk + 1: reads and MFMAs serialise - that build ran at HALF the speed).  A group = the fragments of one k-step
+        // (2 A + 4 B in phase X, 2 A + 2 B in phase L), two register sets; group g + 1 is requested before the MFMAs of group g
+        // issue.  The block barrier of step u + 1 sits in front of the LAST MFMA group of step u, as soon as every fragment of step u
+        // has been read: the first fragments of step u + 1 are then in flight under those MFMAs.
+        const unsigned halo32 = (unsigned)(uintptr_t)halo, ring32 = (unsigned)(uintptr_t)ring;
+        unsigned bx[4];                                   // B fragment address of k-step kk inside a weight tile (column block 0)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bx[kk] = ring32 + b_row_off + (((kk * 2 + lh) ^ b_swz) * 16);
+#define LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LGKM_WAIT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+        // A fragment addresses of tap t in halo buffer `buf`: per MFMA row tile a and k-step kk
+        auto a_addrs = [&](int buf, int tap, unsigned (&aa)[TM][4]) __attribute__((always_inline)) {
+            const int r = tap / 3, sx = tap - r * 3;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int hp = hp0[a] + r * WP + sx;
+                const unsigned base = halo32 + buf * HALO_BYTES + hp * 128;
+                const int swz = (hp >> 1) & 7;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) aa[a][kk] = base + (((kk * 2 + lh) ^ swz) * 16);
+            }
+        };
+        static_assert(TN == 2, "fragment offsets below assume two 32-column blocks per wave");
+        for (int c = 0; c < ncr; ++c) {
+            {   // ---- phase X: nine steps, tap st of xh_c against the weight tiles (wh 2^11, wl') of ring stage st & 1
+                half8 fa[2][TM], fb[2][2 * TN];
+                unsigned aa[TM][4];
+                auto rd = [&](int set, int kk, unsigned soff) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) LDS_READ(fa[set][a], aa[a][kk], 0);
+                    const unsigned ba = bx[kk] + soff;
+                    LDS_READ(fb[set][0], ba, 0);
+                    LDS_READ(fb[set][1], ba, 4096);
+                    LDS_READ(fb[set][2], ba, B_BYTES);
+                    LDS_READ(fb[set][3], ba, B_BYTES + 4096);
+                };
+                auto mm = [&](int set) __attribute__((always_inline)) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int a = 0; a < TM; ++a)
+#pragma unroll
+                            for (int b = 0; b < TN; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][a], fb[set][t * TN + b], acc[a][b], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                RAW_BARRIER();
+                a_addrs(0, 0, aa);
+                rd(0, 0, 0u);
+#pragma unroll 1
+                for (int st = 0; st < 9; ++st) {
+                    const unsigned soff = (st & 1) * 2 * B_BYTES;
+                    rd(1, 1, soff); LGKM_WAIT(6); mm(0);
+                    rd(0, 2, soff); LGKM_WAIT(6); mm(1);
+                    rd(1, 3, soff); LGKM_WAIT(6); mm(0);
+                    LGKM_WAIT(0);
+                    if (p.pair_early && st < 8) {
+                        RAW_BARRIER();
+                        a_addrs(0, st + 1, aa);
+                        rd(0, 0, ((st + 1) & 1) * 2 * B_BYTES);
+                    }
+                    mm(1);
+                    if (!p.pair_early && st < 8) {
+                        RAW_BARRIER();
+                        a_addrs(0, st + 1, aa);
+                        rd(0, 0, ((st + 1) & 1) * 2 * B_BYTES);
+                    }
+                }
+            }
+            {   // ---- phase L: nine passes (taps of xl'_c, one wh tile each), two per step (the ninth alone): steps 9 .. 13
+                half8 fa[2][TM], fb[2][TN];
+                unsigned aa[TM][4];
+                auto rd = [&](int set, int kk, unsigned soff) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) LDS_READ(fa[set][a], aa[a][kk], 0);
+                    const unsigned ba = bx[kk] + soff;
+                    LDS_READ(fb[set][0], ba, 0);
+                    LDS_READ(fb[set][1], ba, 4096);
+                };
+                auto mm = [&](int set) __attribute__((always_inline)) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][a], fb[set][b], acc[a][b], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                auto slot_off = [&](int q) { return (unsigned)(((((q >> 1) + 1) & 1) * 2 + (q & 1)) * B_BYTES); };   // pass q: step 9 + q / 2
+                RAW_BARRIER();
+                a_addrs(1, 0, aa);
+                rd(0, 0, slot_off(0));
+#pragma unroll 1
+                for (int q = 0; q < 9; ++q) {
+                    const unsigned soff = slot_off(q);
+                    rd(1, 1, soff); LGKM_WAIT(4); mm(0);
+                    rd(0, 2, soff); LGKM_WAIT(4); mm(1);
+                    rd(1, 3, soff); LGKM_WAIT(4); mm(0);
+                    LGKM_WAIT(0);
+                    const bool late = !p.pair_early && (q & 1);   // a step's barrier after its last MFMA group instead of before it
+                    if (q < 8 && !late) {
+                        if (q & 1) RAW_BARRIER();          // passes 2 j and 2 j + 1 form one step
+                        a_addrs(1, q + 1, aa);
+                        rd(0, 0, slot_off(q + 1));
+                    }
+                    mm(1);
+                    if (q < 8 && late) {
+                        RAW_BARRIER();
+                        a_addrs(1, q + 1, aa);
+                        rd(0, 0, slot_off(q + 1));
+                    }
+                }
+            }
+        }
+#undef LDS_READ
+#undef LGKM_WAIT
+    } else if constexpr (LW == 0) {
         // prologue: halo of chunk 0, weight tiles 0 and 1
 #pragma unroll
         for (int k = 0; k < HPW; ++k)
@@ -414,6 +599,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
     }
 
     if constexpr (SPLIT) {
+        if (p.ablate & 32) return;    // experiment: no epilogue
         // ------------------------------------------------------------------ fp32 epilogue of the SPLIT build: BN scale (x 2^-11)
         // and shift, fp32 residual, ReLU from column relu_from on, fp32 stores, per-128-row column sums - straight from the
         // accumulators (a row of the MFMA tile is 32 consecutive columns: 128-byte segments).  Rows past M only occur in the
@@ -456,8 +642,10 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
                             f16* dst = p.pack16 + (long long)(m_blk + rowv[e]) * 2 * p.N + col;
                             dst[0] = hv;
                             dst[p.N] = (f16)((v - (float)hv) * 2048.0f);
-                        } else {
+                        } else if (!(p.ablate & 64)) {
                             p.C32[(long long)(m_blk + rowv[e]) * ldc + col] = v;
+                        } else {
+                            asm volatile("" ::"v"(v));
                         }
                     }
                 }
@@ -605,6 +793,7 @@ template <int TW, int IMGS, int LW, bool SPLIT = false>
 int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
     p.fault = ctx->fault;
+    p.pair_early = ctx->split_pair == 2;
     p.loader_prio = ctx->f16_loader_prio == 2 || (ctx->f16_loader_prio == 1 && SPLIT);
     p.frag_ahead = ctx->f16_frag_ahead;
     const int nmt = (p.M + 255) / 256;
@@ -624,13 +813,21 @@ int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
         return REID_OK;
     };
     const int tiles128 = p.N % 128 == 0 ? nmt * (p.N / 128) : 0;
+    constexpr bool CAN_PAIR = SPLIT && LW == 1;
+    const bool pair = CAN_PAIR && ctx->split_pair && p.split_terms == 3;   // the operand-sharing order of the fp32-class products
     if (tiles128 >= 128) {
-        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(tiles128), dim3(threads), 0, ctx->stream, p);
+        if constexpr (CAN_PAIR) {
+            if (pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT, true>), dim3(tiles128), dim3(threads), 0, ctx->stream, p);
+        }
+        if (!pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(tiles128), dim3(threads), 0, ctx->stream, p);
     } else if (ctx->f16_split_k && ctx->f16_wide_splitk && tiles128 >= 48 && tiles128 * 4 <= 256 && nchunk % 4 == 0 && nchunk >= 16) {
         // ... unless the K loop is long enough (layer 4) to split four ways over 128-wide tiles: the same block count with half
         // the barriers and 1.0 instead of 1.5 LDS fragment reads per MFMA
         REID_TRY(splitk(tiles128, 128, 4));
-        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(tiles128 * 4), dim3(threads), 0, ctx->stream, p);
+        if constexpr (CAN_PAIR) {
+            if (pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT, true>), dim3(tiles128 * 4), dim3(threads), 0, ctx->stream, p);
+        }
+        if (!pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(tiles128 * 4), dim3(threads), 0, ctx->stream, p);
     } else {
         // ... and when even those leave CUs idle, split the input channels over 2 or 4 blocks per tile (the K loop is
         // latency-bound at ~0.65 us per (chunk, tap) tile, so its length is what a small launch costs)

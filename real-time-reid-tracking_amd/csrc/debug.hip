@@ -48,6 +48,49 @@ extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, 
 }
 
 
+// Times `iters` launches of one fp32-class 3x3 stride-1 convolution (SPLIT build of the LDS-halo kernel: c real channels as
+// [xh | xl'] against [wh 2^11 | wh | wl'] weights, fp32 out with BN + ReLU epilogue) on operands cut from the loaded weight blob.
+// ablate: experiment switches of the PAIR loop (Gemm16Params.ablate; results are then wrong): 1 no weight DMA after the first step,
+// 2 no halo DMA after the first phase, 4 no MFMAs, 8 no fragment reads, 16 no block barriers.
+extern "C" int reid_debug_conv_split(reid_ctx* ctx, int n, int h, int w, int c, int cout, int ablate, int iters, float* ms_per_launch) {
+    ARG_CHECK(ctx && ms_per_launch && ctx->se18.loaded && c % 64 == 0 && cout % 64 == 0);
+    CTX_GUARD(ctx);
+    typedef _Float16 f16;
+    const size_t nin = (size_t)n * h * w * 2 * c, nw = (size_t)cout * 9 * 3 * c, nout = (size_t)n * h * w * cout;
+    f16 *x, *wt;
+    float *out, *sc;
+    REID_TRY(ctx_ws(ctx, "dbgs.x", nin * 2, (void**)&x));
+    REID_TRY(ctx_ws(ctx, "dbgs.w", nw * 2, (void**)&wt));
+    REID_TRY(ctx_ws(ctx, "dbgs.out", nout * 4, (void**)&out));
+    REID_TRY(ctx_ws(ctx, "dbgs.sc", (size_t)cout * 2 * 4, (void**)&sc));
+    const size_t src_n = ctx->se18.n_floats;
+    for (size_t o = 0; o < nin; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nin - o < src_n ? nin - o : src_n, x + o));
+    for (size_t o = 0; o < nw; o += src_n) REID_TRY(launch_f32_to_f16(ctx, ctx->se18.blob, nw - o < src_n ? nw - o : src_n, wt + o));
+    HIP_TRY(hipMemcpyAsync(sc, ctx->se18.blob, (size_t)cout * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ablate & 128) {   // clock experiment: all-zero operands draw less power (is the kernel power-limited?)
+        HIP_TRY(hipMemsetAsync(x, 0, nin * 2, ctx->stream));
+        HIP_TRY(hipMemsetAsync(wt, 0, nw * 2, ctx->stream));
+    }
+    Gemm16Params q;
+    memset(&q, 0, sizeof(q));
+    q.split_terms = 3;
+    q.H = h; q.W = w; q.Cin = 3 * c; q.R = 3; q.S = 3; q.stride = 1; q.pad = 1; q.Ho = h; q.Wo = w;
+    q.M = n * h * w; q.N = cout; q.K = 27 * c; q.ldb = q.K;
+    q.A = x; q.B = wt; q.C32 = out; q.ldc = cout;
+    q.col_scale = sc; q.col_shift = sc + cout; q.relu = 1;
+    q.acc_scale = 1.0f / 2048.0f;
+    q.zero_page = ctx->se18.zero_page;
+    q.ablate = ablate & 127;
+    int st = REID_OK;
+    for (int i = 0; i < 2 && st == REID_OK; ++i) st = launch_conv3x3_split(ctx, q, REID_K_CONV_GEMM, 0, 0);
+    if (st == REID_OK) st = reid_timer_start(ctx);
+    for (int i = 0; i < iters && st == REID_OK; ++i) st = launch_conv3x3_split(ctx, q, REID_K_CONV_GEMM, 0, 0);
+    float ms = 0.f;
+    if (st == REID_OK) st = reid_timer_stop(ctx, &ms);
+    *ms_per_launch = ms / (iters > 0 ? iters : 1);
+    return st;
+}
+
 // Correctness harness for conv3x3_c64_f16.hip (tests only, not part of the C ABI): fp32 host operands are rounded to f16,
 // the kernel runs once, the f16 result and the fp32 per-image statistics come back as fp32.
 extern "C" int reid_debug_conv_c64(reid_ctx* ctx, int n, const float* x, const float* w_krsc, const float* scale,
