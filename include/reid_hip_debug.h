@@ -38,6 +38,9 @@ int reid_debug_linear_rows(reid_ctx* ctx, const float* x, const float* w, const 
 /* Experiment switch of the fused distance + selection kernel: 0 product behaviour, 1 / 2 skip phases (INCOMPLETE results: timing
  * only), 4 print candidate-list statistics. */
 int reid_debug_select_exp(reid_ctx* ctx, int mode);
+/* Test switch of the large k-NN path (candidates on the f16 matrix pipe + exact fp32 refinement): enable = 0 -> fused fp32 search
+ * for every size; force > 0 -> rows whose index is a multiple of it take the exact-row fallback. */
+int reid_debug_knn_wide(reid_ctx* ctx, int enable, int force);
 /* Switches the s_memtime stamps of the loader-wave conv kernel on / off (out_host [64*8*5] when disabling). */
 int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long long* out_host);
 /* Bare MFMA loop with fragments re-read from LDS (shape 32 = 32x32x16 f16, 16 = 16x16x32 f16). */

@@ -43,6 +43,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F32_STEMPOOL")) c->f32_stem_pool = atoi(e);
     if (const char* e = getenv("REID_STEM_SPLIT")) c->stem_split = atoi(e);
     if (const char* e = getenv("REID_SPLIT_PAIR")) c->split_pair = atoi(e);
+    if (const char* e = getenv("REID_KNN_WIDE")) c->knn_wide = atoi(e);
     if (const char* e = getenv("REID_F16_LOADER_PRIO")) c->f16_loader_prio = atoi(e);
     if (const char* e = getenv("REID_F16_FRAG_AHEAD")) c->f16_frag_ahead = atoi(e);
     if (const char* e = getenv("REID_PACK_EPILOGUE")) c->pack_epilogue = atoi(e);
@@ -1396,6 +1397,20 @@ extern "C" int reid_knn_dev(reid_ctx* ctx, const float* d_xq, int nq, const floa
     ARG_CHECK(ctx && d_D && d_I && nq >= 0 && nb >= 1 && k >= 1);
     CTX_GUARD(ctx);
     if (nq == 0) return REID_OK;
+    if (!ctx->select_two_pass && knn_wide_eligible(ctx, nq, nb, d, k)) {
+        // large searches (the re-ranking's 19 281 x 19 281 x 1 263): candidates on the f16 matrix pipe, exact fp32 refinement - the
+        // numbers and the order of the fused fp32 search below (knn_wide.hip)
+        const float *xp, *yp;
+        int ldx, ldy;
+        REID_TRY(pad_rows_to(ctx, "sel.xpad", d_xq, nq, d, 64, &xp, &ldx));
+        REID_TRY(pad_rows_to(ctx, "sel.ypad", d_xb, nb, d, 64, &yp, &ldy));
+        float *xx, *yy;
+        REID_TRY(ctx_ws(ctx, "dist.xx", (size_t)nq * 4, (void**)&xx));
+        REID_TRY(ctx_ws(ctx, "dist.yy", (size_t)nb * 4, (void**)&yy));
+        REID_TRY(launch_row_sqnorm(ctx, xp, nq, ldx, ldx, xx));
+        REID_TRY(launch_row_sqnorm(ctx, yp, nb, ldy, ldy, yy));
+        return knn_wide_dev(ctx, xp, nq, yp, nb, ldx, xx, yy, k, d_D, d_I);
+    }
     if (!ctx->select_two_pass) {   // fused distance + selection: the nq x nb matrix is never written
         const int st = select_fused_dev(ctx, d_xq, nq, d_xb, nb, d, REID_METRIC_L2SQR, k, d_D, d_I);
         if (st != 1) return st;

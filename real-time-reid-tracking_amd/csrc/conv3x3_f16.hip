@@ -869,8 +869,9 @@ int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double fl
 // ---- "fp32-class" convolutions on the f16 matrix pipe (Gemm16Params: SPLIT build) ---------------------------------------------
 namespace {
 // fp32 [rows][C] -> f16 [rows][2C]: [xh | xl'], xh = f16(x), xl' = f16((x - xh) * 2^11); eight channels per thread
+// scale (may be null): a device scalar every value is multiplied by first (a power of two: knn_wide.hip normalises its operands)
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ x, long long rows, int C, f16* __restrict__ out,
-                                                         int* __restrict__ fault) {
+                                                         int* __restrict__ fault, const float* __restrict__ scale) {
     const int c8 = C >> 3;
     const long long i = blockIdx.x * 256LL + threadIdx.x;
     if (i >= rows * c8) return;
@@ -878,7 +879,8 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
     const int c = (int)(i - row * c8) * 8;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 a = *(const f32x4*)(x + row * C + c), b = *(const f32x4*)(x + row * C + c + 4);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const float sc = scale ? scale[0] : 1.0f;
+    const float v[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, b.x * sc, b.y * sc, b.z * sc, b.w * sc};
     half8 hi, lo;
     unsigned vm = 0u;
 #pragma unroll
@@ -893,12 +895,12 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 }
 // fp32 [cout][taps][cin] -> f16 [cout][taps][3 cin]: [wh * 2^11 | wh | wl'] per tap (wl' = f16((w - wh) * 2^11))
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, long long total, int cin, int terms,
-                                                            f16* __restrict__ out) {
+                                                            f16* __restrict__ out, const float* __restrict__ scale) {
     const long long i = blockIdx.x * 256LL + threadIdx.x;
     if (i >= total) return;
     const long long rt = i / cin;            // (cout, tap)
     const int c = (int)(i - rt * cin);
-    const float v = w[i];
+    const float v = scale ? w[i] * scale[0] : w[i];
     const f16 wh = (f16)v;
     f16* o = out + rt * terms * cin;
     o[c] = (f16)((float)wh * 2048.0f);
@@ -908,19 +910,19 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 }
 }  // namespace
 
-int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out) {
+int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out, const float* d_scale) {
     ARG_CHECK(C % 8 == 0);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)rows * C * 8.0);
     hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((rows * (C / 8) + 255) / 256)), dim3(256), 0, ctx->stream, x, rows, C, out,
-                       ctx->fault);
+                       ctx->fault, d_scale);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
 }
 
-int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, int terms, _Float16* out) {
+int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, int terms, _Float16* out, const float* d_scale) {
     const long long total = (long long)cout * taps * cin;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w, total, cin, terms, out);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w, total, cin, terms, out, d_scale);
     LAUNCH_CHECK();
     return REID_OK;
 }

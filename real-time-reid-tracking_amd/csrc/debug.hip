@@ -325,6 +325,15 @@ extern "C" int reid_debug_select_exp(reid_ctx* ctx, int mode) {
     return REID_OK;
 }
 
+// Test switch of the large k-NN path (knn_wide.hip): enable = 0 sends every search through the fused fp32 kernel; force > 0 makes
+// every row whose index is a multiple of it take the exact-row fallback.
+extern "C" int reid_debug_knn_wide(reid_ctx* ctx, int enable, int force) {
+    ARG_CHECK(ctx && force >= 0);
+    ctx->knn_wide = enable != 0;
+    ctx->knn_wide_force = force;
+    return REID_OK;
+}
+
 // One Swin Linear layer on HOST operands through the f16 linear build of gemm_f16.hip, results back on the host (correctness
 // harness: row-position invariance, tests/test_gpu_parity.py).  mode 1 = fp16 storage (operands rounded to f16), 2 = fp32-class
 // (x packed to [xh | xl'], weights to [wh 2^11 | wh | wl'], K = 3 k virtual columns).  flags bit 0 = erf-GELU; bit 1 = f16 output

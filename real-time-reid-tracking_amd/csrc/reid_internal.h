@@ -195,8 +195,8 @@ bool conv3x3_f16_supported(const Gemm16Params& p);   // conv3x3_f16.hip: 3x3 s1 
 int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);
 int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build, see Gemm16Params
 int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build of gemm_f16 (im2col: strided / 1x1)
-int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out);           // fp32 [rows][C] -> f16 [rows][2C] = [xh | xl']
-int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, int terms, _Float16* out);  // fp32 [cout][taps][cin] -> f16 [cout][taps][terms * cin]
+int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out, const float* d_scale = nullptr);           // fp32 [rows][C] -> f16 [rows][2C] = [xh | xl']
+int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, int terms, _Float16* out, const float* d_scale = nullptr);  // fp32 [cout][taps][cin] -> f16 [cout][taps][terms * cin]
 // fp16 elementwise kernels (elementwise_f16.hip)
 int launch_prep_u8_pad_f16(reid_ctx*, const uint8_t* crops, int n, int h, int w, int hp, int wp, _Float16* out);
 int launch_prep_f32_pad_f16(reid_ctx*, const float* nhwc3, int n, int h, int w, int hp, int wp, _Float16* out);
@@ -363,6 +363,9 @@ struct reid_ctx {
     int stem_split = 1;      // precision 2: the 7x7 stem on split f16 operands (REID_STEM_SPLIT=0: the fp32-pipe stem + split_pack)
     int f32_stem_pool = 1;   // fp32 path: MaxPool(3,2,1) on the stem kernel's accumulators (REID_F32_STEMPOOL=0: separate kernel)
     int split_terms = 3;     // precision 2: f16 products per multiply (REID_SPLIT_TERMS=4 adds the low x low product)
+    int knn_wide = 1;        // large k-NN searches: candidates on the f16 matrix pipe + exact fp32 refinement (knn_wide.hip; REID_KNN_WIDE=0:
+                             // the fused fp32 search for every size)
+    int knn_wide_force = 0;  // tests (reid_debug_knn_wide): every row whose index is a multiple of it takes the exact-row fallback
     int select_exp = 0;      // experiments only (reid_debug_select_exp, debug.hip): 1 / 2 skip phases of the fused selection (results
                              // are then incomplete), 4 prints candidate-list statistics
     int select_two_pass = 0; // REID_SELECT_TWO_PASS=1: arg-min / k-NN through the full distance matrix (A/B against dist_select.hip)
@@ -393,7 +396,11 @@ struct reid_ctx {
     int* fault = nullptr;
 };
 enum { REID_FAULT_RANGE = 1, REID_FAULT_NONFINITE = 2 };
-int ctx_fault_status(reid_ctx* ctx);   // api.hip: REID_OK, or REID_ERR_STATE + message when the fault word is set
+int ctx_fault_status(reid_ctx* ctx);
+// knn_wide.hip: brute-force k-NN for large problems (candidates in fp32-class arithmetic, exact fp32 refinement)
+bool knn_wide_eligible(reid_ctx* ctx, int nq, int nb, int d, int k);
+int knn_wide_dev(reid_ctx* ctx, const float* xp, int nq, const float* yp, int nb, int ld, const float* rs, const float* cq, int k, float* d_D,
+                 int32_t* d_I);   // api.hip: REID_OK, or REID_ERR_STATE + message when the fault word is set
 
 // precision 2: largest |w| of the named tensors against the bound their split form allows; returns "" or "name (max |w| = v)"
 inline std::string split_range_violation(const float* blob, const std::map<std::string, std::pair<size_t, size_t>>& tab,

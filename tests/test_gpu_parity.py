@@ -1719,6 +1719,39 @@ def test_engine_and_bank_can_be_collected_in_any_order(first):
     gc.collect()
 
 
+# ----------------------------------------------------------------------------- large k-NN on the f16 matrix pipe (knn_wide.hip)
+@pytest.mark.parametrize("n,d,k,scale", [(8200, 512, 5, 1.0), (8300, 200, 20, 1.0), (9000, 136, 24, 300.0), (8200, 256, 1, 1e-4)])
+def test_wide_knn_equals_the_fused_fp32_search_bit_for_bit(eng_w0, n, d, k, scale):
+    """reid_knn on a LARGE problem (reid/faiss_utils.py:149-176: the re-ranking's search) takes its candidates from an fp32-class
+    GEMM on the f16 matrix pipe and recomputes them in exact fp32 (knn_wide.hip): indices AND distances must equal the fused
+    fp32 search (dist_select.hip - itself bit-equal to a full sort of the library's distance matrix,
+    test_fused_select_matches_two_pass_and_oracle) bit for bit - on clustered features with duplicate rows (exact ties go to
+    the lower index), with features far outside / inside f16's range (the candidate stage normalises by powers of two), and
+    with every 13th row forced through the exact-row fallback that a failed sufficiency proof takes."""
+    import ctypes as C
+    eng, _ = eng_w0
+    sw = _ffi.debug_lib().reid_debug_knn_wide
+    sw.restype = C.c_int
+    sw.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    _, _, _, x, _, _ = synth.clustered_embeddings(1, n, d=d, n_ids=97, n_cams=6, seed=n + k, sigma=0.9)
+    x = (x * scale).astype(np.float32)
+    x[n // 2] = x[7]
+    x[n - 1] = x[7]
+    q = np.ascontiguousarray(x[: n - 100])              # queries: a (ragged) subset, so that M is not a multiple of the tile
+    try:
+        _ffi.check(sw(eng.h, 0, 0))
+        D0, I0 = eng.knn(q, x, k)
+        _ffi.check(sw(eng.h, 1, 0))
+        D1, I1 = eng.knn(q, x, k)
+        _ffi.check(sw(eng.h, 1, 13))
+        D2, I2 = eng.knn(q, x, k)
+    finally:
+        _ffi.check(sw(eng.h, 1, 0))
+    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+    assert np.array_equal(I0, I2) and np.array_equal(D0, D2)
+    assert I0[7, 0] == 7 and (k < 3 or (I0[7, 1] == n // 2 and I0[7, 2] == n - 1))     # the duplicates, lowest index first
+
+
 # ----------------------------------------------------------------------------- row-position invariance of the linear kernels
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("n,k", [(384, 96), (96, 384), (288, 96), (768, 192), (3072, 768), (768, 3072)])
