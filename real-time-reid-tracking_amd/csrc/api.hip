@@ -44,6 +44,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_STEM_SPLIT")) c->stem_split = atoi(e);
     if (const char* e = getenv("REID_SPLIT_PAIR")) c->split_pair = atoi(e);
     if (const char* e = getenv("REID_KNN_WIDE")) c->knn_wide = atoi(e);
+    if (const char* e = getenv("REID_KNN_WIDE_MIN")) c->knn_wide_min = atoll(e);
     if (const char* e = getenv("REID_F16_LOADER_PRIO")) c->f16_loader_prio = atoi(e);
     if (const char* e = getenv("REID_F16_FRAG_AHEAD")) c->f16_frag_ahead = atoi(e);
     if (const char* e = getenv("REID_PACK_EPILOGUE")) c->pack_epilogue = atoi(e);

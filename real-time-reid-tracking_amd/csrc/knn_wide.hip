@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void scaled_bias_kernel(const float* __restric
 }  // namespace
 
 bool knn_wide_eligible(reid_ctx* ctx, int nq, int nb, int d, int k) {
-    return ctx->knn_wide && k >= 1 && k <= 24 && nb >= 4096 && d >= 128 && (long long)nq * nb >= (1ll << 26);
+    return ctx->knn_wide && k >= 1 && k <= 24 && nb >= 4096 && d >= 128 && (long long)nq * nb >= ctx->knn_wide_min;
 }
 
 // xp [nq][ld] / yp [nb][ld]: the zero-padded operands of the fused fp32 search (ld % 64 == 0), rs / cq their squared norms.

@@ -365,6 +365,7 @@ struct reid_ctx {
     int split_terms = 3;     // precision 2: f16 products per multiply (REID_SPLIT_TERMS=4 adds the low x low product)
     int knn_wide = 1;        // large k-NN searches: candidates on the f16 matrix pipe + exact fp32 refinement (knn_wide.hip; REID_KNN_WIDE=0:
                              // the fused fp32 search for every size)
+    long long knn_wide_min = 1ll << 25;   // query x gallery pairs from which the wide path is taken (REID_KNN_WIDE_MIN): Market-size (3368 x 15913) 0.68 -> 0.41 ms
     int knn_wide_force = 0;  // tests (reid_debug_knn_wide): every row whose index is a multiple of it takes the exact-row fallback
     int select_exp = 0;      // experiments only (reid_debug_select_exp, debug.hip): 1 / 2 skip phases of the fused selection (results
                              // are then incomplete), 4 prints candidate-list statistics
