@@ -43,6 +43,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_F32_STEMPOOL")) c->f32_stem_pool = atoi(e);
     if (const char* e = getenv("REID_STEM_SPLIT")) c->stem_split = atoi(e);
     if (const char* e = getenv("REID_SPLIT_PAIR")) c->split_pair = atoi(e);
+    if (const char* e = getenv("REID_SPLIT_LEAN")) c->split_lean_epi = atoi(e);
     if (const char* e = getenv("REID_KNN_WIDE")) c->knn_wide = atoi(e);
     if (const char* e = getenv("REID_KNN_WIDE_MIN")) c->knn_wide_min = atoll(e);
     if (const char* e = getenv("REID_F16_LOADER_PRIO")) c->f16_loader_prio = atoi(e);

@@ -67,6 +67,22 @@ __device__ __forceinline__ int c_row_natural(int wm, int a, int e, int lh) {
 
 // PAIR (SPLIT builds with loader waves, 128-wide tiles): the three products of the fp32-class arithmetic in an order that shares
 // operands - see the PAIR branch of the main loop.
+// The same row split into the part that is uniform over the wave (per MFMA tile a and register e) and the part that depends on
+// the lane half (and on x = "the register's quarter is 1 or 2"): c_row_natural = c_row_uniform + c_row_lane.  Buffer instructions
+// take the first in the scalar offset and the second in the vector offset.
+template <int TW, int IMGS>
+__device__ __forceinline__ int c_row_uniform(int wm, int a, int e) {
+    if constexpr (TW == 32) return (wm * 2 + a) * 32 + (e & 3) + 8 * (e >> 2);
+    else if constexpr (TW == 16) return (wm * 4 + a * 2) * 16 + e;
+    else return ((wm >> 1) * 16 + (wm & 1) * 8 + a * 2 + 4 * (e >> 3)) * 8 + (e & 7);
+}
+template <int TW, int IMGS>
+__device__ __forceinline__ int c_row_lane(int lh, int x) {
+    if constexpr (TW == 32) return 4 * lh;
+    else if constexpr (TW == 16) return 16 * (lh ^ x);
+    else return 8 * (lh ^ x);
+}
+
 template <int TW, int IMGS, int BN, int LW, bool SPLIT = false, bool PAIR = false>
 __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm16Params p) {
     static_assert(!PAIR || (SPLIT && LW == 1 && BN == 128), "PAIR: fp32-class build, loader waves, 128-wide tiles");
@@ -609,49 +625,124 @@ __global__ __launch_bounds__(LW ? 768 : 512) void conv3x3_f16_kernel(const Gemm1
         const int m_valid = p.M - m_blk;
         float s1[TN], s2[TN];
         float vmax = 0.f;   // largest packed magnitude (range guard: the accumulators cannot hold a NaN that did not start as an inf)
+        // Lean form (every launch of the forward): no per-element predicate, 64-bit address or branch.  M % 128 == 0, so a ragged
+        // last tile has exactly 128 rows and they belong to the waves wm 0, 1 (rows 0 .. 127 in every geometry): the other waves skip
+        // their loads and stores as a whole.  A row's byte offset splits into a lane part (which of the tile's two row groups the
+        // lane half holds: it depends on the lane half and, for the 16- and 8-wide geometries, on the register's quarter) and a
+        // uniform part per (a, e): buffer instructions take the first in the vector offset, the second in the scalar offset, the
+        // column block's +128 B as the immediate.  The arithmetic per element is the general loop's, operation for operation.
+        const bool lean = !p.general_epi && (long long)256 * ldc * 4 < 0x7fffff00ll && (long long)256 * 2 * p.N * 2 < 0x7fffff00ll && (m_valid >= 256 || m_valid == 128);
+        if (lean) {
+            const bool wave_live = m_valid >= 256 || wm < 2;
+            // lane part of the natural row, for registers whose quarter q = e >> 2 is 0 / 3 (x = 0) and 1 / 2 (x = 1)
+            const int lrow[2] = {c_row_lane<TW, IMGS>(lh, 0), c_row_lane<TW, IMGS>(lh, 1)};
+            const int col0 = n_blk + wn * (BN / 2) + li;
+            const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C32 + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)((p.res32 ? p.res32 : p.C32) + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t k_rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)((p.pack16 ? p.pack16 : (f16*)p.C32) + (long long)m_blk * 2 * p.N), 0, 256 * 2 * p.N * 2, 0x00020000);
+            int voff[2], koff[2];
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int lcol = wn * (BN / 2) + b * 32 + li;
-            const int col = n_blk + lcol;
-            const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
-            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
-            const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
-            const bool pk = p.pack16 && col >= p.pack_from;
-            float t1 = 0.f, t2 = 0.f;
+            for (int x = 0; x < 2; ++x) {
+                voff[x] = (lrow[x] * ldc + col0) * 4;
+                koff[x] = (lrow[x] * 2 * p.N + col0) * 2;
+            }
+            auto run = [&](auto res_c) {
+                constexpr bool RES = decltype(res_c)::value;
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                float r[16];
-                int rowv[16];
+                for (int b = 0; b < TN; ++b) {
+                    const int col = col0 + b * 32;
+                    const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
+                    const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+                    const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+                    const bool pk = p.pack16 && col >= p.pack_from;      // uniform per 32-column block
+                    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    rowv[e] = c_row_natural<TW, IMGS>(wm, a, e, lh);
-                    const int rc = rowv[e] < m_valid ? rowv[e] : 0;
-                    r[e] = p.res32 ? p.res32[(long long)(m_blk + rc) * ldc + col] : 0.f;
+                    for (int a = 0; a < TM; ++a) {
+                        float r[16];
+                        if constexpr (RES) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int x = ((e >> 2) == 1 || (e >> 2) == 2) ? 1 : 0;
+                                const int urow = c_row_uniform<TW, IMGS>(wm, a, e);
+                                r[e] = wave_live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff[x] + b * 128, urow * ldc * 4, 0)) : 0.f;
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int x = ((e >> 2) == 1 || (e >> 2) == 2) ? 1 : 0;
+                            const int urow = c_row_uniform<TW, IMGS>(wm, a, e);
+                            float v = acc[a][b][e] * cs + sh;
+                            v += RES ? r[e] : 0.f;           // as the general loop: + 0 when there is no residual
+                            v = fmaxf(v, lo);
+                            if (wave_live) {
+                                t1 += v;
+                                t2 += v * v;
+                                if (pk) {
+                                    vmax = fmaxf(vmax, fabsf(v));
+                                    const f16 hv = (f16)v;
+                                    const f16 lv = (f16)((v - (float)hv) * 2048.0f);
+                                    // (pairing neighbouring lanes' values into one dword store per lane - DPP quad_perm - was measured: slower)
+                                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), k_rs, koff[x] + b * 64, urow * 2 * p.N * 2, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lv), k_rs, koff[x] + b * 64 + p.N * 2, urow * 2 * p.N * 2, 0);
+                                } else {
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff[x] + b * 128, urow * ldc * 4, 0);
+                                }
+                            }
+                        }
+                    }
+                    s1[b] = t1;
+                    s2[b] = t2;
                 }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = acc[a][b][e] * cs + sh;
-                    v += r[e];
-                    v = fmaxf(v, lo);
-                    if (rowv[e] < m_valid) {
-                        t1 += v;
-                        t2 += v * v;
-                        if (pk) {   // [yh | yl'] for the next convolution's loader (uniform per 32-column tile: pack_from % 32 == 0)
-                            vmax = fmaxf(vmax, fabsf(v));
-                            const f16 hv = (f16)v;
-                            f16* dst = p.pack16 + (long long)(m_blk + rowv[e]) * 2 * p.N + col;
-                            dst[0] = hv;
-                            dst[p.N] = (f16)((v - (float)hv) * 2048.0f);
-                        } else if (!(p.ablate & 64)) {
-                            p.C32[(long long)(m_blk + rowv[e]) * ldc + col] = v;
-                        } else {
-                            asm volatile("" ::"v"(v));
+            };
+            if (p.res32) run(std::true_type{});
+            else run(std::false_type{});
+        } else {
+    #pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int lcol = wn * (BN / 2) + b * 32 + li;
+                const int col = n_blk + lcol;
+                const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
+                const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+                const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+                const bool pk = p.pack16 && col >= p.pack_from;
+                float t1 = 0.f, t2 = 0.f;
+    #pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    float r[16];
+                    int rowv[16];
+    #pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        rowv[e] = c_row_natural<TW, IMGS>(wm, a, e, lh);
+                        const int rc = rowv[e] < m_valid ? rowv[e] : 0;
+                        r[e] = p.res32 ? p.res32[(long long)(m_blk + rc) * ldc + col] : 0.f;
+                    }
+    #pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[a][b][e] * cs + sh;
+                        v += r[e];
+                        v = fmaxf(v, lo);
+                        if (rowv[e] < m_valid) {
+                            t1 += v;
+                            t2 += v * v;
+                            if (pk) {   // [yh | yl'] for the next convolution's loader (uniform per 32-column tile: pack_from % 32 == 0)
+                                vmax = fmaxf(vmax, fabsf(v));
+                                const f16 hv = (f16)v;
+                                f16* dst = p.pack16 + (long long)(m_blk + rowv[e]) * 2 * p.N + col;
+                                dst[0] = hv;
+                                dst[p.N] = (f16)((v - (float)hv) * 2048.0f);
+                            } else if (!(p.ablate & 64)) {
+                                p.C32[(long long)(m_blk + rowv[e]) * ldc + col] = v;
+                            } else {
+                                asm volatile("" ::"v"(v));
+                            }
                         }
                     }
                 }
+                s1[b] = t1;
+                s2[b] = t2;
             }
-            s1[b] = t1;
-            s2[b] = t2;
         }
         if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;   // a packed activation f16 cannot hold: the context reports it
         if (p.stats) {   // per 128 natural rows: waves wm 0,1 own rows 0..127, wm 2,3 rows 128..255 in every geometry
@@ -793,6 +884,7 @@ template <int TW, int IMGS, int LW, bool SPLIT = false>
 int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
     p.fault = ctx->fault;
+    p.general_epi = !ctx->split_lean_epi;
     p.pair_early = ctx->split_pair == 2;
     p.loader_prio = ctx->f16_loader_prio == 2 || (ctx->f16_loader_prio == 1 && SPLIT);
     p.frag_ahead = ctx->f16_frag_ahead;

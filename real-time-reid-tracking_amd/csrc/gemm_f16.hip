@@ -359,6 +359,69 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
     if constexpr (SPLIT) {   // fp32 epilogue straight from the accumulators (see conv3x3_f16.hip, SPLIT build)
         float s1[TN], s2[TN];
         float vmax = 0.f;   // largest packed magnitude (range guard, conv3x3_f16.hip)
+        // lean form, as in conv3x3_f16.hip: buffer instructions with the row in the scalar offset, whole waves skipped in a ragged
+        // tile (M % 128 == 0: its 128 rows belong to the waves wm 0, 1); the arithmetic is the general loop's
+        static_assert(WM == 4, "the SPLIT build is the 128-wide tile: four waves along M, 64 rows each");
+        const bool lean = !p.general_epi && (long long)BM * ldc * 4 < 0x7fffff00ll && (long long)BM * 2 * p.N * 2 < 0x7fffff00ll &&
+                          (m_valid >= BM || m_valid == 128);
+        if (lean) {
+            const bool wave_live = m_valid >= BM || wm < 2;
+            const int col0 = n_blk + wn * WTN + li;
+            const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C32 + (long long)m_blk * ldc), 0, BM * ldc * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)((p.res32 ? p.res32 : p.C32) + (long long)m_blk * ldc), 0, BM * ldc * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t k_rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)((p.pack16 ? p.pack16 : (f16*)p.C32) + (long long)m_blk * 2 * p.N), 0, BM * 2 * p.N * 2, 0x00020000);
+            const int voff = (4 * lh * ldc + col0) * 4, koff = (4 * lh * 2 * p.N + col0) * 2;
+            auto run = [&](auto res_c) {
+                constexpr bool RES = decltype(res_c)::value;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int col = col0 + b * 32;
+                    const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
+                    const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+                    const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+                    const bool pk = p.pack16 && col >= p.pack_from;
+                    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        float r[16];
+                        if constexpr (RES) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int urow = wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2);
+                                r[e] = wave_live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff + b * 128, urow * ldc * 4, 0)) : 0.f;
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int urow = wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2);
+                            float v = acc[a][b][e] * cs + sh;
+                            v += RES ? r[e] : 0.f;
+                            v = fmaxf(v, lo);
+                            if (wave_live) {
+                                t1 += v;
+                                t2 += v * v;
+                                if (pk) {
+                                    vmax = fmaxf(vmax, fabsf(v));
+                                    const f16 hv = (f16)v;
+                                    const f16 lv = (f16)((v - (float)hv) * 2048.0f);
+                                    // (pairing neighbouring lanes' values into one dword store per lane - DPP quad_perm - was measured: slower)
+                                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), k_rs, koff + b * 64, urow * 2 * p.N * 2, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lv), k_rs, koff + b * 64 + p.N * 2, urow * 2 * p.N * 2, 0);
+                                } else {
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff + b * 128, urow * ldc * 4, 0);
+                                }
+                            }
+                        }
+                    }
+                    s1[b] = t1;
+                    s2[b] = t2;
+                }
+            };
+            if (p.res32) run(std::true_type{});
+            else run(std::false_type{});
+        } else {
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int lcol = wn * WTN + b * 32 + li;
@@ -400,6 +463,7 @@ __global__ __launch_bounds__(512, (LIN && BN <= 128) ? 4 : 2) void gemm_f16_kern
             }
             s1[b] = t1;
             s2[b] = t2;
+        }
         }
         if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;
         if (p.stats) {   // per 128-row tile: the block covers two of them
@@ -788,6 +852,7 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
 int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p_in, int kind, double flops, double bytes) {
     Gemm16Params p = p_in;
     p.fault = ctx->fault;
+    p.general_epi = !ctx->split_lean_epi;
     ARG_CHECK(p.M > 0 && p.M % 128 == 0 && p.N % 128 == 0 && p.K % 32 == 0 && p.ldb % 8 == 0 && p.C32 && p.zero_page &&
               (p.split_terms == 3 || p.split_terms == 4) && p.Cin % (64 * p.split_terms) == 0 && p.K == p.R * p.S * p.Cin);
     prof_begin(ctx, kind, flops, bytes);

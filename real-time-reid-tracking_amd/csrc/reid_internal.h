@@ -158,6 +158,7 @@ struct Gemm16Params {
     int pack_out;               // LIN staged epilogue: C is [yh | yl'] f16 [M][2 n_real] (hi tile at column n_blk, low tile n_real further)
     int a_k;                    // LIN dense build with split_terms != 0: columns of A ([xh | xl'] = 2 K); K-tile k0 reads column k0 % a_k
     int pair_early;             // PAIR loop: the step barrier in front of the step's last MFMA group (REID_SPLIT_PAIR=2) instead of behind it
+    int general_epi;            // SPLIT builds: the general (predicated, 64-bit addressed) epilogue instead of the lean one (A/B)
     int ablate;                 // experiments only (reid_debug_conv_split): phases of the PAIR loop switched off, results wrong
     int* fault;                 // reid_ctx.fault (may be null): [0] raised when a value packed as [yh | yl'] lies outside f16's range
 };
@@ -356,6 +357,7 @@ struct reid_ctx {
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
     int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
     int pack_epilogue = 1;   // precision 2: conv1 epilogues write [yh | yl'] for conv2 themselves (REID_PACK_EPILOGUE=0: fp32 + pack passes)
+    int split_lean_epi = 1;  // precision 2: buffer-instruction epilogue of the SPLIT convolution builds (REID_SPLIT_LEAN=0: general loop)
     int split_pair = 0;      // precision 2, 128-wide halo tiles (REID_SPLIT_PAIR): 0 = three passes over the virtual channels (default),
                              // 1 / 2 = the operand-sharing PAIR order of conv3x3_f16.hip (barrier behind / in front of a step's last
                              // MFMA group).  Measured at 1024 crops per pass: +1.1 % / -0.9 %; it changes the summation order, and the
