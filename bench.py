@@ -72,6 +72,19 @@ def traffic_from_profile(tag):
         return None
 
 
+def traffic_source(tag):
+    """Where `roofline.traffic` comes from: the committed PMC summary and the commit its library was built from (a constant of
+    that profile, not a measurement of this run)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % tag)))
+    if not cands:
+        return None
+    try:
+        return "profiles/%s (commit %s)" % (os.path.basename(cands[-1]), json.load(open(cands[-1])).get("commit", "unknown"))
+    except ValueError:
+        return None
+
+
 def cpu_baseline_embed(sd, budget_s=12.0):
     """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload:
     batch 64 (reference default --bs 64), all host cores."""
@@ -225,6 +238,7 @@ def run_embed(job, args):
                            "convolution kernels of the fp32 path, v_mfma_f32_32x32x2_f32 (exact fp32): conv_f32_dma_kernel (implicit GEMM, LDS-DMA staging, all 3x3 / 1x1 convs) + the 7x7 stem"),
                 "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile("conv_f16" if f16 else "conv_f16x3" if x3 else "conv_f32"),
+                "traffic_source": traffic_source("conv_f16" if f16 else "conv_f16x3" if x3 else "conv_f32"),
                 "launches": conv["launches"], "avg_launch_us": round(conv["ms"] * 1e3 / max(1, conv["launches"]), 2),
                 "algorithmic_gflop_per_launch": round(conv["flops"] / max(1, conv["launches"]) / 1e9, 3),
                 "algorithmic_bytes_per_launch": round(conv["bytes"] / max(1, conv["launches"]), 1),

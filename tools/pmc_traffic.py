@@ -65,8 +65,10 @@ write = per_kernel(sys.argv[2], "WRITE_SIZE")
 launches = sum(v[0] for v in fetch.values())
 fetch_kb = sum(v[1] for v in fetch.values())
 write_kb = sum(v[1] for v in write.values())
+import os
 res = {
     "kernel_class": LABEL,
+    "commit": os.environ.get("REID_COMMIT", "unknown"),    # the tree the profiled library was built from (passed by the caller: the GPU box has no .git)
     "command": ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload swin --crops 512 --steps 1 --warmup 1 --no-cpu --single --precision %s" % MODE[5:]
                 if MODE.startswith("swin_") else
                 "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload market --steps 2 --warmup 1 --no-cpu"
