@@ -645,8 +645,9 @@ def run_market(job, args):
            "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4]: 3368 x 15913 x 512, gallery rows sharded over %d rank(s): shard distance matrix, then "
-                                  "the search - top-%d per shard with the selection fused into the distance GEMM (no matrix), all-gather "
-                                  "(fp32 distances, int32 indices), device k-way merge" % (world, k)},
+                                  "the search - top-%d per shard: candidates from an fp32-class GEMM on the f16 matrix pipe, exact fp32 "
+                                  "refinement (knn_wide.hip: the numbers and order of the fused fp32 search, which shards below 2^25 pairs "
+                                  "still take), all-gather (fp32 distances, int32 indices), device k-way merge" % (world, k)},
            "distmat_shard_ms": round(dist_ms, 3), "search_ms": round(search_ms, 3),
            "search_tflops": round(2.0 * nq * (hi - lo) * d / (search_ms * 1e-3) / 1e12, 2), "rank1_top%d" % k: rank1,
            "roofline": {"kernel": "gemm_f32_dma_kernel<E_DIST> (dense LDS-DMA GEMM + distance epilogue, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
