@@ -138,6 +138,9 @@ class Job:
             # torch.distributed job on this pool runs on.  A single-rank run never imports torch.
             import torch                    # noqa: F401
             import torch.distributed        # noqa: F401
+            # one node (the bench contract): the gloo group that carries the communicator id uses the loopback interface - gloo starts
+            # from the hostname, which may not resolve on a pool box (RCCL enumerates interfaces itself and is left alone)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         self.eng = get_engine(self.device)  # launches + RCCL calls run on the context's own (non-null, non-blocking) HIP stream
         # RCCL communicator behind the C ABI (reid_comm_init) - the only transport: if it cannot be brought up the RCCL error is
         # printed and the job exits non-zero.  REID_BENCH_COMM1=1: a real 1-rank communicator on one GPU
