@@ -399,6 +399,61 @@ extern "C" int reid_debug_linear_rows(reid_ctx* ctx, const float* x, const float
     return REID_OK;
 }
 
+// The fused pair of linears (two_linear_f16.hip) on its own: out = res + w2 . act(w1 . x + b1) + b2 through launch_split_pack +
+// launch_two_linear, x [m][c], w1 [hid][c], w2 [c][hid], res / out [m][c] fp32 on the host.  iters > 1 repeats the launch and
+// returns the mean time in *ms (may be null).  The context must be in precision 2.
+extern "C" int reid_debug_two_linear(reid_ctx* ctx, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                     const float* res, int m, int c, int hid, int act, int iters, float* out, float* ms) {
+    ARG_CHECK(ctx && x && w1 && b1 && w2 && b2 && res && out && m > 0 && iters >= 1);
+    CTX_GUARD(ctx);
+    ARG_CHECK(two_linear_supported(ctx, m, c, hid));
+    typedef _Float16 f16;
+    float *x32, *dw1, *dw2, *db1, *db2, *r32, *o32;
+    f16* a16;
+    REID_TRY(ctx_ws(ctx, "dbg2.x", (size_t)m * c * 4, (void**)&x32));
+    REID_TRY(ctx_ws(ctx, "dbg2.w1", (size_t)hid * c * 4, (void**)&dw1));
+    REID_TRY(ctx_ws(ctx, "dbg2.w2", (size_t)hid * c * 4, (void**)&dw2));
+    REID_TRY(ctx_ws(ctx, "dbg2.b1", (size_t)hid * 4, (void**)&db1));
+    REID_TRY(ctx_ws(ctx, "dbg2.b2", (size_t)c * 4, (void**)&db2));
+    REID_TRY(ctx_ws(ctx, "dbg2.res", (size_t)m * c * 4, (void**)&r32));
+    REID_TRY(ctx_ws(ctx, "dbg2.out", (size_t)m * c * 4, (void**)&o32));
+    REID_TRY(ctx_ws(ctx, "dbg2.a16", (size_t)m * 2 * c * 2, (void**)&a16));
+    HIP_TRY(hipMemcpyAsync(x32, x, (size_t)m * c * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dw1, w1, (size_t)hid * c * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dw2, w2, (size_t)hid * c * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db1, b1, (size_t)hid * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db2, b2, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(r32, res, (size_t)m * c * 4, hipMemcpyHostToDevice, ctx->stream));
+    REID_TRY(launch_split_pack(ctx, x32, m, c, a16));
+    // the tiled weight images are cached by blob address: this harness re-uses its buffers, so drop what an earlier call left
+    for (const void* key : {(const void*)((const char*)dw1 + 1), (const void*)((const char*)dw2 + 1)}) {
+        auto it = ctx->split_w.find(key);
+        if (it != ctx->split_w.end()) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(it->second);
+            ctx->split_w.erase(it);
+        }
+    }
+    REID_TRY(launch_two_linear(ctx, a16, m, c, hid, dw1, db1, dw2, db2, act, r32, o32));
+    if (iters > 1) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+        for (int i = 0; i < iters; ++i) REID_TRY(launch_two_linear(ctx, a16, m, c, hid, dw1, db1, dw2, db2, act, r32, o32));
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        if (ms) *ms = t / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    HIP_TRY(hipMemcpyAsync(out, o32, (size_t)m * c * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return REID_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ loop-back communicator (tests)
 // Several contexts of THIS process on ONE device act as the ranks of a job: every collective of csrc/comm.hip
 // (reid_allgather_dev and what is built on it - ragged row gathers, reid_frame_gather, reid_knn_gallery_sharded_dev -

@@ -196,6 +196,9 @@ bool conv3x3_f16_supported(const Gemm16Params& p);   // conv3x3_f16.hip: 3x3 s1 
 int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);
 int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build, see Gemm16Params
 int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build of gemm_f16 (im2col: strided / 1x1)
+bool two_linear_supported(const reid_ctx*, long long T, int C, int hid);
+int launch_two_linear(reid_ctx*, const _Float16* a16, long long T, int C, int hid, const float* w1, const float* b1, const float* w2,
+                      const float* b2, int act, const float* res, float* out);
 int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out, const float* d_scale = nullptr);           // fp32 [rows][C] -> f16 [rows][2C] = [xh | xl']
 int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, int terms, _Float16* out, const float* d_scale = nullptr);  // fp32 [cout][taps][cin] -> f16 [cout][taps][terms * cin]
 // fp16 elementwise kernels (elementwise_f16.hip)
@@ -374,6 +377,8 @@ struct reid_ctx {
     int select_two_pass = 0; // REID_SELECT_TWO_PASS=1: arg-min / k-NN through the full distance matrix (A/B against dist_select.hip)
     int swin_stop = -1;      // diagnostics (REID_SWIN_STOP = block * 10 + phase): skip the rest of the Swin blocks after that point
     int swin_fold = 1;       // Swin, fp16-storage mode: to_out and post_proj folded into one Linear (REID_SWIN_FOLD=0: two launches)
+    int swin_two_linear = 1; // Swin, fp32-class mode, C = 96: to_out -> post_proj and fc1 -> GELU -> fc2 as one launch each, the hidden
+                             // values in registers (two_linear_f16.hip; REID_SWIN_TWO_LINEAR=0: two launches through gemm_f16.hip)
     int swin_attn_mfma = 1;  // Swin window attention (REID_SWIN_ATTN): 1 = matrix cores in fp16-storage mode, VALU kernel in exact fp32
                              // (v_mfma_f32_32x32x2_f32 runs at the fp32 VALU rate: no gain); 2 = matrix cores in both; 0 = VALU in both
     int f16_split_k = 1;     // LDS-halo kernel: split the input channels over 2-4 blocks per tile when a launch has < 128 tiles (REID_F16_SPLITK)

@@ -1896,3 +1896,41 @@ def test_bench_prints_one_json_line_and_exits_cleanly():
     d = json.loads(lines[0])
     assert d["unit"] == "crops/s" and d["n_gpus"] == 1 and d["value"] > 0 and d["dtype"] == "f16x3"
     assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,hid,act", [(2048, 384, 1), (1024 + 49, 96, 0), (4096 + 160, 384, 1)])
+def test_fused_pair_of_linears_matches_float64_and_is_position_invariant(eng_w0, m, hid, act):
+    """csrc/two_linear_f16.hip (precision 2, Swin stage 1: to_out -> post_proj + x, fc1 -> GELU -> fc2 + x; swin_transformer.py:23-39,
+    66-82,191-232) through reid_debug_two_linear: out = res + w2 . act(w1 . x + b1) + b2 against float64 at the fp32-class bound,
+    ragged token counts, and copies of one row at different tile positions bit-identical (images are independent in eval mode)."""
+    import ctypes as C
+    import math
+    eng, _ = eng_w0
+    fn = _ffi.debug_lib().reid_debug_two_linear
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p] * 2
+    rng = np.random.default_rng(m + hid)
+    c, R = 96, 61
+    base = rng.normal(size=(R, c)).astype(np.float32)
+    rb = rng.normal(size=(R, c)).astype(np.float32)
+    ids = np.asarray([(i * 5 + i // 7) % R for i in range(m)])
+    x, res = np.ascontiguousarray(base[ids]), np.ascontiguousarray(rb[ids])
+    w1 = (rng.normal(size=(hid, c)) / np.sqrt(c)).astype(np.float32)
+    b1 = rng.normal(size=hid).astype(np.float32)
+    w2 = (rng.normal(size=(c, hid)) / np.sqrt(hid)).astype(np.float32)
+    b2 = rng.normal(size=c).astype(np.float32)
+    out = np.empty((m, c), np.float32)
+    eng.set_precision(2)
+    try:
+        _ffi.check(fn(eng.h, x.ctypes.data, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data, res.ctypes.data, m, c, hid, act, 1,
+                      out.ctypes.data, None))
+    finally:
+        eng.set_precision(0)
+    h = base.astype(np.float64) @ w1.T.astype(np.float64) + b1
+    if act:
+        h = 0.5 * h * (1.0 + np.vectorize(math.erf)(h / math.sqrt(2.0)))
+    ref = (h @ w2.T.astype(np.float64) + b2 + rb)[ids]
+    assert np.abs(out - ref).max() <= 1.5e-6 * np.abs(ref).max()          # fp32-class: three f16 products, fp32 sums (measured 3e-7)
+    first = [int(np.flatnonzero(ids == r)[0]) for r in range(R)]
+    assert np.array_equal(out, out[first][ids])
