@@ -36,9 +36,11 @@ int reid_debug_linear(reid_ctx* ctx, int m, int n, int k, int mode, int iters, f
 int reid_debug_linear_rows(reid_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, int m, int n, int k,
                            int mode, int flags, float* out);
 /* The fused pair of linears of the fp32-class mode (csrc/two_linear_f16.hip) alone: out = res + w2 . act(w1 . x + b1) + b2, x / res /
- * out [m][c], w1 [hid][c], w2 [c][hid], all fp32 on the host; act 1 = erf-GELU.  iters > 1: the launch repeated, mean time in *ms. */
+ * out [m][c], w1 [hid][c], w2 [c][hid], all fp32 on the host; act 1 = erf-GELU.  iters > 1: the launch repeated, mean time in *ms.
+ * ln_g / ln_b [c] (or both null): the first linear reads LayerNorm(x) (eps 1e-5), made in the kernel's prologue. */
 int reid_debug_two_linear(reid_ctx* ctx, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                          const float* res, int m, int c, int hid, int act, int iters, float* out, float* ms);
+                          const float* res, int m, int c, int hid, int act, int iters, float* out, float* ms, const float* ln_g,
+                          const float* ln_b);
 /* Experiment switch of the fused distance + selection kernel: 0 product behaviour, 1 / 2 skip phases (INCOMPLETE results: timing
  * only), 4 print candidate-list statistics. */
 int reid_debug_select_exp(reid_ctx* ctx, int mode);

@@ -403,7 +403,8 @@ extern "C" int reid_debug_linear_rows(reid_ctx* ctx, const float* x, const float
 // launch_two_linear, x [m][c], w1 [hid][c], w2 [c][hid], res / out [m][c] fp32 on the host.  iters > 1 repeats the launch and
 // returns the mean time in *ms (may be null).  The context must be in precision 2.
 extern "C" int reid_debug_two_linear(reid_ctx* ctx, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                                     const float* res, int m, int c, int hid, int act, int iters, float* out, float* ms) {
+                                     const float* res, int m, int c, int hid, int act, int iters, float* out, float* ms, const float* ln_g,
+                                     const float* ln_b) {
     ARG_CHECK(ctx && x && w1 && b1 && w2 && b2 && res && out && m > 0 && iters >= 1);
     CTX_GUARD(ctx);
     ARG_CHECK(two_linear_supported(ctx, m, c, hid));
@@ -418,6 +419,14 @@ extern "C" int reid_debug_two_linear(reid_ctx* ctx, const float* x, const float*
     REID_TRY(ctx_ws(ctx, "dbg2.res", (size_t)m * c * 4, (void**)&r32));
     REID_TRY(ctx_ws(ctx, "dbg2.out", (size_t)m * c * 4, (void**)&o32));
     REID_TRY(ctx_ws(ctx, "dbg2.a16", (size_t)m * 2 * c * 2, (void**)&a16));
+    float *dg = nullptr, *dbt = nullptr;
+    if (ln_g && ln_b) {   // LayerNorm(x) in the kernel instead of the packed input
+        REID_TRY(ctx_ws(ctx, "dbg2.lng", (size_t)c * 4, (void**)&dg));
+        REID_TRY(ctx_ws(ctx, "dbg2.lnb", (size_t)c * 4, (void**)&dbt));
+        HIP_TRY(hipMemcpyAsync(dg, ln_g, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dbt, ln_b, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const _Float16* ain = dg ? nullptr : a16;
     HIP_TRY(hipMemcpyAsync(x32, x, (size_t)m * c * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dw1, w1, (size_t)hid * c * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dw2, w2, (size_t)hid * c * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -434,13 +443,13 @@ extern "C" int reid_debug_two_linear(reid_ctx* ctx, const float* x, const float*
             ctx->split_w.erase(it);
         }
     }
-    REID_TRY(launch_two_linear(ctx, a16, m, c, hid, dw1, db1, dw2, db2, act, r32, o32));
+    REID_TRY(launch_two_linear(ctx, ain, m, c, hid, dw1, db1, dw2, db2, act, r32, o32, x32, dg, dbt));
     if (iters > 1) {
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, ctx->stream));
-        for (int i = 0; i < iters; ++i) REID_TRY(launch_two_linear(ctx, a16, m, c, hid, dw1, db1, dw2, db2, act, r32, o32));
+        for (int i = 0; i < iters; ++i) REID_TRY(launch_two_linear(ctx, ain, m, c, hid, dw1, db1, dw2, db2, act, r32, o32, x32, dg, dbt));
         HIP_TRY(hipEventRecord(e1, ctx->stream));
         HIP_TRY(hipEventSynchronize(e1));
         float t = 0.f;

@@ -198,7 +198,8 @@ int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double 
 int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build of gemm_f16 (im2col: strided / 1x1)
 bool two_linear_supported(const reid_ctx*, long long T, int C, int hid);
 int launch_two_linear(reid_ctx*, const _Float16* a16, long long T, int C, int hid, const float* w1, const float* b1, const float* w2,
-                      const float* b2, int act, const float* res, float* out);
+                      const float* b2, int act, const float* res, float* out, const float* x32 = nullptr, const float* ln_g = nullptr,
+                      const float* ln_b = nullptr);
 int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out, const float* d_scale = nullptr);           // fp32 [rows][C] -> f16 [rows][2C] = [xh | xl']
 int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, int terms, _Float16* out, const float* d_scale = nullptr);  // fp32 [cout][taps][cin] -> f16 [cout][taps][terms * cin]
 // fp16 elementwise kernels (elementwise_f16.hip)
@@ -379,6 +380,7 @@ struct reid_ctx {
     int swin_fold = 1;       // Swin, fp16-storage mode: to_out and post_proj folded into one Linear (REID_SWIN_FOLD=0: two launches)
     int swin_two_linear = 1; // Swin, fp32-class mode, C = 96: to_out -> post_proj and fc1 -> GELU -> fc2 as one launch each, the hidden
                              // values in registers (two_linear_f16.hip; REID_SWIN_TWO_LINEAR=0: two launches through gemm_f16.hip)
+    int two_linear_cfg = 0;  // experiment: 1 = eight-wave blocks, three steps resident, barrier in mid-step (REID_TWO_LINEAR_CFG)
     int swin_attn_mfma = 1;  // Swin window attention (REID_SWIN_ATTN): 1 = matrix cores in fp16-storage mode, VALU kernel in exact fp32
                              // (v_mfma_f32_32x32x2_f32 runs at the fp32 VALU rate: no gain); 2 = matrix cores in both; 0 = VALU in both
     int f16_split_k = 1;     // LDS-halo kernel: split the input channels over 2-4 blocks per tile when a launch has < 128 tiles (REID_F16_SPLITK)

@@ -1334,12 +1334,12 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                     REID_TRY(linear(ctx, nullptr, T, C, k.out_w, k.out_b, C, 0, nullptr, nullptr, att16, (f16*)tmp));   // [T][2C] = tmp's bytes
                     REID_TRY(linear(ctx, nullptr, T, C, k.post_w, k.post_b, C, 0, xin, xcur, (const f16*)tmp));
                 }
-                prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
-                launch_layernorm_packed(ctx, xcur, T, C, k.ln2_g, k.ln2_b, ln16);
-                prof_end(ctx);
-                if (two_linear_supported(ctx, T, C, 4 * C)) {
-                    REID_TRY(launch_two_linear(ctx, ln16, T, C, 4 * C, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, 1, xcur, xcur));
+                if (two_linear_supported(ctx, T, C, 4 * C)) {   // LayerNorm 2 in the kernel's prologue: x is read where it is updated
+                    REID_TRY(launch_two_linear(ctx, nullptr, T, C, 4 * C, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, 1, xcur, xcur, xcur, k.ln2_g, k.ln2_b));
                 } else {
+                    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
+                    launch_layernorm_packed(ctx, xcur, T, C, k.ln2_g, k.ln2_b, ln16);
+                    prof_end(ctx);
                     REID_TRY(linear(ctx, nullptr, T, C, k.fc1_w, k.fc1_b, 4 * C, 1, nullptr, nullptr, ln16, big16));
                     REID_TRY(linear(ctx, nullptr, T, 4 * C, k.fc2_w, k.fc2_b, C, 0, xcur, xcur, big16));
                 }

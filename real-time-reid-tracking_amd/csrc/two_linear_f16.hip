@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void two_linear_w2_tiles_kernel(const float* _
 }
 
 struct TwoLinearParams {
-    const f16* A;        // [T][2C]: [xh | xl']
+    const f16* A;        // [T][2C]: [xh | xl'] - or null: LayerNorm(X32) computed here
+    const float* X32;    // [T][C] fp32 (LN builds)
+    const float* ln_g;   // [C]
+    const float* ln_b;
     long long T;
     const f16* W1t;      // two_linear_w1_tiles_kernel
     const f16* W2t;      // two_linear_w2_tiles_kernel
@@ -80,6 +83,7 @@ struct TwoLinearParams {
     float* out;          // [T][C] fp32
     int hid;
     int* fault;
+    int ablate;          // experiments (timing only): 1 = no weight refills after the first two steps, 2 = no block barriers
 };
 
 // One block = NW waves x 32 tokens.  STEP it (0 .. NG + 1) of a wave, NG = HID / 32 hidden groups:
@@ -93,8 +97,8 @@ struct TwoLinearParams {
 // against 320 in this order.)
 // The weights of a step ([W1 group it | W2 group it - 2], 2-KB tiles as the load-time kernels wrote them) are one linear
 // global -> LDS DMA copy into a ring of three steps; one block barrier per step.
-template <int C, int NW, bool ACT, int AHEAD, int TT>
-__global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_kernel(const TwoLinearParams p) {
+template <int C, int NW, bool ACT, int AHEAD, int TT, int NS, bool LN>
+__global__ __launch_bounds__(NW * 64, (TT == 1 && C <= 96) ? 2 : 1) void two_linear_f16x3_kernel(const TwoLinearParams p) {
     constexpr int NT = 3 * C / 32;           // tiles per group and GEMM: GEMM 1 K-tiles of 32 / GEMM 2 (output tile, part)
     constexpr int KS1 = 3 * C / 16;          // GEMM 1 k-steps over the virtual K
     constexpr int KR = 2 * C / 16;           // x fragments held (real K)
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
     constexpr int SB = 2 * HB;               // ... of a step
     constexpr int PI = SB / 1024;            // DMA wave-instructions per step
     constexpr int IPW = (PI + NW - 1) / NW;  // ... per wave (the surplus repeats earlier pieces: same bytes, same place)
-    constexpr int NS = 3;                    // steps resident: being read / landed or landing / being issued
+    constexpr bool MID = NS == 3;            // three steps resident: the block barrier sits in the middle of a step (below); two: at its start
     constexpr int BT = NW * 32 * TT;         // tokens per block (TT 32-token tiles per wave)
     static_assert(KS1 == NM2, "the two GEMMs of a group are the same number of MFMAs");
     static_assert(NS * SB + 16 * C <= 160 * 1024, "LDS budget");
@@ -118,18 +122,68 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
     const int NG = p.hid / 32;
     const int last = NG + 1;                 // steps 0 .. NG + 1
 
+    __shared__ __attribute__((aligned(16))) float lns[LN ? 2 * C : 4];
     for (int i = tid; i < p.hid; i += NW * 64) b1s[i] = p.b1[i];
+    if constexpr (LN) {
+        for (int i = tid; i < C; i += NW * 64) {
+            lns[i] = p.ln_g[i];
+            lns[C + i] = p.ln_b[i];
+        }
+    }
     __syncthreads();                         // (before any DMA is in flight: the only full drain of the kernel)
 
     // ---- this lane's token row as B fragments: k-step r covers columns 16 r .. 16 r + 15 of [xh | xl'], 8 per lane half
     half8 xf[TT][KR];
+    unsigned xmax = 0u;
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         long long tok = tok0 + (wave * TT + t) * 32 + li;
         if (tok >= p.T) tok = p.T - 1;       // a ragged last block: a valid row, its results fall outside the store descriptor
-        const f16* arow = p.A + tok * (2 * C) + 8 * lh;
+        if constexpr (LN) {
+            // LayerNorm (swin_transformer.py:195,228; eps 1e-5) of the fp32 row, then the [yh | yl'] split, in registers: the lane
+            // holds columns 16 r + 8 lh .. + 7 (half the row), its partner lane ^ 32 the rest; two-pass statistics as
+            // layernorm_v4_kernel's
+            constexpr int KH = C / 16;
+            const float* xrow = p.X32 + tok * C + 8 * lh;
+            f32x4 xv[2 * KH];
 #pragma unroll
-        for (int r = 0; r < KR; ++r) xf[t][r] = *(const half8*)(arow + 16 * r);
+            for (int r = 0; r < KH; ++r) {
+                xv[2 * r] = *(const f32x4*)(xrow + 16 * r);
+                xv[2 * r + 1] = *(const f32x4*)(xrow + 16 * r + 4);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2 * KH; ++i) sum += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2 * KH; ++i) {
+                const f32x4 d = xv[i] - mean;
+                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+            q += __shfl_xor(q, 32);
+            const float rstd = 1.0f / sqrtf(q / C + 1e-5f);
+#pragma unroll
+            for (int r = 0; r < KH; ++r) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 gg = *(const f32x4*)&lns[16 * r + 8 * lh + 4 * h], bb = *(const f32x4*)&lns[C + 16 * r + 8 * lh + 4 * h];
+                    const f32x4 y = (xv[2 * r + h] - mean) * rstd * gg + bb;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xmax = range_acc(xmax, y[i]);
+                        const f16 hv = cvt_f16_rn(y[i]);
+                        xf[t][r][4 * h + i] = hv;
+                        xf[t][KH + r][4 * h + i] = cvt_f16_rn((y[i] - (float)hv) * 2048.0f);
+                    }
+                }
+            }
+        } else {
+            const f16* arow = p.A + tok * (2 * C) + 8 * lh;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) xf[t][r] = *(const half8*)(arow + 16 * r);
+        }
     }
 
     auto issue_step = [&](int it, int slot) {   // absent halves (it >= NG, it < 2) copy a neighbouring group: never read
@@ -145,7 +199,7 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
         }
     };
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_step(s, s);     // NG >= 1: at least three steps
+    for (int s = 0; s < 2; ++s) issue_step(s, s);          // NG >= 1: at least three steps
 
     f32x16 oacc[TT][NJ];
 #pragma unroll
@@ -160,7 +214,7 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) foff[kk] = li * 64 + (((kk * 2 + lh) ^ (li >> 2)) & 3) * 16;
 
-    int slot_c = 0, slot_i = NS - 1;
+    int slot_c = 0, slot_i = MID ? 2 : 0;    // slot being read / slot the next DMA goes to
     float vmax = 0.f;
     f32x16 hcur[TT], hnext[TT];              // GEMM 1 accumulators: the group in the epilogue / the group being summed
     half8 Hh[TT][2], Hl[TT][2];              // the group GEMM 2 reads
@@ -182,12 +236,14 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
     // The block barrier of a step sits in its MIDDLE: it publishes step it + 1 (every wave's DMA pieces have landed) and frees
     // the slot of step it - 1 (every wave is past it) for step it + 2 - so the fragment reads run on across the step boundary
     // (the last AHEAD chunks of a step read the first fragments of the next) and no wave starts a step with an empty pipeline.
-    WAIT_VMCNT(IPW);                         // step 0 (step 1 may be in flight)
-    RAW_BARRIER();
+    if constexpr (MID) {
+        WAIT_VMCNT(IPW);                     // step 0 (step 1 may be in flight)
+        RAW_BARRIER();
 #pragma unroll
-    for (int m = 0; m < PF; ++m) {
-        pf1[m] = read1(0, m);
-        pf2[m] = read2(0, m);
+        for (int m = 0; m < PF; ++m) {
+            pf1[m] = read1(0, m);
+            pf2[m] = read2(0, m);
+        }
     }
 
     auto step = [&](int it, auto g1_c, auto e_c, auto g2_c) {
@@ -197,10 +253,24 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
         half8 f1[KS1], f2[NM2];
         f32x4 bq[4];
         half8 nHh[TT][2], nHl[TT][2];
+        if constexpr (MID) {
 #pragma unroll
-        for (int m = 0; m < PF; ++m) {
-            f1[m] = pf1[m];
-            f2[m] = pf2[m];
+            for (int m = 0; m < PF; ++m) {
+                f1[m] = pf1[m];
+                f2[m] = pf2[m];
+            }
+        } else {
+            // two slots: own pieces of step it landed -> barrier (everyone's did, step it - 1 has been read) -> step it + 1 into
+            // the slot of step it - 1
+            if (it == 0) WAIT_VMCNT(IPW);    // (steps 0 and 1 were issued before the loop)
+            else WAIT_VMCNT(0);
+            if (!(p.ablate & 2)) RAW_BARRIER();
+            if (it >= 1 && it + 1 <= last && !(p.ablate & 1)) issue_step(it + 1, slot_i);
+#pragma unroll
+            for (int m = 0; m < PF; ++m) {
+                if constexpr (G1) f1[m] = read1(slot_c, m);
+                if constexpr (G2) f2[m] = read2(slot_c, m);
+            }
         }
         if constexpr (E) {
 #pragma unroll
@@ -215,7 +285,7 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            if (c == 8) {
+            if (MID && c == 8) {
                 WAIT_VMCNT(0);               // own pieces of step it + 1 (issued half a step ago; nothing else is in flight)
                 RAW_BARRIER();
                 if (it + 2 <= last) issue_step(it + 2, slot_i);
@@ -227,7 +297,7 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
                     if constexpr (G1) f1[m] = read1(slot_c, m);
                     if constexpr (G2) f2[m] = read2(slot_c, m);
                 }
-            } else if constexpr (!LAST) {    // the next step's first fragments (whichever of the two GEMMs it runs)
+            } else if constexpr (MID && !LAST) {   // the next step's first fragments (whichever of the two GEMMs it runs)
 #pragma unroll
                 for (int m = mlo(c + AHEAD - 16); m < mlo(c + AHEAD - 15); ++m) {
                     pf1[m] = read1(slot_n, m);
@@ -267,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
             if constexpr (G1) hcur[t] = hnext[t];
         }
         slot_c = slot_n;
-        slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
+        if (MID || it >= 1) slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
     };
     const std::true_type Y{};
     const std::false_type N{};
@@ -278,6 +348,7 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
     else step(1, N, Y, N);
     step(NG + 1, N, N, Y);
     if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;   // range guard of the hidden layer's split
+    if constexpr (LN) range_raise(p.fault, xmax);       // ... and of the normalised input's
 
     // ---------------- out = res + oacc 2^-11 + b2: register e of lane half lh is token (e & 3) + 8 (e >> 2) + 4 lh, column = li
 #pragma unroll
@@ -305,23 +376,27 @@ __global__ __launch_bounds__(NW * 64, TT == 1 ? 2 : 1) void two_linear_f16x3_ker
     }
 }
 
-template <int C, int NW, int AHEAD, int TT = 1>
+template <int C, int NW, int AHEAD, int TT, int NS>
 void launch_variant(reid_ctx* ctx, const TwoLinearParams& p, int act) {
     const unsigned grid = (unsigned)((p.T + NW * 32 * TT - 1) / (NW * 32 * TT));
-    if (act) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, true, AHEAD, TT>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, false, AHEAD, TT>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
+    // the builds in use: MLP = LayerNorm + GELU, to_out -> post_proj = packed input, no activation (+ the two mixed forms for tests)
+    if (p.X32 && act) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, true, AHEAD, TT, NS, true>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
+    else if (p.X32) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, false, AHEAD, TT, NS, true>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
+    else if (act) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, true, AHEAD, TT, NS, false>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, false, AHEAD, TT, NS, false>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
 }
 
 }  // namespace
 
 bool two_linear_supported(const reid_ctx* ctx, long long T, int C, int hid) {
-    return ctx->precision == 2 && ctx->swin_two_linear && C == 96 && hid % 32 == 0 && hid <= 4 * C && T >= 1024;
+    return ctx->precision == 2 && ctx->swin_two_linear && (C == 96 || C == 192) && hid % 32 == 0 && hid <= 4 * C && T >= 1024;
 }
 
-// a16: [T][2C] ([xh | xl']); w1 [hid][C], w2 [C][hid] fp32 (the blob's); res / out fp32 [T][C]
+// input: a16 [T][2C] ([xh | xl']) - or, a16 null, LayerNorm(x32 [T][C]; ln_g, ln_b) made in the kernel; w1 [hid][C], w2 [C][hid] fp32
+// (the blob's); res / out fp32 [T][C]
 int launch_two_linear(reid_ctx* ctx, const _Float16* a16, long long T, int C, int hid, const float* w1, const float* b1, const float* w2,
-                      const float* b2, int act, const float* res, float* out) {
-    ARG_CHECK(two_linear_supported(ctx, T, C, hid) && b1 && b2 && res && out);
+                      const float* b2, int act, const float* res, float* out, const float* x32, const float* ln_g, const float* ln_b) {
+    ARG_CHECK(two_linear_supported(ctx, T, C, hid) && b1 && b2 && res && out && (a16 || (x32 && ln_g && ln_b)));
     const int HG = 1;   // one 32-unit hidden tile per group (the tile images are written for any)
     const void* k1 = (const char*)w1 + 1;   // the tiled images live beside the plain split forms (keys: the blob address + 1)
     const void* k2 = (const char*)w2 + 1;
@@ -343,10 +418,13 @@ int launch_two_linear(reid_ctx* ctx, const _Float16* a16, long long T, int C, in
     REID_TRY(tiles(k1, w1, false, &t1));
     REID_TRY(tiles(k2, w2, true, &t2));
     TwoLinearParams p;
-    p.A = a16; p.T = T; p.W1t = (const f16*)t1; p.W2t = (const f16*)t2; p.b1 = b1; p.b2 = b2; p.res = res; p.out = out; p.hid = hid;
+    p.A = a16; p.X32 = a16 ? nullptr : x32; p.ln_g = ln_g; p.ln_b = ln_b; p.T = T; p.W1t = (const f16*)t1; p.W2t = (const f16*)t2; p.b1 = b1; p.b2 = b2; p.res = res; p.out = out; p.hid = hid;
     p.fault = ctx->fault;
+    p.ablate = ctx->two_linear_cfg >> 4;
     prof_begin(ctx, REID_K_CONV_GEMM, 4.0 * T * C * hid, (double)T * C * 12.0 + 8.0 * C * hid);
-    launch_variant<96, 8, 2>(ctx, p, act);
+    if (C == 192) launch_variant<192, 4, 2, 1, 2>(ctx, p, act);
+    else if ((ctx->two_linear_cfg & 15) == 1) launch_variant<96, 8, 2, 1, 3>(ctx, p, act);
+    else launch_variant<96, 4, 2, 1, 2>(ctx, p, act);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;

@@ -1899,20 +1899,24 @@ def test_bench_prints_one_json_line_and_exits_cleanly():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m,hid,act", [(2048, 384, 1), (1024 + 49, 96, 0), (4096 + 160, 384, 1)])
-def test_fused_pair_of_linears_matches_float64_and_is_position_invariant(eng_w0, m, hid, act):
-    """csrc/two_linear_f16.hip (precision 2, Swin stage 1: to_out -> post_proj + x, fc1 -> GELU -> fc2 + x; swin_transformer.py:23-39,
-    66-82,191-232) through reid_debug_two_linear: out = res + w2 . act(w1 . x + b1) + b2 against float64 at the fp32-class bound,
-    ragged token counts, and copies of one row at different tile positions bit-identical (images are independent in eval mode)."""
+@pytest.mark.parametrize("m,c,hid,act,ln", [(2048, 96, 384, 1, 1), (1024 + 49, 96, 96, 0, 0), (4096 + 160, 96, 384, 1, 0), (2048 + 16 * 49, 192, 768, 1, 1),
+                                             (1024 + 784, 192, 192, 0, 0)])
+def test_fused_pair_of_linears_matches_float64_and_is_position_invariant(eng_w0, m, c, hid, act, ln):
+    """csrc/two_linear_f16.hip (precision 2, Swin stages 1-2: to_out -> post_proj + x, LayerNorm -> fc1 -> GELU -> fc2 + x;
+    swin_transformer.py:23-39,66-82,191-232) through reid_debug_two_linear: out = res + w2 . act(w1 . [LN](x) + b1) + b2 against float64
+    at the fp32-class bound, ragged token counts, and copies of one row at different tile positions bit-identical (images are
+    independent in eval mode)."""
     import ctypes as C
     import math
     eng, _ = eng_w0
     fn = _ffi.debug_lib().reid_debug_two_linear
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p] * 2
+    fn.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p] * 4
     rng = np.random.default_rng(m + hid)
-    c, R = 96, 61
+    R = 61
     base = rng.normal(size=(R, c)).astype(np.float32)
+    if ln:
+        base = (base * rng.uniform(0.5, 3.0, size=(R, 1)) + rng.normal(size=(R, 1))).astype(np.float32)
     rb = rng.normal(size=(R, c)).astype(np.float32)
     ids = np.asarray([(i * 5 + i // 7) % R for i in range(m)])
     x, res = np.ascontiguousarray(base[ids]), np.ascontiguousarray(rb[ids])
@@ -1920,14 +1924,19 @@ def test_fused_pair_of_linears_matches_float64_and_is_position_invariant(eng_w0,
     b1 = rng.normal(size=hid).astype(np.float32)
     w2 = (rng.normal(size=(c, hid)) / np.sqrt(hid)).astype(np.float32)
     b2 = rng.normal(size=c).astype(np.float32)
+    g = (1.0 + 0.1 * rng.normal(size=c)).astype(np.float32)
+    bt = (0.1 * rng.normal(size=c)).astype(np.float32)
     out = np.empty((m, c), np.float32)
     eng.set_precision(2)
     try:
         _ffi.check(fn(eng.h, x.ctypes.data, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data, res.ctypes.data, m, c, hid, act, 1,
-                      out.ctypes.data, None))
+                      out.ctypes.data, None, g.ctypes.data if ln else None, bt.ctypes.data if ln else None))
     finally:
         eng.set_precision(0)
-    h = base.astype(np.float64) @ w1.T.astype(np.float64) + b1
+    b64 = base.astype(np.float64)
+    if ln:
+        b64 = (b64 - b64.mean(1, keepdims=True)) / np.sqrt(b64.var(1, keepdims=True) + 1e-5) * g + bt
+    h = b64 @ w1.T.astype(np.float64) + b1
     if act:
         h = 0.5 * h * (1.0 + np.vectorize(math.erf)(h / math.sqrt(2.0)))
     ref = (h @ w2.T.astype(np.float64) + b2 + rb)[ids]

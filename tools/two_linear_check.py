@@ -16,7 +16,7 @@ eng.set_precision(2)
 dbg = _ffi.debug_lib()
 two = dbg.reid_debug_two_linear
 two.restype = C.c_int
-two.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p] * 2
+two.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p] * 4
 lin = dbg.reid_debug_linear_rows
 lin.restype = C.c_int
 lin.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]
@@ -24,7 +24,7 @@ rng = np.random.default_rng(0)
 erf = np.vectorize(math.erf)
 
 
-def case(m, c, hid, act, iters=1):
+def case(m, c, hid, act, iters=1, ln=False):
     R = 61
     base = rng.normal(size=(R, c)).astype(np.float32)
     ids = np.asarray([(i * 5 + i // 7) % R for i in range(m)])
@@ -37,10 +37,19 @@ def case(m, c, hid, act, iters=1):
     b2 = rng.normal(size=c).astype(np.float32)
     out = np.empty((m, c), np.float32)
     ms = C.c_float(0)
+    g = (1.0 + 0.1 * rng.normal(size=c)).astype(np.float32)
+    bt = (0.1 * rng.normal(size=c)).astype(np.float32)
+    if ln:      # rows with a mean and a spread of their own
+        base = (base * rng.uniform(0.5, 3.0, size=(R, 1)) + rng.normal(size=(R, 1))).astype(np.float32)
+        x = np.ascontiguousarray(base[ids])
     check(two(eng.h, x.ctypes.data, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data, res.ctypes.data, m, c, hid, act, iters,
-              out.ctypes.data, C.addressof(ms)))
+              out.ctypes.data, C.addressof(ms), g.ctypes.data if ln else None, bt.ctypes.data if ln else None))
     # (a) float64
-    h = base.astype(np.float64) @ w1.T.astype(np.float64) + b1
+    b64 = base.astype(np.float64)
+    if ln:
+        b64 = (b64 - b64.mean(1, keepdims=True)) / np.sqrt(b64.var(1, keepdims=True) + 1e-5) * g + bt
+        x = np.ascontiguousarray(b64.astype(np.float32)[ids])      # what the two-launch form is given
+    h = b64 @ w1.T.astype(np.float64) + b1
     if act:
         h = 0.5 * h * (1.0 + erf(h / math.sqrt(2.0)))
     ref = (h @ w2.T.astype(np.float64) + b2 + rb)[ids]
@@ -56,19 +65,26 @@ def case(m, c, hid, act, iters=1):
     first = [int(np.flatnonzero(ids == r)[0]) for r in range(R)]
     ndiff = int((out != out[first][ids]).sum())
     flops = 4.0 * m * c * hid * 3
-    print("m %7d c %3d hid %4d act %d: fused vs f64 %.2e, two launches vs f64 %.2e, fused vs two launches %.2e, %d elements differ between "
-          "copies%s" % (m, c, hid, act, err, err_un, dfu, ndiff,
+    print("m %7d c %3d hid %4d act %d ln %d: fused vs f64 %.2e, two launches vs f64 %.2e, fused vs two launches %.2e, %d elements differ between "
+          "copies%s" % (m, c, hid, act, ln, err, err_un, dfu, ndiff,
                         "; %.1f us per launch = %.0f TFLOP/s (f16 products)" % (ms.value * 1e3, flops / ms.value / 1e9) if iters > 1 else ""))
     return err, ndiff
 
 
 bad = 0
-for (m, c, hid, act) in ((2048, 96, 384, 1), (2048 + 32, 96, 96, 0), (4096 + 160, 96, 384, 1), (1024 + 49, 96, 96, 0), (1568 * 3, 96, 384, 1)):
-    e, nd = case(m, c, hid, act)
-    bad += (e > 3e-6) + nd
+for (m, c, hid, act) in ((2048, 96, 384, 1), (2048 + 32, 96, 96, 0), (4096 + 160, 96, 384, 1), (1024 + 49, 96, 96, 0), (1568 * 3, 96, 384, 1),
+                         (2048, 192, 768, 1), (1024 + 16 * 49, 192, 192, 0)):
+    for ln in (False, True):
+        e, nd = case(m, c, hid, act, ln=ln)
+        bad += (e > 3e-6) + nd
 big = int(sys.argv[1]) if len(sys.argv) > 1 else 256 * 3136
 case(big, 96, 384, 1, iters=10)
+case(big, 96, 384, 1, iters=10, ln=True)
 case(big, 96, 96, 0, iters=10)
 case(big, 96, 384, 0, iters=10)
+if True:
+    case(big // 4, 192, 768, 1, iters=10)
+    case(big // 4, 192, 768, 1, iters=10, ln=True)
+    case(big // 4, 192, 192, 0, iters=10)
 print("FAILED" if bad else "OK")
 sys.exit(1 if bad else 0)
