@@ -200,6 +200,9 @@ bool two_linear_supported(const reid_ctx*, long long T, int C, int hid);
 int launch_two_linear(reid_ctx*, const _Float16* a16, long long T, int C, int hid, const float* w1, const float* b1, const float* w2,
                       const float* b2, int act, const float* res, float* out, const float* x32 = nullptr, const float* ln_g = nullptr,
                       const float* ln_b = nullptr);
+bool ln_linear_supported(const reid_ctx*, long long T, int C, int n);
+int launch_ln_linear(reid_ctx*, const float* x32, const float* ln_g, const float* ln_b, long long T, int C, int n, const float* w, const float* bias,
+                     float* out, int ldc);
 int launch_split_pack(reid_ctx* ctx, const float* x, long long rows, int C, _Float16* out, const float* d_scale = nullptr);           // fp32 [rows][C] -> f16 [rows][2C] = [xh | xl']
 int launch_split_weights(reid_ctx* ctx, const float* w, int cout, int taps, int cin, int terms, _Float16* out, const float* d_scale = nullptr);  // fp32 [cout][taps][cin] -> f16 [cout][taps][terms * cin]
 // fp16 elementwise kernels (elementwise_f16.hip)

@@ -1317,10 +1317,14 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 f16* ln16 = (f16*)lnb;      // [T][2C]
                 f16* att16 = (f16*)att;     // [T][2C]
                 f16* big16 = (f16*)big;     // MLP hidden [T][8C] (same bytes as the fp32 [T][4C])
-                prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
-                launch_layernorm_packed(ctx, xin, T, C, k.ln1_g, k.ln1_b, ln16);
-                prof_end(ctx);
-                REID_TRY(linear(ctx, nullptr, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big, ln16));
+                if (ln_linear_supported(ctx, T, C, 3 * C)) {   // LayerNorm 1 + to_qkv: the normalised tokens never leave the registers
+                    REID_TRY(launch_ln_linear(ctx, xin, k.ln1_g, k.ln1_b, T, C, 3 * C, k.qkv_w, nullptr, big, 3 * C));
+                } else {
+                    prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 8);
+                    launch_layernorm_packed(ctx, xin, T, C, k.ln1_g, k.ln1_b, ln16);
+                    prof_end(ctx);
+                    REID_TRY(linear(ctx, nullptr, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big, ln16));
+                }
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 16);
                 hipLaunchKernelGGL(window_attn_kernel<float>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, 3 * C, n,
                                    Hs, Ws, heads, shifted, k.pos, (float*)nullptr, att16, ctx->fault);

@@ -69,6 +69,50 @@ __global__ __launch_bounds__(256) void two_linear_w2_tiles_kernel(const float* _
     out[tile * 1024 + tile_pos(row, kpos)] = split_part(w[(long long)n * hid + h], part);
 }
 
+// LayerNorm (swin_transformer.py:195,228; eps 1e-5) of one fp32 token row, then the [yh | yl'] split, in registers, as the MFMA
+// fragments of that token: the lane holds columns 16 r + 8 lh .. + 7 (half the row), its partner lane ^ 32 the rest; two-pass
+// statistics as layernorm_v4_kernel's.  lns: [gamma | beta] in LDS.  Returns the running range-guard word.
+template <int C>
+__device__ __forceinline__ unsigned token_fragments_ln(const float* __restrict__ row, const float* lns, int lh, half8 (&xf)[2 * C / 16], unsigned xmax) {
+    constexpr int KH = C / 16;
+    const float* xrow = row + 8 * lh;
+    f32x4 xv[2 * KH];
+#pragma unroll
+    for (int r = 0; r < KH; ++r) {
+        xv[2 * r] = *(const f32x4*)(xrow + 16 * r);
+        xv[2 * r + 1] = *(const f32x4*)(xrow + 16 * r + 4);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * KH; ++i) sum += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * KH; ++i) {
+        const f32x4 d = xv[i] - mean;
+        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    q += __shfl_xor(q, 32);
+    const float rstd = 1.0f / sqrtf(q / C + 1e-5f);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 gg = *(const f32x4*)&lns[16 * r + 8 * lh + 4 * h], bb = *(const f32x4*)&lns[C + 16 * r + 8 * lh + 4 * h];
+            const f32x4 y = (xv[2 * r + h] - mean) * rstd * gg + bb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xmax = range_acc(xmax, y[i]);
+                const f16 hv = cvt_f16_rn(y[i]);
+                xf[r][4 * h + i] = hv;
+                xf[KH + r][4 * h + i] = cvt_f16_rn((y[i] - (float)hv) * 2048.0f);
+            }
+        }
+    }
+    return xmax;
+}
+
 struct TwoLinearParams {
     const f16* A;        // [T][2C]: [xh | xl'] - or null: LayerNorm(X32) computed here
     const float* X32;    // [T][C] fp32 (LN builds)
@@ -139,47 +183,8 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 && C <= 96) ? 2 : 1) void two_lin
     for (int t = 0; t < TT; ++t) {
         long long tok = tok0 + (wave * TT + t) * 32 + li;
         if (tok >= p.T) tok = p.T - 1;       // a ragged last block: a valid row, its results fall outside the store descriptor
-        if constexpr (LN) {
-            // LayerNorm (swin_transformer.py:195,228; eps 1e-5) of the fp32 row, then the [yh | yl'] split, in registers: the lane
-            // holds columns 16 r + 8 lh .. + 7 (half the row), its partner lane ^ 32 the rest; two-pass statistics as
-            // layernorm_v4_kernel's
-            constexpr int KH = C / 16;
-            const float* xrow = p.X32 + tok * C + 8 * lh;
-            f32x4 xv[2 * KH];
-#pragma unroll
-            for (int r = 0; r < KH; ++r) {
-                xv[2 * r] = *(const f32x4*)(xrow + 16 * r);
-                xv[2 * r + 1] = *(const f32x4*)(xrow + 16 * r + 4);
-            }
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2 * KH; ++i) sum += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
-            sum += __shfl_xor(sum, 32);
-            const float mean = sum / C;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2 * KH; ++i) {
-                const f32x4 d = xv[i] - mean;
-                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-            }
-            q += __shfl_xor(q, 32);
-            const float rstd = 1.0f / sqrtf(q / C + 1e-5f);
-#pragma unroll
-            for (int r = 0; r < KH; ++r) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 gg = *(const f32x4*)&lns[16 * r + 8 * lh + 4 * h], bb = *(const f32x4*)&lns[C + 16 * r + 8 * lh + 4 * h];
-                    const f32x4 y = (xv[2 * r + h] - mean) * rstd * gg + bb;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        xmax = range_acc(xmax, y[i]);
-                        const f16 hv = cvt_f16_rn(y[i]);
-                        xf[t][r][4 * h + i] = hv;
-                        xf[t][KH + r][4 * h + i] = cvt_f16_rn((y[i] - (float)hv) * 2048.0f);
-                    }
-                }
-            }
-        } else {
+        if constexpr (LN) xmax = token_fragments_ln<C>(p.X32 + tok * C, lns, lh, xf[t], xmax);
+        else {
             const f16* arow = p.A + tok * (2 * C) + 8 * lh;
 #pragma unroll
             for (int r = 0; r < KR; ++r) xf[t][r] = *(const half8*)(arow + 16 * r);
@@ -376,6 +381,100 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 && C <= 96) ? 2 : 1) void two_lin
     }
 }
 
+// ---- LayerNorm + ONE linear (Swin: norm1 -> to_qkv, swin_transformer.py:66-70,195): out[T][n] = LN(x) . W^T (+ bias), fp32 out.
+// The same register-resident tokens, here as the A operand (the two fragment layouts of the 32x32x16 MFMA are the same: lane =
+// row or column, lane half = k half): D[token][column], so a wave's stores are 128 contiguous bytes per token row.  Weights: the
+// W1 tile images above, GPS groups of 32 output columns per step through two LDS slots.
+struct LnLinearParams {
+    const float* X32;    // [T][C]
+    const float* ln_g;
+    const float* ln_b;
+    long long T;
+    const f16* Wt;       // two_linear_w1_tiles_kernel of W [n][C]
+    const float* bias;   // [n] or null
+    float* out;          // [T][ldc]
+    int n, ldc;
+    int* fault;
+};
+
+template <int C, int NW, int GPS>
+__global__ __launch_bounds__(NW * 64, 2) void ln_linear_f16x3_kernel(const LnLinearParams p) {
+    constexpr int NT = 3 * C / 32, KS1 = 3 * C / 16, KR = 2 * C / 16;
+    constexpr int HB = NT * 2048, SB = GPS * HB, PI = SB / 1024, IPW = (PI + NW - 1) / NW;
+    static_assert(2 * SB + 8 * C <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) char lds[2 * SB];
+    __shared__ __attribute__((aligned(16))) float lns[2 * C];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const long long row0 = ((long long)blockIdx.x * NW + wave) * 32;
+    const int nsteps = p.n / (32 * GPS);
+    for (int i = tid; i < C; i += NW * 64) {
+        lns[i] = p.ln_g[i];
+        lns[C + i] = p.ln_b[i];
+    }
+    __syncthreads();
+    half8 xf[KR];
+    unsigned xmax;
+    {
+        long long tok = row0 + li;
+        if (tok >= p.T) tok = p.T - 1;
+        xmax = token_fragments_ln<C>(p.X32 + tok * C, lns, lh, xf, 0u);
+    }
+    auto issue_step = [&](int it, int slot) {
+        const char* src = (const char*)p.Wt + (long long)it * SB;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            int q = wave + NW * j;
+            if (q >= PI) q -= PI;
+            __builtin_amdgcn_global_load_lds(GPTR(src + q * 1024 + lane * 16), LPTR(lds + slot * SB + q * 1024), 16, 0, 0);
+        }
+    };
+    issue_step(0, 0);
+    if (nsteps > 1) issue_step(1, 1);
+    int foff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) foff[kk] = li * 64 + (((kk * 2 + lh) ^ (li >> 2)) & 3) * 16;
+    const long long rows_left = p.T - row0;
+    const int rows = rows_left <= 0 ? 0 : (rows_left < 32 ? (int)rows_left : 32);
+    const __amdgpu_buffer_rsrc_t o_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (rows ? row0 : 0) * p.ldc), 0, rows ? ((rows - 1) * p.ldc + p.n) * 4 : 0, 0x00020000);
+    int slot = 0;
+    for (int it = 0; it < nsteps; ++it) {
+        // own pieces of step it landed (and this wave's stores of step it - 1 retired: they share the counter) -> barrier -> step
+        // it + 1 into the other slot, which every wave has finished reading
+        if (it == 0 && nsteps > 1) WAIT_VMCNT(IPW);
+        else WAIT_VMCNT(0);
+        RAW_BARRIER();
+        if (it >= 1 && it + 1 < nsteps) issue_step(it + 1, slot ^ 1);
+        const char* Ws = lds + slot * SB;
+        f32x16 acc[GPS];
+#pragma unroll
+        for (int g = 0; g < GPS; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int g = 0; g < GPS; ++g) {
+                const half8 wf = *(const half8*)(Ws + g * HB + (ks >> 1) * 2048 + foff[ks & 1]);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[ks % KR], wf, acc[g], 0, 0, 0);
+            }
+#pragma unroll
+        for (int g = 0; g < GPS; ++g) {
+            const int col = (it * GPS + g) * 32 + li;
+            const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = fmaf(acc[g][e], 1.0f / 2048.0f, bias);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rs, (((e & 3) + 8 * (e >> 2) + 4 * lh) * p.ldc + col) * 4, 0, 0);
+            }
+        }
+        slot ^= 1;
+    }
+    range_raise(p.fault, xmax);
+}
+
 template <int C, int NW, int AHEAD, int TT, int NS>
 void launch_variant(reid_ctx* ctx, const TwoLinearParams& p, int act) {
     const unsigned grid = (unsigned)((p.T + NW * 32 * TT - 1) / (NW * 32 * TT));
@@ -425,6 +524,40 @@ int launch_two_linear(reid_ctx* ctx, const _Float16* a16, long long T, int C, in
     if (C == 192) launch_variant<192, 4, 2, 1, 2>(ctx, p, act);
     else if ((ctx->two_linear_cfg & 15) == 1) launch_variant<96, 8, 2, 1, 3>(ctx, p, act);
     else launch_variant<96, 4, 2, 1, 2>(ctx, p, act);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+bool ln_linear_supported(const reid_ctx* ctx, long long T, int C, int n) {
+    return ctx->precision == 2 && ctx->swin_two_linear && (C == 96 || C == 192) && n % 96 == 0 && T >= 1024;
+}
+
+// out [T][ldc] fp32 = LayerNorm(x32 [T][C]; ln_g, ln_b) . w^T (+ bias); w [n][C] fp32 (the blob's)
+int launch_ln_linear(reid_ctx* ctx, const float* x32, const float* ln_g, const float* ln_b, long long T, int C, int n, const float* w,
+                     const float* bias, float* out, int ldc) {
+    ARG_CHECK(ln_linear_supported(ctx, T, C, n) && x32 && ln_g && ln_b && w && out && ldc >= n);
+    const void* key = (const char*)w + 1;
+    auto it = ctx->split_w.find(key);
+    if (it == ctx->split_w.end()) {
+        void* t;
+        const long long total = (long long)n * 3 * C;
+        HIP_TRY(hipMalloc(&t, (size_t)total * 2));
+        hipLaunchKernelGGL(two_linear_w1_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w, n, C, 1, (f16*)t);
+        LAUNCH_CHECK();
+        it = ctx->split_w.emplace(key, t).first;
+    }
+    LnLinearParams p;
+    p.X32 = x32; p.ln_g = ln_g; p.ln_b = ln_b; p.T = T; p.Wt = (const f16*)it->second; p.bias = bias; p.out = out; p.n = n; p.ldc = ldc;
+    p.fault = ctx->fault;
+    prof_begin(ctx, REID_K_CONV_GEMM, 2.0 * T * C * n, (double)T * 4.0 * (C + n) + 6.0 * C * n);
+    const unsigned grid = (unsigned)((T + 127) / 128);
+    if (C == 96) {
+        if (ctx->two_linear_cfg == 3) hipLaunchKernelGGL((ln_linear_f16x3_kernel<96, 4, 3>), dim3(grid), dim3(256), 0, ctx->stream, p);
+        else hipLaunchKernelGGL((ln_linear_f16x3_kernel<96, 4, 1>), dim3(grid), dim3(256), 0, ctx->stream, p);
+    } else {
+        hipLaunchKernelGGL((ln_linear_f16x3_kernel<192, 4, 1>), dim3(grid), dim3(256), 0, ctx->stream, p);
+    }
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
