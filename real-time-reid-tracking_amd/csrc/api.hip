@@ -57,6 +57,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_SPLIT_TERMS")) c->split_terms = atoi(e) == 4 ? 4 : 3;
     if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
     if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);
+    if (const char* e = getenv("REID_SWIN_ATTN_SPLIT")) c->swin_attn_split = atoi(e);
     if (const char* e = getenv("REID_SWIN_TWO_LINEAR")) c->swin_two_linear = atoi(e);
     if (const char* e = getenv("REID_TWO_LINEAR_CFG")) c->two_linear_cfg = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;

@@ -381,6 +381,7 @@ void launch_layernorm(reid_ctx* ctx, const float* x, long long T, int C, const f
 // (create_mask, :95-108) are applied from per-key flags.
 typedef f16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "lin_math.h"
 
 __device__ __forceinline__ void build_bias_table(const float* __restrict__ pos, float* sbias, int* kflag, int nthreads) {
     for (int idx = threadIdx.x; idx < 64 * 64; idx += nthreads) {
@@ -557,6 +558,180 @@ __global__ __launch_bounds__(256) void window_attn_mfma_f16_kernel(const f16* __
         f16* dst = out + token(lane) * C + head * 32;
 #pragma unroll
         for (int c = 0; c < 4; ++c) *(half8*)(dst + c * 8) = *(const half8*)(zl + lane * ZP + c * 8);
+    }
+}
+
+// fp32-class mode (precision 2): the same kernel on fp32 q / k / v split into [hi | lo'] f16 in registers - x.y = xh.yh + (xl'.yh +
+// xh.yl') 2^-11 with the leading product and the two corrections in accumulators of their own (no operand carries a 2^11 factor:
+// activations are only known to be < 65504) - for S^T and for P.V: 24 + 24 MFMAs per (window, head); exact expf; the result goes
+// out as [zh | zl'] f16 [tokens][2C], what the to_out linear reads.
+// OPT-IN (REID_SWIN_ATTN_SPLIT=1), not the default: measured end to end (bench.py --workload swin, 1024 images, same box, twice
+// each) 14.0 k img/s with this kernel against 14.7 k with the exact-fp32 VALU kernel above.  With 49 tokens and 32 dims per head
+// the products are the small part of a window: the hi / lo splits of q, k, v and of the 64 x 64 probabilities, the range guards,
+// 64 expf per lane and two LDS transposes are as many VALU instructions (~3.5 k per wave) as the VALU kernel's whole
+// arithmetic (~4.2 k), on top of 48 MFMAs.  The exact-fp32 matrix-core form (v_mfma_f32_32x32x2_f32, below) runs at the VALU
+// rate and was 5 % slower as well (round 2).
+__global__ __launch_bounds__(256) void window_attn_mfma_split_kernel(const float* __restrict__ qkv, int ldq, int n_img, int H, int W,
+                                                                     int heads, int shifted, const float* __restrict__ bias_tab,
+                                                                     f16* __restrict__ packed, int* __restrict__ fault) {
+    constexpr int VP = 72;   // V^T row pitch in f16 (144 B)
+    constexpr int ZP = 40;   // Z row pitch in f16 (80 B, 16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) float sbias[64 * 64];
+    __shared__ int kflag[64];
+    __shared__ __attribute__((aligned(16))) f16 wbuf[4][2][64 * ZP];   // per wave, hi / lo: V^T [32][VP], later Z [64][ZP]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *(float4*)(sbias + (threadIdx.x + 256 * i) * 4) = *(const float4*)(bias_tab + (threadIdx.x + 256 * i) * 4);
+    if (threadIdx.x < 64) {
+        const int key = threadIdx.x, jy = key / 7, jx = key - jy * 7;
+        kflag[key] = key < 49 ? ((jy >= 4 ? 1 : 0) | (jx >= 4 ? 2 : 0)) : 0;
+    }
+    const int nwh = H / 7, nww = W / 7;
+    const long long task = blockIdx.x * 4LL + wave;
+    const long long ntask = (long long)n_img * nwh * nww * heads;
+    const bool live = task < ntask;
+    const int C = heads * 32;
+    int head = 0, wx = 0, wy = 0, img = 0;
+    if (live) {
+        head = (int)(task % heads);
+        long long t = task / heads;
+        wx = (int)(t % nww);
+        t /= nww;
+        wy = (int)(t % nwh);
+        img = (int)(t / nwh);
+    }
+    const int sh = shifted ? 3 : 0;
+    auto token = [&](int idx) -> long long {   // window position idx (< 49) -> token row
+        const int iy = idx / 7, ix = idx - iy * 7;
+        const int y = (wy * 7 + iy + sh) % H, x = (wx * 7 + ix + sh) % W;
+        return ((long long)img * H + y) * W + x;
+    };
+    auto split8 = [](const f32x4& a, const f32x4& b, half8& hi, half8& lo) {
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = cvt_f16_rn(v[j]);
+            lo[j] = cvt_f16_rn((v[j] - (float)hi[j]) * 2048.0f);
+        }
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    unsigned vm = 0u;        // range guard (reid_ctx.fault): |q|, |k|, |v|, |z| < 65504
+    f16* vth = wbuf[wave][0];
+    f16* vtl = wbuf[wave][1];
+    // V^T of this (window, head): lane = token, 32 dims -> vt[dim][token], hi and lo; padded tokens are zero rows
+    f32x4 vv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) vv[c] = zero4;
+    if (live && lane < 49) {
+        const float* base = qkv + token(lane) * ldq + 2 * C + head * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) vv[c] = *(const f32x4*)(base + c * 4);
+    }
+    // Q / K fragments: lane (li, lh) holds dims 8*lh .. +7 (k-step 0) and 16 + 8*lh .. (k-step 1) of tokens li and 32 + li
+    half8 qh[2][2], ql[2][2], kh[2][2], kl[2][2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+        const int idx = t2 * 32 + li;
+        const bool ok = live && idx < 49;
+        const float* base = ok ? qkv + token(idx) * ldq + head * 32 + 8 * lh : qkv;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const f32x4 q0 = ok ? *(const f32x4*)(base + s2 * 16) : zero4, q1 = ok ? *(const f32x4*)(base + s2 * 16 + 4) : zero4;
+            const f32x4 k0 = ok ? *(const f32x4*)(base + C + s2 * 16) : zero4, k1 = ok ? *(const f32x4*)(base + C + s2 * 16 + 4) : zero4;
+            vm = range_acc(range_acc(range_acc(range_acc(vm, q0.x), q0.y), q0.z), q0.w);
+            vm = range_acc(range_acc(range_acc(range_acc(vm, q1.x), q1.y), q1.z), q1.w);
+            vm = range_acc(range_acc(range_acc(range_acc(vm, k0.x), k0.y), k0.z), k0.w);
+            vm = range_acc(range_acc(range_acc(range_acc(vm, k1.x), k1.y), k1.z), k1.w);
+            split8(q0, q1, qh[t2][s2], ql[t2][s2]);
+            split8(k0, k1, kh[t2][s2], kl[t2][s2]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        half8 hi, lo;
+        split8(vv[2 * c], vv[2 * c + 1], hi, lo);
+        vm = range_acc(range_acc(range_acc(range_acc(vm, vv[2 * c].x), vv[2 * c].y), vv[2 * c].z), vv[2 * c].w);
+        vm = range_acc(range_acc(range_acc(range_acc(vm, vv[2 * c + 1].x), vv[2 * c + 1].y), vv[2 * c + 1].z), vv[2 * c + 1].w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            vth[(c * 8 + j) * VP + lane] = hi[j];
+            vtl[(c * 8 + j) * VP + lane] = lo[j];
+        }
+    }
+    __syncthreads();   // bias table ready (the wave's own V^T writes are ordered before its reads)
+    if (!live) return;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16 corr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[kt][qt][e] = 0.f; corr[e] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kt][s2], qh[qt][s2], acc[kt][qt], 0, 0, 0);
+                corr = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[kt][s2], qh[qt][s2], corr, 0, 0, 0);
+                corr = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kt][s2], ql[qt][s2], corr, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[kt][qt][e] = fmaf(corr[e], 1.0f / 2048.0f, acc[kt][qt][e]);
+        }
+    softmax_scores<false>(acc, sbias, kflag, lane, shifted && wy == nwh - 1, shifted && wx == nww - 1);
+    // O = P . V: A = registers 8*s2 .. 8*s2+7 of the S^T tile as [ph | pl'] (element j of lane half h is key
+    // 16*s2 + 8*(j>>2) + 4*h + (j&3) of the tile), B = V^T[dim = li][those keys]
+    f32x16 z[2], zc[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { z[qt][e] = 0.f; zc[qt][e] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int voff = li * VP + kt * 32 + 16 * s2 + 4 * lh;
+            const half4 h0 = *(const half4*)(vth + voff), h1 = *(const half4*)(vth + voff + 8);
+            const half4 l0 = *(const half4*)(vtl + voff), l1 = *(const half4*)(vtl + voff + 8);
+            const half8 vbh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            const half8 vbl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                half8 pah, pal;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = acc[kt][qt][8 * s2 + j];
+                    pah[j] = cvt_f16_rn(pv);
+                    pal[j] = cvt_f16_rn((pv - (float)pah[j]) * 2048.0f);
+                }
+                z[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pah, vbh, z[qt], 0, 0, 0);
+                zc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pal, vbh, zc[qt], 0, 0, 0);
+                zc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pah, vbl, zc[qt], 0, 0, 0);
+            }
+        }
+    // Z[query][dim] (col = dim on the lane, rows in registers) -> [zh | zl'] -> LDS -> one 64-byte row each per token
+    f16* zhl = wbuf[wave][0];
+    f16* zll = wbuf[wave][1];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = fmaf(zc[qt][e], 1.0f / 2048.0f, z[qt][e]);
+            vm = range_acc(vm, v);
+            const f16 hv = cvt_f16_rn(v);
+            const int o = (qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * ZP + li;
+            zhl[o] = hv;
+            zll[o] = cvt_f16_rn((v - (float)hv) * 2048.0f);
+        }
+    range_raise(fault, vm);
+    if (lane < 49) {
+        f16* dst = packed + token(lane) * 2 * C + head * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            *(half8*)(dst + c * 8) = *(const half8*)(zhl + lane * ZP + c * 8);
+            *(half8*)(dst + C + c * 8) = *(const half8*)(zll + lane * ZP + c * 8);
+        }
     }
 }
 
@@ -1326,8 +1501,12 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                     REID_TRY(linear(ctx, nullptr, T, C, k.qkv_w, nullptr, 3 * C, 0, nullptr, big, ln16));
                 }
                 prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)T * C * 16);
-                hipLaunchKernelGGL(window_attn_kernel<float>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, 3 * C, n,
-                                   Hs, Ws, heads, shifted, k.pos, (float*)nullptr, att16, ctx->fault);
+                if (ctx->swin_attn_split)
+                    hipLaunchKernelGGL(window_attn_mfma_split_kernel, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, 3 * C, n,
+                                       Hs, Ws, heads, shifted, w.blk16[bi].bias_tab, att16, ctx->fault);
+                else
+                    hipLaunchKernelGGL(window_attn_kernel<float>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, ctx->stream, big, 3 * C, n,
+                                       Hs, Ws, heads, shifted, k.pos, (float*)nullptr, att16, ctx->fault);
                 prof_end(ctx);
                 LAUNCH_CHECK();
                 // each pair of linears as ONE launch where the hidden values fit the register file (two_linear_f16.hip): same
