@@ -313,7 +313,7 @@ def run_swin(job, args):
     from reid_amd import _ffi, parallel, synth, weights
     eng, comm, world, rank = job.eng, job.comm, job.world, job.rank
     n = args.crops
-    eng.set_chunk(min(args.chunk, 256))
+    eng.set_chunk(min(args.chunk, 1024))
     sd = synth.swin_state_dict(0)
     eng.load_swin(*weights.pack_swin(sd)[:2])
     # 256 distinct images per rank repeated (a 4096 x 3 x 224 x 224 fp32 batch is 2.4 GB: generated as 16 x 256)
@@ -372,7 +372,7 @@ def run_swin(job, args):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": main_prec, "data": "synthetic",
            "config": {"workload": "BASELINE configs[2]: Swin-T v1 backbone, %d images 224x224 per GPU (+ all-gather of the 96-d embeddings)" % n,
-                      "images_per_gpu": n, "embed_dim": 96, "chunk": min(args.chunk, 256)}}
+                      "images_per_gpu": n, "embed_dim": 96, "chunk": min(args.chunk, 1024)}}
     out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
     for o, r in others.items():
         out[o + "_path"] = r

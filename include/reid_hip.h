@@ -150,7 +150,7 @@ int reid_ctx_set_debug_keep(reid_ctx* ctx, int on);   /* tests only: give every 
                                                         * 2 keeps the production (fused) kernels: stage 0 is not written */
 int reid_debug_stage(reid_ctx* ctx, int stage, float* out_host, size_t max_floats, size_t* count);
 /* the same for the Swin backbone: stage 0 = ShadowFeatureExtraction output [n][H/4][W/4][96], 1..4 = the four stage outputs (NHWC),
- * 5 = GeM_1D output [n][96]; valid after a reid_swin_embed_* call that ran as one pass (n <= min(chunk, 256)) */
+ * 5 = GeM_1D output [n][96]; valid after a reid_swin_embed_* call that ran as one pass (n <= min(chunk, 1024)) */
 int reid_debug_swin_stage(reid_ctx* ctx, int stage, float* out_host, size_t max_floats, size_t* count);
 
 /* ---- Swin-T backbone (reference "v1": reid/backbones/swin_transformer.py:339-427, swin_t :508-513) -------------------

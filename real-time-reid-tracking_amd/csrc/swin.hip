@@ -1610,7 +1610,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
 
 // Intermediate activations of the last reid_swin_embed_* call (stage-level parity tests): 0 = ShadowFeatureExtraction output
 // [n][56][56][96], 1..4 = outputs of the four stages (NHWC fp32 residual streams), 5 = GeM_1D output [n][96].  Valid when the
-// call ran as ONE pass (n <= min(chunk, 256)); the buffers are the forward's own workspaces.
+// call ran as ONE pass (n <= min(chunk, 1024)); the buffers are the forward's own workspaces.
 extern "C" int reid_debug_swin_stage(reid_ctx* ctx, int stage, float* out, size_t max_floats, size_t* count) {
     ARG_CHECK(ctx && out && stage >= 0 && stage <= 7);
     CTX_GUARD(ctx);
@@ -1640,7 +1640,12 @@ extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int
         return REID_ERR_STATE;
     }
     const SwinWeights& sw = *swp;
-    const int chunk = ctx->chunk < 256 ? ctx->chunk : 256;   // ~13 MB of fp32 activations per 224x224 image
+    // images per pass: ~13 MB of fp32 activations per 224x224 image, 13 GB at the cap.  Passes of 1024 instead of 256 images run
+    // 8 % faster in the fp32-class mode (14.6 -> 15.7 k img/s): the stage 3-4 linears of a 256-image pass are 294-588 tiles for 512
+    // block slots.  Results are bit-identical for every pass size (tools/swin_chunk_check.py).  REID_SWIN_CHUNK_MAX lowers the cap.
+    int cap = 1024;
+    if (const char* e = getenv("REID_SWIN_CHUNK_MAX")) cap = atoi(e) > 0 && atoi(e) < cap ? atoi(e) : cap;
+    const int chunk = ctx->chunk < cap ? ctx->chunk : cap;
     const size_t img = (size_t)3 * h * w;
     for (int i = 0; i < n; i += chunk) {
         const int m = n - i < chunk ? n - i : chunk;
