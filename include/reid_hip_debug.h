@@ -35,6 +35,9 @@ int reid_debug_linear(reid_ctx* ctx, int m, int n, int k, int mode, int iters, f
  * output (+ res) through the buffer-store epilogue. */
 int reid_debug_linear_rows(reid_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, int m, int n, int k,
                            int mode, int flags, float* out);
+/* Timing experiments on that kernel (WRONG results while set): bit 0 = no weight refills after the first two steps, bit 1 = no block
+ * barriers.  0 restores the product behaviour. */
+int reid_debug_two_linear_ablate(reid_ctx* ctx, int bits);
 /* The fused pair of linears of the fp32-class mode (csrc/two_linear_f16.hip) alone: out = res + w2 . act(w1 . x + b1) + b2, x / res /
  * out [m][c], w1 [hid][c], w2 [c][hid], all fp32 on the host; act 1 = erf-GELU.  iters > 1: the launch repeated, mean time in *ms.
  * ln_g / ln_b [c] (or both null): the first linear reads LayerNorm(x) (eps 1e-5), made in the kernel's prologue. */

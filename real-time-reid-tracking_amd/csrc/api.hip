@@ -59,7 +59,6 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);
     if (const char* e = getenv("REID_SWIN_ATTN_SPLIT")) c->swin_attn_split = atoi(e);
     if (const char* e = getenv("REID_SWIN_TWO_LINEAR")) c->swin_two_linear = atoi(e);
-    if (const char* e = getenv("REID_TWO_LINEAR_CFG")) c->two_linear_cfg = atoi(e);
     if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
     if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
     if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e);   // 0 GEMM + pool, 1 fused, 2 fused reading uint8 crops

@@ -399,6 +399,14 @@ extern "C" int reid_debug_linear_rows(reid_ctx* ctx, const float* x, const float
     return REID_OK;
 }
 
+// Timing experiments on the fused pair of linears: bit 0 = no weight refills after the first two steps, bit 1 = no block barriers.
+// The results are WRONG while a bit is set (which is why this lives here and not behind an environment variable of the library).
+extern "C" int reid_debug_two_linear_ablate(reid_ctx* ctx, int bits) {
+    ARG_CHECK(ctx && bits >= 0 && bits < 4);
+    ctx->two_linear_ablate = bits;
+    return REID_OK;
+}
+
 // The fused pair of linears (two_linear_f16.hip) on its own: out = res + w2 . act(w1 . x + b1) + b2 through launch_split_pack +
 // launch_two_linear, x [m][c], w1 [hid][c], w2 [c][hid], res / out [m][c] fp32 on the host.  iters > 1 repeats the launch and
 // returns the mean time in *ms (may be null).  The context must be in precision 2.

@@ -385,7 +385,7 @@ struct reid_ctx {
                              // values in registers (two_linear_f16.hip; REID_SWIN_TWO_LINEAR=0: two launches through gemm_f16.hip)
     int swin_attn_split = 0; // REID_SWIN_ATTN_SPLIT=1: Swin window attention of the fp32-class mode on the matrix cores, split operands, instead
                              // of the exact-fp32 VALU kernel (measured: 14.0 k against 14.7 k img/s - see window_attn_mfma_split_kernel)
-    int two_linear_cfg = 0;  // experiment: 1 = eight-wave blocks, three steps resident, barrier in mid-step (REID_TWO_LINEAR_CFG)
+    int two_linear_ablate = 0;   // reid_debug_two_linear_ablate (timing experiments: WRONG results): 1 = no weight refills, 2 = no barriers
     int swin_attn_mfma = 1;  // Swin window attention (REID_SWIN_ATTN): 1 = matrix cores in fp16-storage mode, VALU kernel in exact fp32
                              // (v_mfma_f32_32x32x2_f32 runs at the fp32 VALU rate: no gain); 2 = matrix cores in both; 0 = VALU in both
     int f16_split_k = 1;     // LDS-halo kernel: split the input channels over 2-4 blocks per tile when a launch has < 128 tiles (REID_F16_SPLITK)

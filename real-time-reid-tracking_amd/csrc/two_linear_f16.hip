@@ -138,10 +138,11 @@ struct TwoLinearParams {
 // GEMMs' MFMAs and the fragment reads of two chunks ahead - with a scheduling barrier between chunks: the matrix pipe works on
 // groups it and it - 2 while the VALU runs the GELU of group it - 1.  (Phase by phase - GEMM 1, barrier, GELU, GEMM 2, barrier -
 // every wave of the block does the same kind of work at the same time and nothing overlaps: 708 us per stage-1 MLP of 256 images
-// against 320 in this order.)
+// on random operands (tools/two_linear_check.py) against 610-630 in this order; 480-490 us inside the Swin pass, whose operands
+// let the chip hold a higher clock.)
 // The weights of a step ([W1 group it | W2 group it - 2], 2-KB tiles as the load-time kernels wrote them) are one linear
-// global -> LDS DMA copy into a ring of three steps; one block barrier per step.
-template <int C, int NW, bool ACT, int AHEAD, int TT, int NS, bool LN>
+// global -> LDS DMA copy into one of two slots; one block barrier per step.
+template <int C, int NW, bool ACT, int AHEAD, int TT, bool LN>
 __global__ __launch_bounds__(NW * 64, (TT == 1 && C <= 96) ? 2 : 1) void two_linear_f16x3_kernel(const TwoLinearParams p) {
     constexpr int NT = 3 * C / 32;           // tiles per group and GEMM: GEMM 1 K-tiles of 32 / GEMM 2 (output tile, part)
     constexpr int KS1 = 3 * C / 16;          // GEMM 1 k-steps over the virtual K
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 && C <= 96) ? 2 : 1) void two_lin
     constexpr int SB = 2 * HB;               // ... of a step
     constexpr int PI = SB / 1024;            // DMA wave-instructions per step
     constexpr int IPW = (PI + NW - 1) / NW;  // ... per wave (the surplus repeats earlier pieces: same bytes, same place)
-    constexpr bool MID = NS == 3;            // three steps resident: the block barrier sits in the middle of a step (below); two: at its start
+    constexpr int NS = 2;                    // steps resident: the one being read, the one landing
     constexpr int BT = NW * 32 * TT;         // tokens per block (TT 32-token tiles per wave)
     static_assert(KS1 == NM2, "the two GEMMs of a group are the same number of MFMAs");
     static_assert(NS * SB + 16 * C <= 160 * 1024, "LDS budget");
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 && C <= 96) ? 2 : 1) void two_lin
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) foff[kk] = li * 64 + (((kk * 2 + lh) ^ (li >> 2)) & 3) * 16;
 
-    int slot_c = 0, slot_i = MID ? 2 : 0;    // slot being read / slot the next DMA goes to
+    int slot_c = 0;                          // slot being read; the next DMA goes to the other one
     float vmax = 0.f;
     f32x16 hcur[TT], hnext[TT];              // GEMM 1 accumulators: the group in the epilogue / the group being summed
     half8 Hh[TT][2], Hl[TT][2];              // the group GEMM 2 reads
@@ -230,52 +231,27 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 && C <= 96) ? 2 : 1) void two_lin
 
     // MFMAs of chunk c: GEMM indices [mlo(c), mlo(c + 1)) - KS1 over 16 chunks
     auto mlo = [](int c) { return c * KS1 / 16; };
-    constexpr int PF = AHEAD * KS1 / 16;     // fragments of a step read during the step before it
-    half8 pf1[PF], pf2[PF];
+    constexpr int PF = AHEAD * KS1 / 16;     // fragments read before a step's first chunk
     // fragment of MFMA m of each GEMM in ring slot `slot`: GEMM 1 k-step m; GEMM 2 m = (s * 3 + part) * NJ + j
     auto read1 = [&](int slot, int m) { return *(const half8*)(lds + slot * SB + (m >> 1) * 2048 + foff[m & 1]); };
     auto read2 = [&](int slot, int m) {
         const int j = m % NJ, sp = m / NJ, part = sp % 3, s = sp / 3;
         return *(const half8*)(lds + slot * SB + HB + (j * 3 + part) * 2048 + foff[s]);
     };
-    // The block barrier of a step sits in its MIDDLE: it publishes step it + 1 (every wave's DMA pieces have landed) and frees
-    // the slot of step it - 1 (every wave is past it) for step it + 2 - so the fragment reads run on across the step boundary
-    // (the last AHEAD chunks of a step read the first fragments of the next) and no wave starts a step with an empty pipeline.
-    if constexpr (MID) {
-        WAIT_VMCNT(IPW);                     // step 0 (step 1 may be in flight)
-        RAW_BARRIER();
-#pragma unroll
-        for (int m = 0; m < PF; ++m) {
-            pf1[m] = read1(0, m);
-            pf2[m] = read2(0, m);
-        }
-    }
-
     auto step = [&](int it, auto g1_c, auto e_c, auto g2_c) {
         constexpr bool G1 = decltype(g1_c)::value, E = decltype(e_c)::value, G2 = decltype(g2_c)::value;
-        constexpr bool LAST = !G1 && !E;
-        const int slot_n = slot_c + 1 == NS ? 0 : slot_c + 1;
         half8 f1[KS1], f2[NM2];
         f32x4 bq[4];
         half8 nHh[TT][2], nHl[TT][2];
-        if constexpr (MID) {
+        // own pieces of step it landed -> barrier (everyone's did, and step it - 1 has been read) -> step it + 1 into the other slot
+        if (it == 0) WAIT_VMCNT(IPW);        // (steps 0 and 1 were issued before the loop)
+        else WAIT_VMCNT(0);
+        if (!(p.ablate & 2)) RAW_BARRIER();
+        if (it >= 1 && it + 1 <= last && !(p.ablate & 1)) issue_step(it + 1, slot_c ^ 1);
 #pragma unroll
-            for (int m = 0; m < PF; ++m) {
-                f1[m] = pf1[m];
-                f2[m] = pf2[m];
-            }
-        } else {
-            // two slots: own pieces of step it landed -> barrier (everyone's did, step it - 1 has been read) -> step it + 1 into
-            // the slot of step it - 1
-            if (it == 0) WAIT_VMCNT(IPW);    // (steps 0 and 1 were issued before the loop)
-            else WAIT_VMCNT(0);
-            if (!(p.ablate & 2)) RAW_BARRIER();
-            if (it >= 1 && it + 1 <= last && !(p.ablate & 1)) issue_step(it + 1, slot_i);
-#pragma unroll
-            for (int m = 0; m < PF; ++m) {
-                if constexpr (G1) f1[m] = read1(slot_c, m);
-                if constexpr (G2) f2[m] = read2(slot_c, m);
-            }
+        for (int m = 0; m < PF; ++m) {
+            if constexpr (G1) f1[m] = read1(slot_c, m);
+            if constexpr (G2) f2[m] = read2(slot_c, m);
         }
         if constexpr (E) {
 #pragma unroll
@@ -290,23 +266,11 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 && C <= 96) ? 2 : 1) void two_lin
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            if (MID && c == 8) {
-                WAIT_VMCNT(0);               // own pieces of step it + 1 (issued half a step ago; nothing else is in flight)
-                RAW_BARRIER();
-                if (it + 2 <= last) issue_step(it + 2, slot_i);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if (c + AHEAD < 16) {
 #pragma unroll
                 for (int m = mlo(c + AHEAD); m < mlo(c + AHEAD + 1); ++m) {
                     if constexpr (G1) f1[m] = read1(slot_c, m);
                     if constexpr (G2) f2[m] = read2(slot_c, m);
-                }
-            } else if constexpr (MID && !LAST) {   // the next step's first fragments (whichever of the two GEMMs it runs)
-#pragma unroll
-                for (int m = mlo(c + AHEAD - 16); m < mlo(c + AHEAD - 15); ++m) {
-                    pf1[m] = read1(slot_n, m);
-                    pf2[m] = read2(slot_n, m);
                 }
             }
 #pragma unroll
@@ -341,8 +305,7 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 && C <= 96) ? 2 : 1) void two_lin
             }
             if constexpr (G1) hcur[t] = hnext[t];
         }
-        slot_c = slot_n;
-        if (MID || it >= 1) slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
+        slot_c ^= 1;
     };
     const std::true_type Y{};
     const std::false_type N{};
@@ -475,14 +438,14 @@ __global__ __launch_bounds__(NW * 64, 2) void ln_linear_f16x3_kernel(const LnLin
     range_raise(p.fault, xmax);
 }
 
-template <int C, int NW, int AHEAD, int TT, int NS>
+template <int C, int NW, int AHEAD, int TT>
 void launch_variant(reid_ctx* ctx, const TwoLinearParams& p, int act) {
     const unsigned grid = (unsigned)((p.T + NW * 32 * TT - 1) / (NW * 32 * TT));
     // the builds in use: MLP = LayerNorm + GELU, to_out -> post_proj = packed input, no activation (+ the two mixed forms for tests)
-    if (p.X32 && act) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, true, AHEAD, TT, NS, true>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
-    else if (p.X32) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, false, AHEAD, TT, NS, true>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
-    else if (act) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, true, AHEAD, TT, NS, false>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, false, AHEAD, TT, NS, false>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
+    if (p.X32 && act) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, true, AHEAD, TT, true>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
+    else if (p.X32) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, false, AHEAD, TT, true>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
+    else if (act) hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, true, AHEAD, TT, false>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((two_linear_f16x3_kernel<C, NW, false, AHEAD, TT, false>), dim3(grid), dim3(NW * 64), 0, ctx->stream, p);
 }
 
 }  // namespace
@@ -519,11 +482,11 @@ int launch_two_linear(reid_ctx* ctx, const _Float16* a16, long long T, int C, in
     TwoLinearParams p;
     p.A = a16; p.X32 = a16 ? nullptr : x32; p.ln_g = ln_g; p.ln_b = ln_b; p.T = T; p.W1t = (const f16*)t1; p.W2t = (const f16*)t2; p.b1 = b1; p.b2 = b2; p.res = res; p.out = out; p.hid = hid;
     p.fault = ctx->fault;
-    p.ablate = ctx->two_linear_cfg >> 4;
+    p.ablate = ctx->two_linear_ablate;
     prof_begin(ctx, REID_K_CONV_GEMM, 4.0 * T * C * hid, (double)T * C * 12.0 + 8.0 * C * hid);
-    if (C == 192) launch_variant<192, 4, 2, 1, 2>(ctx, p, act);
-    else if ((ctx->two_linear_cfg & 15) == 1) launch_variant<96, 8, 2, 1, 3>(ctx, p, act);
-    else launch_variant<96, 4, 2, 1, 2>(ctx, p, act);
+    // blocks of four waves (128 tokens): at C = 96 two of them share a CU, so one's prologue / epilogue runs beside the other's steps
+    if (C == 192) launch_variant<192, 4, 2, 1>(ctx, p, act);
+    else launch_variant<96, 4, 2, 1>(ctx, p, act);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
@@ -553,8 +516,7 @@ int launch_ln_linear(reid_ctx* ctx, const float* x32, const float* ln_g, const f
     prof_begin(ctx, REID_K_CONV_GEMM, 2.0 * T * C * n, (double)T * 4.0 * (C + n) + 6.0 * C * n);
     const unsigned grid = (unsigned)((T + 127) / 128);
     if (C == 96) {
-        if (ctx->two_linear_cfg == 3) hipLaunchKernelGGL((ln_linear_f16x3_kernel<96, 4, 3>), dim3(grid), dim3(256), 0, ctx->stream, p);
-        else hipLaunchKernelGGL((ln_linear_f16x3_kernel<96, 4, 1>), dim3(grid), dim3(256), 0, ctx->stream, p);
+        hipLaunchKernelGGL((ln_linear_f16x3_kernel<96, 4, 1>), dim3(grid), dim3(256), 0, ctx->stream, p);   // (three column groups per step: no faster)
     } else {
         hipLaunchKernelGGL((ln_linear_f16x3_kernel<192, 4, 1>), dim3(grid), dim3(256), 0, ctx->stream, p);
     }

@@ -1,6 +1,6 @@
 """The fused pair of linears (csrc/two_linear_f16.hip) against (a) float64, (b) the two launches it replaces (gemm_f16.hip linear
 builds through reid_debug_linear_rows), (c) itself on copies of the same rows at other positions (bit-identical), and its time.
-python tools/two_linear_check.py [tokens]"""
+python tools/two_linear_check.py [tokens] [ablate bits: 1 = no weight refills, 2 = no barriers - timing only, wrong results]"""
 import ctypes as C
 import math
 import os, sys
@@ -78,6 +78,9 @@ for (m, c, hid, act) in ((2048, 96, 384, 1), (2048 + 32, 96, 96, 0), (4096 + 160
         e, nd = case(m, c, hid, act, ln=ln)
         bad += (e > 3e-6) + nd
 big = int(sys.argv[1]) if len(sys.argv) > 1 else 256 * 3136
+if len(sys.argv) > 2:
+    print("ablation bits %s: the errors below are expected" % sys.argv[2])
+    check(dbg.reid_debug_two_linear_ablate(eng.h, int(sys.argv[2])))
 case(big, 96, 384, 1, iters=10)
 case(big, 96, 384, 1, iters=10, ln=True)
 case(big, 96, 96, 0, iters=10)
