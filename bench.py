@@ -354,7 +354,8 @@ def run_swin(job, args):
                               "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2),
                               "algorithmic_bytes_per_launch": round(g["bytes"] / max(1, g["launches"]), 1),
                               "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / peak, 4)} if f16 else
-                             {"kernel": ("Swin Linear / conv contractions, fp32-class (gemm_f16 linear builds over hi/lo-split operands, "
+                             {"kernel": ("Swin Linear / conv contractions, fp32-class (stages 1-2: fused pairs of linears and LayerNorm + "
+                                         "to_qkv of two_linear_f16.hip; the rest: gemm_f16 linear builds; hi/lo-split operands, "
                                          "3 x v_mfma_f32_32x32x16_f16 per multiply; peak = f16 dense / 3)" if x3 else
                                          "Swin Linear / conv contractions (gemm_f32_dma / conv_f32_dma, v_mfma_f32_32x32x2_f32)"),
                               "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
