@@ -917,7 +917,9 @@ inline int grid_for(long long work, int block) {
 // x_packed (precision 2): x already as [xh | xl'] f16 [m][2k]; out_packed: the result as [yh | yl'] f16 [m][2n] instead of fp32 `out`
 int linear(reid_ctx* ctx, const float* x, long long m, int k, const float* w, const float* bias, int n, int act,
            const float* residual, float* out, const f16* x_packed = nullptr, f16* out_packed = nullptr) {
-    if (ctx->precision == 2 && k % 32 == 0 && (m >= 1024 || x_packed)) {
+    // (only for packed inputs - the block linears of mode 2; the classifier's [n][96] input stays on the exact kernel for every batch
+    // size: which arithmetic a layer runs in must not depend on how many images a pass holds)
+    if (ctx->precision == 2 && k % 32 == 0 && x_packed) {
         // fp32-class arithmetic on the f16 matrix pipe (reid_ctx_set_precision(ctx, 2); the ResNet convolutions' trick,
         // conv3x3_f16.hip): x -> [xh | xl'] f16, weights [wh 2^11 | wh | wl'] made once, three products per multiply through the
         // f16 linear build with K = 3 k virtual columns, fp32 accumulate, fp32 in / out
@@ -1038,7 +1040,7 @@ int conv_split(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, cons
 int conv_bias(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, const float* w, const float* bias, int Cout, int R,
               int S, int stride, int pad_y, int pad_x, int Ho, int Wo, const float* residual, float* out, int scat_h = 0,
               int scat_w = 0, int py = 0, int px = 0, const f16* zero_page = nullptr) {
-    if (ctx->precision == 2 && zero_page && Cin % 32 == 0 && (long long)n * Ho * Wo >= 1024)
+    if (ctx->precision == 2 && zero_page && Cin % 32 == 0)
         return conv_split(ctx, x, n, H, W, Cin, w, bias, Cout, R, S, stride, pad_y, pad_x, Ho, Wo, residual, out, scat_h, scat_w, py, px, 1,
                           zero_page);
     GemmParams p;
@@ -1061,7 +1063,7 @@ int conv_bias(reid_ctx* ctx, const float* x, int n, int H, int W, int Cin, const
 // wts: four [Cout][4 Cin] matrices.  One launch of 4 x the tile grid on the LDS-DMA kernel, else one launch per parity.
 int conv_transpose_parities(reid_ctx* ctx, const float* x, int n, int Hi, int Wi, int ci, const float* wts, const float* bias, int co,
                             const float* residual, float* out, const f16* zero_page = nullptr) {
-    if (ctx->precision == 2 && zero_page && ci % 32 == 0 && (long long)n * Hi * Wi >= 1024)
+    if (ctx->precision == 2 && zero_page && ci % 32 == 0)
         return conv_split(ctx, x, n, Hi, Wi, ci, wts, bias, co, 2, 2, 1, 1, 1, Hi, Wi, residual, out, Hi, Wi, 0, 0, 4, zero_page);
     GemmParams p;
     memset(&p, 0, sizeof(p));
@@ -1485,7 +1487,7 @@ static int swin_forward(reid_ctx* ctx, const SwinWeights& w, const float* x, int
                 REID_TRY(linear16(ctx, big16, T, 4 * C, 4 * C, h.fc2, k.fc2_b, C, 0, xcur, nullptr, xcur, C));
                 continue;
             }
-            if (ctx->precision == 2 && T >= 1024) {
+            if (ctx->precision == 2) {   // (every pass size: an image's arithmetic must not depend on the batch it comes in)
                 // fp32-class mode: the five linears in three-product f16 arithmetic (linear()); LayerNorm, the attention kernel, to_out
                 // and fc1 write their results as [yh | yl'] f16 directly, so no linear input goes through a pack pass (the
                 // reference's two roundings to_out -> post_proj are kept: no folded matrix in fp32)

@@ -451,7 +451,7 @@ void launch_variant(reid_ctx* ctx, const TwoLinearParams& p, int act) {
 }  // namespace
 
 bool two_linear_supported(const reid_ctx* ctx, long long T, int C, int hid) {
-    return ctx->precision == 2 && ctx->swin_two_linear && (C == 96 || C == 192) && hid % 32 == 0 && hid <= 4 * C && T >= 1024;
+    return ctx->precision == 2 && ctx->swin_two_linear && (C == 96 || C == 192) && hid % 32 == 0 && hid <= 4 * C && T >= 1;
 }
 
 // input: a16 [T][2C] ([xh | xl']) - or, a16 null, LayerNorm(x32 [T][C]; ln_g, ln_b) made in the kernel; w1 [hid][C], w2 [C][hid] fp32
@@ -493,7 +493,7 @@ int launch_two_linear(reid_ctx* ctx, const _Float16* a16, long long T, int C, in
 }
 
 bool ln_linear_supported(const reid_ctx* ctx, long long T, int C, int n) {
-    return ctx->precision == 2 && ctx->swin_two_linear && (C == 96 || C == 192) && n % 96 == 0 && T >= 1024;
+    return ctx->precision == 2 && ctx->swin_two_linear && (C == 96 || C == 192) && n % 96 == 0 && T >= 1;
 }
 
 // out [T][ldc] fp32 = LayerNorm(x32 [T][C]; ln_g, ln_b) . w^T (+ bias); w [n][C] fp32 (the blob's)

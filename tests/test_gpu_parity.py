@@ -1952,3 +1952,29 @@ def test_fused_pair_of_linears_matches_float64_and_is_position_invariant(eng_w0,
     assert np.abs(out - ref).max() <= 1.5e-6 * np.abs(ref).max()          # fp32-class: three f16 products, fp32 sums (measured 3e-7)
     first = [int(np.flatnonzero(ids == r)[0]) for r in range(R)]
     assert np.array_equal(out, out[first][ids])
+
+
+@pytest.mark.gpu
+def test_swin_embeddings_do_not_depend_on_the_pass_size():
+    """reid_swin_embed_* walks a batch in passes of up to 1024 images (swin.hip); REID_SWIN_CHUNK_MAX lowers the cap.  Images are
+    independent in eval mode (swin_transformer.py:248-260), so 12 images embedded in passes of 2, 5 and 12 must agree bit for bit, in
+    the exact and in the fp32-class mode (whose stage 1-2 launches are the fused kernels of two_linear_f16.hip in every one of these
+    passes, and plain gemm_f16 launches when REID_SWIN_TWO_LINEAR=0 - which must agree with them at the mode's error level)."""
+    import subprocess, sys, json as _json
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from reid_amd import synth, weights; from reid_amd.engine import get_engine;"
+            "eng = get_engine(0); eng.load_swin(*weights.pack_swin(synth.swin_state_dict(0))[:2]); eng.set_chunk(4096); x = synth.images_f32(12, 4);"
+            "a = eng.swin_embed_f32_nchw(x); eng.set_precision(2); b = eng.swin_embed_f32_nchw(x); print(json.dumps([a.tolist(), b.tolist()]))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+    def run(**env):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, check=True).stdout
+        return [np.asarray(v, np.float32) for v in _json.loads(out.strip().splitlines()[-1])]
+
+    ref = run(REID_SWIN_CHUNK_MAX="12")
+    for cap in ("2", "5"):
+        got = run(REID_SWIN_CHUNK_MAX=cap)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), cap
+    unfused = run(REID_SWIN_CHUNK_MAX="12", REID_SWIN_TWO_LINEAR="0")
+    assert np.array_equal(unfused[0], ref[0])                                  # the exact mode has no fused launches
+    assert np.abs(unfused[1] - ref[1]).max() <= 2e-6 * np.abs(ref[1]).max()   # same roundings, another summation order
+    assert np.abs(ref[1] - ref[0]).max() <= 2e-6 * np.abs(ref[0]).max()       # fp32-class against exact fp32
