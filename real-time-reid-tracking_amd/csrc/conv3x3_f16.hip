@@ -912,22 +912,41 @@ int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
             if (pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT, true>), dim3(tiles128), dim3(threads), 0, ctx->stream, p);
         }
         if (!pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(tiles128), dim3(threads), 0, ctx->stream, p);
-    } else if (ctx->f16_split_k && ctx->f16_wide_splitk && tiles128 >= 48 && tiles128 * 4 <= 256 && nchunk % 4 == 0 && nchunk >= 16) {
-        // ... unless the K loop is long enough (layer 4) to split four ways over 128-wide tiles: the same block count with half
-        // the barriers and 1.0 instead of 1.5 LDS fragment reads per MFMA
-        REID_TRY(splitk(tiles128, 128, 4));
-        if constexpr (CAN_PAIR) {
-            if (pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT, true>), dim3(tiles128 * 4), dim3(threads), 0, ctx->stream, p);
-        }
-        if (!pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(tiles128 * 4), dim3(threads), 0, ctx->stream, p);
     } else {
-        // ... and when even those leave CUs idle, split the input channels over 2 or 4 blocks per tile (the K loop is
-        // latency-bound at ~0.65 us per (chunk, tap) tile, so its length is what a small launch costs)
-        const int tiles = nmt * (p.N / 64);
-        int sk = 1;
-        if (ctx->f16_split_k) while (sk < 4 && tiles * sk * 2 <= 256 && nchunk % (sk * 2) == 0) sk *= 2;
-        REID_TRY(splitk(tiles, 64, sk));
-        hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64, LW, SPLIT>), dim3(tiles * sk), dim3(threads), 0, ctx->stream, p);
+        // Few output tiles (a tracking frame): the launch leaves CUs idle and its K loop is latency-bound at ~0.65 us per (chunk, tap)
+        // tile of a 64-wide block and ~1.3 us of a 128-wide one, so its length is what the launch costs.  Split the input channels
+        // over sk blocks per output tile and pick, among 64- and 128-wide tiles and sk = 1 .. 4, the form with the shortest
+        // rounds x K-loop (a block owns a CU: 256 at a time).  128-wide tiles (half the barriers, 1.0 instead of 1.5 fragment reads
+        // per MFMA) need a long K loop to split (layer 4).  sk = 3 is what the Poisson(30) frames of 17-23 and 33-42 crops were
+        // missing: 36 crops took 1.24 ms against 0.83 ms for 30 (layer 4 as 144 unsplit blocks) - now 1.0x.
+        const int tiles64 = nmt * (p.N / 64);
+        int best_bn = 64, best_sk = 1;
+        double best = 1e30;
+        auto consider = [&](int bn, int tiles, int sk, double bias) {
+            if (tiles <= 0 || nchunk % sk != 0 || (sk > 1 && (!ctx->f16_split_k || tiles * sk > 256))) return;
+            const double cost = (double)((tiles * sk + 255) / 256) * (nchunk / sk) * 9 * (bn == 128 ? 1.3 : 0.65) + (sk > 1 ? 2.0 : 0.0) + bias;
+            if (cost < best) { best = cost; best_bn = bn; best_sk = sk; }
+        };
+        // (ties go to the forms of earlier rounds, so that a frame size they served keeps its summation order: 128-wide x 4, then
+        // 64-wide with sk a power of two)
+        if (ctx->f16_wide_splitk && nchunk >= 16 && tiles128 >= 48) consider(128, tiles128, 4, -0.003);
+        for (int sk = 4; sk >= 1; sk >>= 1) consider(64, tiles64, sk, -0.002 + 0.0001 * sk);
+        consider(64, tiles64, 3, 0.0);
+        if (ctx->f16_wide_splitk && nchunk >= 12 && tiles128 >= 48) {   // (layer 4's first convolution: 12 chunks)
+            consider(128, tiles128, 4, 0.001);
+            consider(128, tiles128, 3, 0.001);
+            consider(128, tiles128, 2, 0.001);
+        }
+        const int tiles = best_bn == 128 ? tiles128 : tiles64;
+        REID_TRY(splitk(tiles, best_bn, best_sk));
+        if (best_bn == 128) {
+            if constexpr (CAN_PAIR) {
+                if (pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT, true>), dim3(tiles * best_sk), dim3(threads), 0, ctx->stream, p);
+            }
+            if (!pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT>), dim3(tiles * best_sk), dim3(threads), 0, ctx->stream, p);
+        } else {
+            hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 64, LW, SPLIT>), dim3(tiles * best_sk), dim3(threads), 0, ctx->stream, p);
+        }
     }
     LAUNCH_CHECK();
     return REID_OK;
