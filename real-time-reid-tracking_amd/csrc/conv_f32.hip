@@ -629,6 +629,15 @@ void launch_bn(reid_ctx* ctx, const GemmParams& p0) {
         const int nk = p.R * p.S * (p.Cin / BK);
         int sk = 1;
         while (sk < 4 && grid * sk * 2 <= 512 && nk % (sk * 2) == 0 && nk / (sk * 2) >= 8) sk *= 2;
+        // between the powers of two: three ways where two leave a third of the block slots empty, and a split for launches of
+        // 257 .. 511 tiles, which used to run unsplit at full K length (a frame of 33 crops took 2.12 ms against 1.29 ms for 32).
+        // Launches of exactly 256 or 512 tiles (passes of 64 crops) keep the form they had.
+        // (only K loops that stay long: layer 1's 18 K-tiles split two ways were slower than unsplit)
+        if (sk == 2 && grid * 3 <= 512 && nk % 3 == 0 && nk / 3 >= 16) sk = 3;
+        else if (sk == 1 && grid > 256 && grid < 512) {
+            if (nk % 3 == 0 && nk / 3 >= 16 && grid * 3 <= 1024) sk = 3;
+            else if (nk % 2 == 0 && nk / 2 >= 16) sk = 2;
+        }
         if (sk > 1 && grid <= 1024) {
             float* ws;
             int* cnt;
