@@ -271,6 +271,9 @@ int launch_stem_split(reid_ctx* ctx, const void* x, bool is_u8, int n, const flo
     // there are few images
     int tpb = 64;
     while (tpb > 8 && (long long)n * (64 / tpb) < 256) tpb >>= 1;
+    // just past a full round (33 .. 63 images at eight strips each: 264-504 blocks on 256 CUs, one block per CU) the second round is
+    // nearly empty: strips of four tiles (five with the redone one) in three rounds are 15 tile times against 18 (36 crops: 75 -> 6x us)
+    if (tpb == 8 && (long long)n * 8 > 256 && (long long)n * 16 <= 768) tpb = 4;
     const int grid = n * (64 / tpb);
     // per device, so not cached in a static: contexts of one process may sit on different GPUs
     if (is_u8) HIP_TRY(hipFuncSetAttribute((const void*)stem_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
