@@ -907,7 +907,7 @@ int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
     const int tiles128 = p.N % 128 == 0 ? nmt * (p.N / 128) : 0;
     constexpr bool CAN_PAIR = SPLIT && LW == 1;
     const bool pair = CAN_PAIR && ctx->split_pair && p.split_terms == 3;   // the operand-sharing order of the fp32-class products
-    if (tiles128 >= 128) {
+    if (tiles128 > 128) {
         if constexpr (CAN_PAIR) {
             if (pair) hipLaunchKernelGGL((conv3x3_f16_kernel<TW, IMGS, 128, LW, SPLIT, true>), dim3(tiles128), dim3(threads), 0, ctx->stream, p);
         }
@@ -932,6 +932,10 @@ int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
         if (ctx->f16_wide_splitk && nchunk >= 16 && tiles128 >= 48) consider(128, tiles128, 4, -0.003);
         for (int sk = 4; sk >= 1; sk >>= 1) consider(64, tiles64, sk, -0.002 + 0.0001 * sk);
         consider(64, tiles64, 3, 0.0);
+        // exactly 128 wide tiles (a pass of 64 crops - the library's default pass size - in layers 2 and 4): as 256 tiles of 64 columns
+        // every CU has a block instead of every other one; unsplit, so each output still sums its K range in the same order and the
+        // results are the 128-wide launch's bit for bit
+        if (tiles128 == 128) consider(128, tiles128, 1, 0.0005);
         if (ctx->f16_wide_splitk && nchunk >= 12 && tiles128 >= 48) {   // (layer 4's first convolution: 12 chunks)
             consider(128, tiles128, 4, 0.001);
             consider(128, tiles128, 3, 0.001);
