@@ -1,6 +1,8 @@
 // Two Linear layers in one launch, fp32-class arithmetic (reid_ctx_set_precision(ctx, 2)):
 //     out = res + W2 . act(W1 . x + b1) + b2            x: [T][C] as [xh | xl'] f16, W1: [HID][C], W2: [C][HID], fp32 res / out
 // the Swin block's MLP (fc1 -> GELU -> fc2 + x, swin_transformer.py:23-39) and its to_out -> post_proj pair (+ x, :66-82,191-232).
+// x comes packed ([T][2C] f16) or as the fp32 residual stream with LayerNorm 2 applied in the kernel's prologue (:228).  At the end of
+// the file: LayerNorm 1 + to_qkv as one launch on the same register-resident tokens (ln_linear_f16x3_kernel).
 //
 // Why: in stages 1-2 (C = 96 / 192) these pairs are bound by the HIDDEN tensor's trip through HBM, not by arithmetic - the MLP of
 // stage 1 writes and re-reads [T][4C] values (2.5 GB per 256 images) around 0.36 TFLOP.  Here the hidden values never leave the
