@@ -79,7 +79,8 @@ int reid_device_sync(reid_ctx* ctx);
  * is set, every embed / frame entry point, reid_ctx_sync and reid_device_sync return REID_ERR_STATE (the synchronising embed
  * calls report a fault raised by their own work); reid_ctx_clear_fault drains the stream and resets it. */
 int reid_ctx_clear_fault(reid_ctx* ctx);
-/* crops per pass through the network (activation working set = chunk * 3.2 MB, kept inside the 256 MiB Infinity Cache) */
+/* crops per pass through the network, 1..4096; default 1024 (the measured-best size: a pass of 1024 crops fills every launch of the
+ * network with whole rounds of tiles; activation working set = crops in the pass * 3.2 MB).  Swin passes are capped at 1024 images. */
 int reid_ctx_set_chunk(reid_ctx* ctx, int crops_per_pass);
 /* arithmetic of the convolution GEMMs:
  *   0 = exact fp32 (v_mfma_f32_32x32x2_f32) - the reference's arithmetic, the default;

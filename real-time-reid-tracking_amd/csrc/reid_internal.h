@@ -331,7 +331,8 @@ struct reid_ctx {
     reid_comm* comm = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    int chunk = 64;
+    int chunk = 1024;        // crops per pass (reid_ctx_set_chunk).  64 until round 4: 45 k crops/s in mode 2 where 1024 gives 68 k; the parity
+                             // sets give the reference's arg-min on every row at 64, 128, 256 and 1024 (tools/config1_chunk_check.py)
     int precision = 0;
     bool profile = false;
     ProfSlot prof[REID_K_COUNT];

@@ -127,7 +127,7 @@ def _seres18_fixture_check(eng, golden_dir, tag, crops_fn, precision=0):
     # rebatching does not change results beyond fp32 noise (chunked passes)
     eng.set_chunk(2)
     emb_c = eng.embed_u8(crops)
-    eng.set_chunk(64)
+    eng.set_chunk(1024)
     np.testing.assert_allclose(emb_c, emb, rtol=1e-6, atol=1e-6 * np.abs(emb).max())
 
 
@@ -143,7 +143,7 @@ def test_fused_stem_pool_is_the_same_for_whole_images_and_strips(eng_w0):
     strips = eng.embed_u8(crops)
     eng.set_chunk(40)
     small = eng.embed_u8(crops)
-    eng.set_chunk(64)
+    eng.set_chunk(1024)
     assert np.array_equal(whole, strips)
     cos = (whole * small).sum(1) / np.linalg.norm(whole, axis=1) / np.linalg.norm(small, axis=1)
     assert (1 - cos).max() < 1e-6 and np.abs(whole - small).max() < 1e-5 * np.abs(whole).max()
@@ -906,9 +906,10 @@ def test_f16_path_small_and_odd_batches(eng_w0, n):
 
 
 # ----------------------------------------------------------------------------- reference-held vectors at BASELINE sizes
+@pytest.mark.parametrize("chunk", [64, 1024])   # four passes of 64 crops (the library default of rounds 1-3) / one pass of 256
 @pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("tag,crops_fn,seed", [("rand0", synth.crops_u8, 0), ("smooth5", synth.smooth_crops_u8, 5)])
-def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, crops_fn, seed):
+def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, crops_fn, seed, chunk):
     """BASELINE configs[0]: 256 crops -> emb[256,512] -> (1 - cos) / 2 matrix -> row arg-min, against vectors the REFERENCE's own
     SERse18_IBN + cosine_dist produced (tests/golden/config1.npz, oracle/gen_golden.py:gen_config1).  The arg-min vector is
     compared on ALL 256 rows: the number of differing rows is printed and every one of them must be a row whose top-2 gap in the
@@ -918,10 +919,12 @@ def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, c
     g = np.load(os.path.join(golden_dir, "config1.npz"))
     ref, gap = g[tag + "_emb"], g[tag + "_gap"]
     eng.set_precision(precision)
+    eng.set_chunk(chunk)
     try:
         emb = eng.embed_u8(crops_fn(256, seed))
     finally:
         eng.set_precision(0)
+        eng.set_chunk(1024)
     cos = (emb * ref).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(ref, axis=1)
     f16s = precision == 1                                                 # precision 2 (fp32-class) is held to the fp32 thresholds
     assert (1 - cos).max() < (1e-4 if f16s else 1e-5)                     # north_star allows 1e-3
@@ -1481,7 +1484,7 @@ def test_camera_bias_and_view_embedding_match_reference_fixture(eng, golden_dir,
         with pytest.raises(_ffi.ReidHipError):
             eng.embed_u8(crops)
         np.testing.assert_array_equal(eng.embed_u8(crops), plain)      # nothing left pending after the errors
-        eng.set_chunk(64)
+        eng.set_chunk(1024)
         m = models.build_model("seres18_ibn", num_classes=751, loss="triplet", pretrained=False).eval()
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         out, lg = m(seres18.preprocess_u8(crops), cam=torch.from_numpy(g["cam"]), return_logits=True)
@@ -1507,7 +1510,7 @@ def test_camera_bias_and_view_embedding_match_reference_fixture(eng, golden_dir,
             models.build_model("swin_transformer", num_classes=751, loss="triplet", pretrained=False)(img, view_index=[0, 0, 0])
     finally:
         eng.set_side_index(None)
-        eng.set_chunk(64)
+        eng.set_chunk(1024)
         eng.set_precision(0)
 
 
