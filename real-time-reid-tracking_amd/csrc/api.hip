@@ -37,6 +37,7 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     reid_ctx* c = new reid_ctx();
     c->device = device;
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
+    if (const char* e = getenv("REID_F16_LIN_256")) c->f16_lin_256 = atoi(e);
     if (const char* e = getenv("REID_F16_SPLITK")) c->f16_split_k = atoi(e);
     if (const char* e = getenv("REID_BANK_FAST")) c->bank_fast = atoi(e);
     if (const char* e = getenv("REID_SIDE_COPY")) c->side_copy = atoi(e);

@@ -755,8 +755,13 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
         // (624 TF), 256 -> 128642 (679 TF), 512 -> 256642 (953 TF) when that still gives >= 192 blocks
         const long long mt = (p.M + 255) / 256;
         const bool k64 = p.K % 64 == 0 && (AMODE != A16_IM2COL || p.Cin % 64 == 0);
-        // (the linear-epilogue build of the 256-wide tile spills 98 VGPRs: those launches take the 128-wide one)
+        // (the linear-epilogue build of the 256-wide tile used to spill 98 VGPRs: the fp16-storage mode's launches take the 128-wide one)
         int bn = !p.lin && p.N % 256 == 0 && mt * (p.N / 256) >= 192 ? 256 : (p.N % 128 == 0 ? 128 : 64);
+        // fp32-class Swin layers whose width allows it and whose K loop is long (stage 3 fc1, stage 4, the 768-wide trunk convolutions): the
+        // 256-wide tile's main loop is 20-25 % faster on these shapes (profiles/r04_gemm_cfg_sweep.txt) and its linear epilogue no longer
+        // spills more than the 128-wide one's (23 VGPRs each).  The choice depends on the layer's shape only, and an output's K order is
+        // the same in both tiles: bit-identical results.
+        if (p.lin && ctx->f16_lin_256 && p.split_terms && p.N % 256 == 0 && k64 && p.K >= 1152) bn = 256;
         // a tracking frame: twice the blocks on a half-empty chip.  Convolutions only: the tile shape of a Swin linear must not
         // depend on the batch (the two instantiations round their epilogues differently, an image's embedding would too)
         if (!p.lin && bn == 128 && p.N > 128 && mt * (p.N / 128) < 128) bn = 64;
@@ -764,7 +769,7 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
         else if (bn == 128 && p.N == 128) cfg = 128323;
         // Swin's linears have short K loops (K = 96 .. 768, fc2 up to 3072): with BK = 32 and three stages a block needs 72 KB of
         // LDS, so TWO blocks share a CU and one's prologue / epilogue hides behind the other's MFMAs (measured: 15.97 -> 17.7 k img/s)
-        else if (p.lin) cfg = bn * 1000 + 323;
+        else if (p.lin) cfg = bn == 256 ? 256642 : bn * 1000 + 323;
         else cfg = bn * 1000 + 642;
     }
     if (p.lin) {   // linear-epilogue builds exist for the tile shapes the heuristic above picks (no STEM mode)
