@@ -38,6 +38,10 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     c->device = device;
     if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
     if (const char* e = getenv("REID_F16_LIN_256")) c->f16_lin_256 = atoi(e);
+    if (const char* e = getenv("REID_SWIN_CHUNK_MAX")) {
+        const int v = atoi(e);
+        if (v > 0 && v < c->swin_chunk_cap) c->swin_chunk_cap = v;
+    }
     if (const char* e = getenv("REID_F16_SPLITK")) c->f16_split_k = atoi(e);
     if (const char* e = getenv("REID_BANK_FAST")) c->bank_fast = atoi(e);
     if (const char* e = getenv("REID_SIDE_COPY")) c->side_copy = atoi(e);

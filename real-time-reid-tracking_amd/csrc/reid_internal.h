@@ -390,6 +390,7 @@ struct reid_ctx {
     int swin_attn_mfma = 1;  // Swin window attention (REID_SWIN_ATTN): 1 = matrix cores in fp16-storage mode, VALU kernel in exact fp32
                              // (v_mfma_f32_32x32x2_f32 runs at the fp32 VALU rate: no gain); 2 = matrix cores in both; 0 = VALU in both
     int f16_split_k = 1;     // LDS-halo kernel: split the input channels over 2-4 blocks per tile when a launch has < 128 tiles (REID_F16_SPLITK)
+    int swin_chunk_cap = 1024;   // images per Swin pass at most (REID_SWIN_CHUNK_MAX lowers it, read at context creation)
     int f16_lin_256 = 1;     // fp32-class Swin linears / trunk convolutions with N % 256 == 0 and K >= 1152 on 256 x 256 tiles, BK 64 (REID_F16_LIN_256=0:
                              // 256 x 128, BK 32).  Same K order per output: bit-identical; 16.11 -> 16.25 k img/s
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)

@@ -1645,8 +1645,7 @@ extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int
     // images per pass: ~13 MB of fp32 activations per 224x224 image, 13 GB at the cap.  Passes of 1024 instead of 256 images run
     // 8 % faster in the fp32-class mode (14.6 -> 15.7 k img/s): the stage 3-4 linears of a 256-image pass are 294-588 tiles for 512
     // block slots.  Results are bit-identical for every pass size (tools/swin_chunk_check.py).  REID_SWIN_CHUNK_MAX lowers the cap.
-    int cap = 1024;
-    if (const char* e = getenv("REID_SWIN_CHUNK_MAX")) cap = atoi(e) > 0 && atoi(e) < cap ? atoi(e) : cap;
+    const int cap = ctx->swin_chunk_cap;
     const int chunk = ctx->chunk < cap ? ctx->chunk : cap;
     const size_t img = (size_t)3 * h * w;
     for (int i = 0; i < n; i += chunk) {
