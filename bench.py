@@ -366,6 +366,23 @@ def run_swin(job, args):
 
     main_prec = args.precision
     main_res = run(main_prec, args.steps, args.warmup)
+    # what was timed is checked before it is printed: the embeddings of the timed configuration (passes of up to 1024 images) are
+    # finite, and six of them agree with the exact-fp32 mode's on the same images (images are independent,
+    # swin_transformer.py:191-232,248-260; the GPU tests hold exact fp32 to the reference's vectors)
+    eng.set_precision({"f32": 0, "f16": 1, "f16x3": 2}[main_prec])
+    step()
+    got = emb_local.numpy()
+    if not np.isfinite(got).all():
+        raise RuntimeError("swin: non-finite embeddings in the timed configuration")
+    eng.set_precision(0)
+    six = parallel.DevArray(eng, (6, 96))
+    eng.swin_embed_dev(x.ptr, 6, 224, 224, six.ptr)
+    want = six.numpy()
+    cos6 = (got[:6] * want).sum(1) / np.linalg.norm(got[:6], axis=1) / np.linalg.norm(want, axis=1)
+    check = {"rows": 6, "max_1_minus_cos_vs_exact_fp32": float((1 - cos6).max()),
+             "max_rel_err_vs_exact_fp32": float(np.abs(got[:6] - want).max() / np.abs(want).max())}
+    if check["max_1_minus_cos_vs_exact_fp32"] > (1e-4 if main_prec == "f16" else 1e-5):
+        raise RuntimeError("swin: timed configuration disagrees with exact fp32: %r" % (check,))
     others = {} if args.single else {o: run(o, max(1, min(2, args.steps)), 1) for o in ("f32", "f16x3", "f16") if o != main_prec}
     if rank != 0:
         return None
@@ -375,6 +392,7 @@ def run_swin(job, args):
            "config": {"workload": "BASELINE configs[2]: Swin-T v1 backbone, %d images 224x224 per GPU (+ all-gather of the 96-d embeddings)" % n,
                       "images_per_gpu": n, "embed_dim": 96, "chunk": min(args.chunk, 1024)}}
     out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
+    out["self_check"] = check
     for o, r in others.items():
         out[o + "_path"] = r
     if not args.no_cpu and world == 1:
@@ -671,7 +689,7 @@ def run_market(job, args):
 SUB_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config", "roofline", "cpu_baseline",
             "f16_path", "f32_path", "f16x3_path", "f16x3_vs_f32", "other_kernels", "embed_ms", "distmat_ms", "distmat_shard_ms", "search_ms", "search_tflops",
             "crops_per_s", "ms_per_frame_median", "ms_per_frame_p95", "allgather_us_median", "camera_streams", "rank1_top20",
-            "whole_net_tflops", "f16_vs_f32_max_cosine_err")
+            "whole_net_tflops", "f16_vs_f32_max_cosine_err", "self_check", "plugin_default")
 
 
 def run_all(job, args):
@@ -683,20 +701,45 @@ def run_all(job, args):
     from a watchdog thread: rank 0 prints the line with what it has and EVERY rank leaves with a non-zero exit code (3), so the
     launcher and the driver see the failure.  REID_BENCH_LIMIT_SCALE scales the time limits (tests)."""
     import copy
+    import tempfile
     import threading
     state = {"out": None, "current": None, "deadline": None}
+    # "rank 0 has printed the line": a flag file named after this job's rendezvous.  Every rank's watchdog fires on its own clock,
+    # and the launcher (torch.distributed.run) SIGTERMs the remaining ranks as soon as ONE exits non-zero - so a rank other than 0
+    # must not leave before rank 0 has written what it has (it waits for the flag, bounded), or the partial line is lost.
+    flag = os.path.join(tempfile.gettempdir(), "reid_bench_%s_%s_%s.emitted" % (
+        os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid()))))
+    if job.rank == 0:
+        try:
+            os.unlink(flag)
+        except OSError:
+            pass
+
+    def leave_failed(line_out):
+        """Rank 0: print the partial line, raise the flag, exit 3.  Other ranks: wait until the flag is up (at most 10 s), exit 3."""
+        if job.rank == 0:
+            if line_out is not None:
+                emit(json.dumps(line_out))
+            try:
+                open(flag, "w").close()
+            except OSError:
+                pass
+        elif job.world > 1:
+            t_end = time.monotonic() + 10.0
+            while not os.path.exists(flag) and time.monotonic() < t_end:
+                time.sleep(0.05)
+        os._exit(3)                           # a lost collective / hung or failed sub-workload is a FAILED run
 
     def watchdog():
         while True:
-            time.sleep(1.0)
+            time.sleep(0.25)
             dl = state["deadline"]
             if dl is not None and time.monotonic() > dl:
-                if job.rank == 0 and state["out"] is not None:
-                    state["out"][state["current"]] = {"error": "no answer within the time limit (watchdog)"}
-                    emit(json.dumps(state["out"]))
                 print("[bench rank %d] watchdog: %s did not come back within its time limit" % (job.rank, state["current"]),
                       file=sys.stderr, flush=True)
-                os._exit(3)                   # a lost collective / hung sub-workload is a FAILED run
+                if job.rank == 0 and state["out"] is not None:
+                    state["out"][state["current"]] = {"error": "no answer within the time limit (watchdog)"}
+                leave_failed(state["out"])
 
     out = run_embed(job, args)
     state["out"] = out
@@ -740,11 +783,48 @@ def run_all(job, args):
         sub("tracking", tracking_both, 300, cameras=4 if job.world == 1 else 0)
     except Exception as e:     # noqa: BLE001 - multi-rank job out of step: print what there is and leave
         print("[bench rank %d] sub-workload failed: %r" % (job.rank, e), file=sys.stderr, flush=True)
-        if job.rank == 0 and out is not None:
-            emit(json.dumps(out))
-        os._exit(3)                           # ranks out of step: never report success
+        state["deadline"] = None              # this thread prints and leaves; the watchdog must not race it
+        leave_failed(out)                     # ranks out of step: never report success
     state["deadline"] = None
+    if out is not None:
+        out["plugin_default"] = plugin_default(job, out)
     return out
+
+
+def plugin_default(job, out):
+    """What the drop-in surface delivers when the tracker sets nothing: the arithmetic Extractor / build_model pick by default
+    (reid_amd.precision: $REID_PRECISION, else f16x3), this line's numbers for THAT arithmetic by name, and the synchronous
+    plugin call itself - Extractor.__call__ on ~30 ragged crops, packed, uploaded, resized, embedded and downloaded per call, as
+    track_yolov5.py:178-253 drives it (feature_extractor.py:48-53)."""
+    from reid_amd import precision, synth
+    from reid_amd.extractor import Extractor
+    label = precision.LABEL[precision.resolve(None)]
+
+    def pick(obj):
+        if not isinstance(obj, dict):
+            return None
+        return obj if obj.get("dtype") == label else obj.get(label + "_path")
+    head, trk = pick(out), pick(out.get("tracking"))
+    res = {"precision": label,
+           "crops_per_s": head.get("value") if head else None,
+           "tracking_frames_per_s": trk.get("value") if trk else None}
+    try:
+        ext = Extractor(synth.seres18_state_dict(0, gem_p=3.0))
+        pool = synth.ragged_crops_u8(256, seed=3)
+        frames = [[pool[(f * 7 + i) % 256] for i in range(30)] for f in range(40)]
+        for fr in frames[:10]:
+            ext(fr)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            for fr in frames:
+                ext(fr)
+        el = time.perf_counter() - t0
+        res["extractor_call_30_crops_ms"] = round(el / 200 * 1e3, 3)
+        res["extractor_calls_per_s"] = round(200 / el, 1)
+        res["extractor_precision_after"] = ext.precision
+    except Exception as e:     # noqa: BLE001
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    return res
 
 
 _RESULT_FD = None

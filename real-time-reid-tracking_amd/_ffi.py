@@ -109,7 +109,8 @@ _dbg = None
 
 
 class ReidHipError(RuntimeError):
-    pass
+    """A non-zero reid_status; ``status`` carries it (include/reid_hip.h: REID_ERR_ARG -1, _HIP -2, _STATE -3, _NOMEM -4)."""
+    status = None
 
 
 def lib():
@@ -143,4 +144,6 @@ def debug_lib():
 def check(status):
     if status != 0:
         msg = lib().reid_last_error()
-        raise ReidHipError("libreid_hip status %d: %s" % (status, msg.decode() if msg else "?"))
+        err = ReidHipError("libreid_hip status %d: %s" % (status, msg.decode() if msg else "?"))
+        err.status = int(status)
+        raise err

@@ -9,6 +9,7 @@ from collections import OrderedDict
 
 import numpy as np
 
+from . import precision as _precision
 from . import synth, weights
 from .engine import IMG_H, IMG_W, get_engine
 
@@ -85,9 +86,11 @@ class SERes18IBN:
     embed_dim = 512
     arch = "seres18_ibn"
 
-    def __init__(self, num_classes=751, loss="triplet", pretrained=False, use_gpu=True, seed=0, num_cams=6, cam_factor=-1.0, **_):
+    def __init__(self, num_classes=751, loss="triplet", pretrained=False, use_gpu=True, seed=0, num_cams=6, cam_factor=-1.0,
+                 precision=None, **_):
         if loss not in ("triplet", "softmax"):
             raise NotImplementedError                      # seres18_ibn(), SERes18_IBN.py:279-285
+        self._mode = _precision.resolve(precision)         # "f16x3" unless the argument or $REID_PRECISION says otherwise (precision.py)
         self.num_classes = num_classes
         self.num_cams, self.cam_factor = num_cams, float(cam_factor)   # SERes18_IBN.py:193,198: cam_bias [num_cams,512] and its factor
         self.is_reid = loss == "softmax"
@@ -155,14 +158,23 @@ class SERes18IBN:
         return missing, unexpected + mismatched
 
     # ---- engine
-    def _engine(self):
-        eng = get_engine(self._device)
-        if self._dirty or getattr(eng, "_owner", None) is not self:
-            blob, manifest, _ = weights.pack_seres18(self._sd, cam_factor=getattr(self, "cam_factor", -1.0))
-            eng.load_seres18(blob, manifest)
-            eng._owner = self
-            self._dirty = False
-        return eng
+    @property
+    def precision(self):
+        """The arithmetic this model runs in now ("f16x3", "f32" or "f16"; "f32" after a fall back, precision.py)."""
+        return _precision.LABEL[self._mode]
+
+    def _needs_bind(self, eng):
+        return self._dirty or getattr(eng, "_owner", None) is not self
+
+    def _do_bind(self, eng):
+        blob, manifest, _ = weights.pack_seres18(self._sd, cam_factor=getattr(self, "cam_factor", -1.0))
+        eng.load_seres18(blob, manifest)
+        eng._owner = self
+        self._dirty = False
+
+    def _run(self, fn):
+        """fn(engine) with this model's weights bound and the context in this model's arithmetic (precision.run)."""
+        return _precision.run(self, get_engine(self._device), self.arch, fn)
 
     def warmup(self, imgsz=(1, 3, IMG_H, IMG_W)):
         """One dummy batch: allocates workspaces and loads code objects (track_yolov5.py:169-171)."""
@@ -187,18 +199,23 @@ class SERes18IBN:
         if is_torch and x.is_cuda:
             if x.device.index != self._device:
                 self.to(x.device.index)
-            eng = self._engine()
-            if cam is not None:
-                eng.set_side_index(_index_array(cam, x.shape[0]))
-            emb, logits = _torch_cuda_forward(
-                x, lambda xf, o: eng.embed_f32_nchw_dev(xf.data_ptr(), xf.shape[0], o[0].data_ptr(), o[1].data_ptr()), eng,
-                (self.embed_dim, self.num_classes))
+
+
+            def on_device(eng):
+                if cam is not None:
+                    eng.set_side_index(_index_array(cam, x.shape[0]))
+                return _torch_cuda_forward(
+                    x, lambda xf, o: eng.embed_f32_nchw_dev(xf.data_ptr(), xf.shape[0], o[0].data_ptr(), o[1].data_ptr()), eng,
+                    (self.embed_dim, self.num_classes))
+            emb, logits = self._run(on_device)
         else:
             x_np = x.detach().float().cpu().numpy() if is_torch else np.asarray(x, np.float32)
-            eng = self._engine()
-            if cam is not None:
-                eng.set_side_index(_index_array(cam, x_np.shape[0]))
-            emb, logits = eng.embed_f32_nchw(x_np, logits=True)
+
+            def on_host(eng):
+                if cam is not None:
+                    eng.set_side_index(_index_array(cam, x_np.shape[0]))
+                return eng.embed_f32_nchw(x_np, logits=True)
+            emb, logits = self._run(on_host)
             if is_torch:
                 import torch
                 emb, logits = torch.from_numpy(emb), torch.from_numpy(logits)
@@ -210,7 +227,8 @@ class SERes18IBN:
 
     def embed_crops(self, crops):
         """uint8 HxWx3 crops of any size -> float32[N,512]; resize + normalise on the device."""
-        return self._engine().embed_ragged_u8(list(crops))
+        crops = list(crops)
+        return self._run(lambda eng: eng.embed_ragged_u8(crops))
 
 
 def seres18_ibn(num_classes=751, loss="triplet", pretrained=False, use_gpu=True, **kwargs):
@@ -251,8 +269,11 @@ class SwinT:
 
     embed_dim = 96
 
+    arch = "swin_transformer"
+
     def __init__(self, num_classes=751, loss="softmax", pretrained=False, use_gpu=True, seed=0, camera=0, sequence=0, side_info=True,
-                 side_info_coeff=1.5, **_):
+                 side_info_coeff=1.5, precision=None, **_):
+        self._mode = _precision.resolve(precision)
         self.num_classes = num_classes
         self.loss = loss
         self.training = False
@@ -290,14 +311,17 @@ class SwinT:
         self._dirty = True
         return missing, unexpected + mismatched
 
-    def _engine(self):
-        eng = get_engine(self._device)
-        if self._dirty or getattr(eng, "_swin_owner", None) is not self:
-            blob, manifest, _ = weights.pack_swin(self._sd, side_info_coeff=getattr(self, "side_info_coeff", 1.5))
-            eng.load_swin(blob, manifest)
-            eng._swin_owner = self
-            self._dirty = False
-        return eng
+    precision = SERes18IBN.precision
+    _run = SERes18IBN._run
+
+    def _needs_bind(self, eng):
+        return self._dirty or getattr(eng, "_swin_owner", None) is not self
+
+    def _do_bind(self, eng):
+        blob, manifest, _ = weights.pack_swin(self._sd, side_info_coeff=getattr(self, "side_info_coeff", 1.5))
+        eng.load_swin(blob, manifest)
+        eng._swin_owner = self
+        self._dirty = False
 
     def warmup(self, imgsz=(1, 3, 224, 224)):
         self(np.zeros(imgsz, np.float32))
@@ -324,18 +348,23 @@ class SwinT:
                 raise ValueError("expected float[n,3,224k,224m], got %s" % (tuple(x.shape),))
             if x.device.index != self._device:
                 self.to(x.device.index)
-            eng = self._engine()
-            if view_index is not None:
-                eng.set_side_index(_index_array(view_index, x.shape[0]))
-            emb, logits = _torch_cuda_forward(
-                x, lambda xf, o: eng.swin_embed_dev(xf.data_ptr(), xf.shape[0], xf.shape[2], xf.shape[3], o[0].data_ptr(), o[1].data_ptr()),
-                eng, (self.embed_dim, self.num_classes))
+
+
+            def on_device(eng):
+                if view_index is not None:
+                    eng.set_side_index(_index_array(view_index, x.shape[0]))
+                return _torch_cuda_forward(
+                    x, lambda xf, o: eng.swin_embed_dev(xf.data_ptr(), xf.shape[0], xf.shape[2], xf.shape[3], o[0].data_ptr(), o[1].data_ptr()),
+                    eng, (self.embed_dim, self.num_classes))
+            emb, logits = self._run(on_device)
         else:
             x_np = x.detach().float().cpu().numpy() if is_torch else np.asarray(x, np.float32)
-            eng = self._engine()
-            if view_index is not None:
-                eng.set_side_index(_index_array(view_index, x_np.shape[0]))
-            emb, logits = eng.swin_embed_f32_nchw(x_np, logits=True)
+
+            def on_host(eng):
+                if view_index is not None:
+                    eng.set_side_index(_index_array(view_index, x_np.shape[0]))
+                return eng.swin_embed_f32_nchw(x_np, logits=True)
+            emb, logits = self._run(on_host)
             if is_torch:
                 import torch
                 emb, logits = torch.from_numpy(emb), torch.from_numpy(logits)

@@ -113,6 +113,12 @@ class Engine:
         """0 exact fp32 (the reference's arithmetic), 1 fp16 storage / fp32 accumulate, 2 "fp32-class": fp32 storage, the 3x3
         stride-1 convolutions as three f16 matrix-core products per multiply on hi/lo-split operands (fp32 accumulate)."""
         check(self.lib.reid_ctx_set_precision(self.h, int(mode)))
+        self._precision = int(mode)
+
+    @property
+    def precision(self):
+        """The arithmetic mode this context is in (the library's default is 0)."""
+        return getattr(self, "_precision", 0)
 
     def set_side_index(self, index):
         """Camera (ResNet18-IBN-SE: SERes18_IBN.py:269-270) or view (Swin: swin_transformer.py:301-302) index of every image of
@@ -159,6 +165,7 @@ class Engine:
     # ---- weights
     def load_seres18(self, blob, manifest):
         blob = _f32(blob)
+        self._owner = None                       # the plugin objects (Extractor, backbones) mark what THEY loaded afterwards
         check(self.lib.reid_seres18_load(self.h, _ptr(blob), blob.size, manifest.encode()))
         d, nc = C.c_int(), C.c_int()
         check(self.lib.reid_seres18_dims(self.h, C.byref(d), C.byref(nc)))
@@ -166,6 +173,7 @@ class Engine:
 
     def load_swin(self, blob, manifest):
         blob = _f32(blob)
+        self._swin_owner = None
         check(self.lib.reid_swin_load(self.h, _ptr(blob), blob.size, manifest.encode()))
         d, nc = C.c_int(), C.c_int()
         check(self.lib.reid_swin_dims(self.h, C.byref(d), C.byref(nc)))

@@ -16,28 +16,41 @@ import logging
 
 import numpy as np
 
+from . import precision as _precision
 from . import weights
-from .engine import get_engine
 
 
 class Extractor(object):
-    def __init__(self, model_path, use_cuda=True, device=0):
+    def __init__(self, model_path, use_cuda=True, device=0, precision=None):
+        """``Extractor(model_path, use_cuda=True)`` as feature_extractor.py:15-29.  ``precision`` (keyword, not in the reference):
+        "f16x3" (default; $REID_PRECISION overrides the default) / "f32" / "f16" - see precision.py; a checkpoint the fp32-class
+        arithmetic cannot represent runs in exact fp32, with one log line."""
         if not use_cuda:
             raise RuntimeError("Extractor: the MI355X engine has no CPU path (use_cuda=False is not supported)")
         self.device = "cuda"
         self.size = (128, 256)                 # (W, H), feature_extractor.py:24
-        self.net = get_engine(device)
+        self._mode = _precision.resolve(precision)
         if isinstance(model_path, dict):
             state_dict = model_path            # already-loaded state_dict (tests, benchmarks)
         else:
-            import torch                       # PyTorch only reads the checkpoint (feature_extractor.py:18)
-            state_dict = torch.load(model_path, map_location="cpu")
+            # PyTorch only reads the checkpoint (feature_extractor.py:18) - and it is imported BEFORE the engine: torch bundles its
+            # own HIP runtime, and the process must hold ONE (libreid_hip.so binds to whichever is loaded first; the other order
+            # loads two and aborts in the exit handlers - DESIGN.md section 6, the rule parallel.RcclComm.from_env enforces)
+            import torch
+            state_dict = torch.load(model_path, map_location="cpu")   # {"state_dict": ...} / "module." prefixes: weights.pack_seres18
+        from .engine import get_engine
+        self.net = get_engine(device)
         blob, manifest, self.info = weights.pack_seres18(state_dict)   # strict=False semantics, :19
-        self.net.load_seres18(blob, manifest)
-        self.net._owner = self
         self._packed = (blob, manifest)
+        self.net._owner = None
+        _precision.run(self, self.net, "Extractor", lambda eng: None)      # load now; a checkpoint mode 2 refuses falls back here
         logger = logging.getLogger("root.tracker")
         logger.info("Loading weights from {}... Done!".format(model_path if not isinstance(model_path, dict) else "<state_dict>"))
+
+    @property
+    def precision(self):
+        """The arithmetic this extractor runs in now ("f16x3", "f32" or "f16"; "f32" after a fall back)."""
+        return _precision.LABEL[self._mode]
 
     def _preprocess(self, im_crops):
         """Host-visible equivalent of feature_extractor.py:31-46 is fused into the device path; this only
@@ -46,15 +59,19 @@ class Extractor(object):
             raise RuntimeError("Extractor: expected a non-empty list of crops")   # torch.cat([]) raises, :44
         return [np.asarray(im) for im in im_crops]
 
-    def _bind(self):
-        if getattr(self.net, "_owner", None) is not self:      # another model was loaded on this device meanwhile
-            self.net.load_seres18(*self._packed)
-            self.net._owner = self
+    def _needs_bind(self, eng):
+        return getattr(eng, "_owner", None) is not self        # another model was loaded on this device meanwhile
+
+    def _do_bind(self, eng):
+        eng.load_seres18(*self._packed)
+        eng._owner = self
+
+    def _run(self, fn):
+        return _precision.run(self, self.net, "Extractor", fn)
 
     def __call__(self, im_crops):
         crops = self._preprocess(im_crops)
-        self._bind()
-        return self.net.embed_ragged_u8(crops)
+        return self._run(lambda eng: eng.embed_ragged_u8(crops))
 
     def from_frame(self, bbox_xywh, ori_img):
         """DeepSort._get_features(bbox_xywh, ori_img) ([external] deep_sort.py) in one call: centre-format boxes are
@@ -69,5 +86,4 @@ class Extractor(object):
         xyxy = np.empty((boxes.shape[0], 4), np.int32)
         for i, (x, y, w, h) in enumerate(boxes):
             xyxy[i] = (max(int(x - w / 2), 0), max(int(y - h / 2), 0), min(int(x + w / 2), width - 1), min(int(y + h / 2), height - 1))
-        self._bind()
-        return self.net.embed_frame_u8(ori_img, xyxy)
+        return self._run(lambda eng: eng.embed_frame_u8(ori_img, xyxy))

@@ -18,10 +18,11 @@ def show_avai_models():
     print(list(__model_factory.keys()))
 
 
-def build_model(name, num_classes, loss='softmax', pretrained=True, use_gpu=True):
+def build_model(name, num_classes, loss='softmax', pretrained=True, use_gpu=True, precision=None):
     """Same signature, same ``KeyError`` text as models/__init__.py:93-121; constructors are called with
-    exactly (num_classes, loss, pretrained, use_gpu)."""
+    (num_classes, loss, pretrained, use_gpu).  ``precision`` (keyword, this engine's addition): the arithmetic the model runs
+    in - None = $REID_PRECISION, else "f16x3", the mode bench.py reports (precision.py)."""
     avai_models = list(__model_factory.keys())
     if name not in avai_models:
         raise KeyError('Unknown model: {}. Must be one of {}'.format(name, avai_models))
-    return __model_factory[name](num_classes=num_classes, loss=loss, pretrained=pretrained, use_gpu=use_gpu)
+    return __model_factory[name](num_classes=num_classes, loss=loss, pretrained=pretrained, use_gpu=use_gpu, precision=precision)

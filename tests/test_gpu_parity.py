@@ -1268,7 +1268,116 @@ def test_build_model_warmup_and_cuda_tensor_entry(eng_w0):
     assert float((1 - cos).max()) < 1e-5                                # inputs rounded to fp16, arithmetic still fp32
     # host call right after a device call on another stream: the engine drains the old stream before it switches
     eng.set_stream(None)
-    assert np.array_equal(eng.embed_f32_nchw(x.numpy()), want)
+    assert model.precision == os.environ.get("REID_PRECISION", "f16x3") and eng.precision == 0   # the model's arithmetic is its own:
+    eng.set_precision({"f32": 0, "f16": 1, "f16x3": 2}[model.precision])                      # the shared engine kept the mode it had
+    try:
+        assert np.array_equal(eng.embed_f32_nchw(x.numpy()), want)
+    finally:
+        eng.set_precision(0)
+
+
+_EXTRACTOR_FROM_FILE = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+from reid_amd import _ffi, synth
+from reid_amd.extractor import Extractor
+assert _ffi._lib is None and "torch" not in sys.modules          # importing the plugin loads neither torch nor the library
+ext = Extractor(sys.argv[2], use_cuda=True)                        # feature_extractor.py:15: (model_path, use_cuda=True)
+emb = ext(synth.ragged_crops_u8(5, seed=11))
+hip = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+print(json.dumps({"emb": emb.tolist(), "precision": ext.precision, "hip_runtimes": hip}))
+"""
+
+
+@pytest.mark.timeout(600)
+def test_extractor_from_a_checkpoint_file_in_a_fresh_process(eng_w0, tmp_path):
+    """The reference's actual constructor, ``Extractor(model_path: str, use_cuda=True)`` (modification_deepsort/
+    feature_extractor.py:15-19: torch.load + load_state_dict(strict=False)), on a checkpoint FILE as the trainer writes it
+    (saved from DataParallel: "module." prefix, image_reid_train.py:111,635), in a process that has imported nothing before:
+    torch reads the file BEFORE the engine loads libreid_hip.so, so the process holds ONE HIP runtime (the other order loads
+    torch's bundled libamdhip64 beside /opt/rocm's and aborts in the exit handlers), the call returns the
+    embeddings of the in-process extractor bit for bit, in the plugin's default arithmetic, and the interpreter exits 0."""
+    import json
+    import subprocess
+    import sys
+    from reid_amd.extractor import Extractor
+    eng, sd = eng_w0
+    path = tmp_path / "ckpt.t7"
+    torch.save({"module." + k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, str(path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "REID_PRECISION"}
+    r = subprocess.run([sys.executable, "-c", _EXTRACTOR_FROM_FILE, root, str(path)], capture_output=True, text=True, env=env, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "double free" not in r.stderr and "corruption" not in r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["precision"] == "f16x3" and len(d["hip_runtimes"]) == 1, d["hip_runtimes"]
+    got = np.asarray(d["emb"], np.float32)
+    crops = synth.ragged_crops_u8(5, seed=11)
+    assert np.array_equal(got, Extractor(sd, precision="f16x3")(crops))
+    want = seres18.forward(sd, torch.from_numpy(matching.preprocess(crops)))[0].numpy()
+    cos = (got * want).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(want, axis=1)
+    assert (1 - cos).max() < 1e-5
+
+
+def test_plugin_precision_argument_environment_and_fallback(eng_w0, caplog, monkeypatch):
+    """The plugin objects run in the arithmetic bench.py reports unless told otherwise: precision= argument > $REID_PRECISION >
+    "f16x3"; their mode is applied per call and the shared engine keeps the mode other callers gave it.  A checkpoint the
+    fp32-class mode refuses (a weight it cannot split: at load; an activation outside f16: through the fault word, at the first
+    call) runs in exact fp32 from then on - same numbers as precision="f32" - with ONE log line."""
+    import logging
+    from reid_amd import models
+    from reid_amd.extractor import Extractor
+    eng, sd = eng_w0
+    crops = synth.ragged_crops_u8(4, seed=5)
+    monkeypatch.delenv("REID_PRECISION", raising=False)
+    e2, e0 = Extractor(sd), Extractor(sd, precision="f32")
+    assert (e2.precision, e0.precision) == ("f16x3", "f32")
+    a2, a0 = e2(crops), e0(crops)
+    assert eng.precision == 0 and not np.array_equal(a2, a0) and np.abs(a2 - a0).max() <= 2e-5 * np.abs(a0).max()
+    eng.set_precision(2)
+    try:
+        b0 = eng.embed_ragged_u8(crops)          # the extractors left the weights of e0 bound (same checkpoint) and the engine's mode alone
+        assert np.array_equal(b0, a2) and np.array_equal(e0(crops), a0) and eng.precision == 2
+    finally:
+        eng.set_precision(0)
+    monkeypatch.setenv("REID_PRECISION", "f32")
+    assert Extractor(sd).precision == "f32" and models.build_model("seres18_ibn", 751, loss="triplet", pretrained=False).precision == "f32"
+    assert models.build_model("swin_transformer", 751, pretrained=False, precision=1).precision == "f16"
+    monkeypatch.delenv("REID_PRECISION")
+    with pytest.raises(ValueError):
+        Extractor(sd, precision="bf16")
+    # (1) weights outside the split range: refused when the mode is selected -> fall back at construction
+    bad = dict(sd)
+    bad["basicBlock31.block_pre.conv2.weight"] = np.array(sd["basicBlock31.block_pre.conv2.weight"], copy=True)
+    bad["basicBlock31.block_pre.conv2.weight"][3, 5, 1, 1] = 40.0
+    try:
+        with caplog.at_level(logging.WARNING, logger="root.tracker"):
+            caplog.clear()
+            eb = Extractor(bad)
+            assert eb.precision == "f32"
+            got = eb(crops)
+            got2 = eb(crops)
+        lines = [r for r in caplog.records if "fp32-class" in r.getMessage()]
+        assert len(lines) == 1 and "b31.conv2.w" in lines[0].getMessage()
+        assert np.array_equal(got, Extractor(bad, precision="f32")(crops)) and np.array_equal(got, got2)
+        # (2) an activation outside f16's range: the fault word at the first call -> cleared, exact fp32, same call answered
+        hot = dict(sd)
+        hot["bn0.weight"] = np.asarray(sd["bn0.weight"]) * 1e7
+        with caplog.at_level(logging.WARNING, logger="root.tracker"):
+            caplog.clear()
+            m = models.build_model("seres18_ibn", 751, loss="triplet", pretrained=False)
+            m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in hot.items()}, strict=True)
+            assert m.precision == "f16x3"
+            out = m.embed_crops(crops)
+            assert m.precision == "f32" and np.isfinite(out).all()
+            out2 = m.embed_crops(crops)
+        assert len([r for r in caplog.records if "fp32-class" in r.getMessage()]) == 1
+        assert np.array_equal(out, out2) and np.array_equal(out, Extractor(hot, precision="f32")(crops))
+        eng.sync()                                # no fault left pending
+    finally:
+        eng.clear_fault()
+        eng.set_precision(0)
+        eng.load_seres18(*weights.pack_seres18(sd)[:2])
 
 
 def test_swin_cuda_tensor_entry(eng):
@@ -1369,15 +1478,15 @@ def test_sibling_backbones_match_reference_fixture(eng, golden_dir, tag, name, s
     3x3 convolutions in fp32-class arithmetic on the f16 matrix pipe, same thresholds."""
     eng.set_precision(precision)
     try:
-        _sibling_check(eng, golden_dir, tag, name, sd_fn)
+        _sibling_check(eng, golden_dir, tag, name, sd_fn, precision)
     finally:
         eng.set_precision(0)
 
 
-def _sibling_check(eng, golden_dir, tag, name, sd_fn):
+def _sibling_check(eng, golden_dir, tag, name, sd_fn, precision):
     from reid_amd.models import build_model
     g = np.load(os.path.join(golden_dir, "siblings.npz"))
-    model = build_model(name, num_classes=751, loss="triplet", pretrained=False, use_gpu=True)
+    model = build_model(name, num_classes=751, loss="triplet", pretrained=False, use_gpu=True, precision=precision)
     assert list(model.state_dict().keys()) == list(sd_fn(0).keys())       # the reference's own key layout (positional in downsample blocks)
     model.load_state_dict(sd_fn(0), strict=True)
     x = seres18.preprocess_u8(synth.smooth_crops_u8(3, 7)).numpy()
@@ -1485,7 +1594,7 @@ def test_camera_bias_and_view_embedding_match_reference_fixture(eng, golden_dir,
             eng.embed_u8(crops)
         np.testing.assert_array_equal(eng.embed_u8(crops), plain)      # nothing left pending after the errors
         eng.set_chunk(1024)
-        m = models.build_model("seres18_ibn", num_classes=751, loss="triplet", pretrained=False).eval()
+        m = models.build_model("seres18_ibn", num_classes=751, loss="triplet", pretrained=False, precision=precision).eval()
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         out, lg = m(seres18.preprocess_u8(crops), cam=torch.from_numpy(g["cam"]), return_logits=True)
         assert np.abs(out.numpy() - g["emb"]).max() / np.abs(g["emb"]).max() < tol
@@ -1501,7 +1610,7 @@ def test_camera_bias_and_view_embedding_match_reference_fixture(eng, golden_dir,
         cos = (semb * g["swin_emb"]).sum(1) / np.linalg.norm(semb, axis=1) / np.linalg.norm(g["swin_emb"], axis=1)
         assert (1 - cos).max() < ctol
         from reid_amd import backbone
-        sm = backbone.swin_t(num_classes=751, loss="triplet", pretrained=False, camera=4).eval()   # swin_t(**kwargs), swin_transformer.py:508-510
+        sm = backbone.swin_t(num_classes=751, loss="triplet", pretrained=False, camera=4, precision=precision).eval()   # swin_t(**kwargs), swin_transformer.py:508-510
         sm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ssd.items()}, strict=True)
         e2 = sm(torch.from_numpy(img), view_index=torch.from_numpy(g["view"]))
         assert np.abs(e2.numpy() - g["swin_emb"]).max() / np.abs(g["swin_emb"]).max() < (2e-4 if precision != 1 else 2e-2)
@@ -1559,6 +1668,42 @@ def test_full_size_config2_swin_properties(eng, precision):
         cos = (emb[sample] * want).sum(1) / np.linalg.norm(emb[sample], axis=1) / np.linalg.norm(want, axis=1)
         assert (1 - cos).max() < (1e-4 if precision == 1 else 1e-5)
         assert np.abs(emb[sample] - want).max() / np.abs(want).max() < (1e-2 if precision == 1 else 2e-4)
+    finally:
+        eng.set_chunk(128)
+        eng.set_precision(0)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", [0, 2])
+def test_swin_at_the_bench_pass_size(eng, precision):
+    """bench.py times Swin in ONE pass of 1024 images per reid_swin_embed_* pass (run_swin: set_chunk(min(chunk, 1024)); 13 GB of
+    activations, csrc/swin.hip reid_swin_embed_f32_nchw_dev) - the size nothing else exercises.  1024 images = 64 distinct x 16,
+    shuffled, in exact fp32 and in the bench's fp32-class arithmetic: (a) copies bit-identical, (b) bit-equal to the same batch
+    in four passes of 256 (images are independent: swin_transformer.py:191-232 attends inside a window of ONE image, LayerNorm
+    is per token, :248-260), (c) six rows against oracle/swin.py at the thresholds of the 256-pass full-size test."""
+    from oracle import swin
+    sd = synth.swin_state_dict(0)
+    eng.load_swin(*weights.pack_swin(sd)[:2])
+    rng = np.random.default_rng(21)
+    base = synth.images_f32(64, 7)
+    ids = np.repeat(np.arange(64), 16)
+    rng.shuffle(ids)
+    x = base[ids]                                                        # 617 MB of host memory
+    eng.set_precision(precision)
+    try:
+        eng.set_chunk(1024)
+        emb = eng.swin_embed_f32_nchw(x)
+        eng.set_chunk(256)
+        emb256 = eng.swin_embed_f32_nchw(x)
+        first = np.asarray([np.flatnonzero(ids == c)[0] for c in range(64)])
+        assert emb.shape == (1024, 96) and np.isfinite(emb).all()
+        assert np.array_equal(emb, emb[first][ids])                     # (a)
+        assert np.array_equal(emb, emb256)                              # (b)
+        sample = first[:6]
+        want = swin.embed(sd, base[ids[sample]])                        # (c)
+        cos = (emb[sample] * want).sum(1) / np.linalg.norm(emb[sample], axis=1) / np.linalg.norm(want, axis=1)
+        assert (1 - cos).max() < 1e-5
+        assert np.abs(emb[sample] - want).max() / np.abs(want).max() < 2e-4
     finally:
         eng.set_chunk(128)
         eng.set_precision(0)
