@@ -9,6 +9,12 @@
 extern "C" {
 #endif
 
+/* Experiment switches of a context, by the name of the reid_ctx field (csrc/reid_internal.h: f16_cfg, split_pair, split_terms,
+ * swin_two_linear, swin_attn_mfma, swin_attn_split, swin_fold, swin_stop, knn_wide, knn_wide_min, select_two_pass, f32_conv, ...).
+ * They select kernels, arithmetic forms and summation orders; the product library gives them fixed defaults and reads none of them
+ * from the environment.  The setter drains the context's stream first.  Unknown name / value: REID_ERR_ARG. */
+int reid_debug_set_switch(reid_ctx* ctx, const char* name, long long value);
+int reid_debug_get_switch(reid_ctx* ctx, const char* name, long long* value);
 /* Times `iters` launches of one fp16-storage implicit-GEMM convolution (SERes18_IBN.py:120-128 shapes) on random device
  * data; cfg = BN*1000 + BK*10 + NST, 2000000 / 2000001 = LDS-halo kernel without / with loader waves. */
 int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int cfg, int iters,

@@ -36,39 +36,16 @@ extern "C" int reid_ctx_create(int device, reid_ctx** out) {
     DeviceGuard _dev_guard(device);   // streams / events below are created on `device`; the caller's current device is restored
     reid_ctx* c = new reid_ctx();
     c->device = device;
-    if (const char* e = getenv("REID_F16_CFG")) c->f16_cfg = atoi(e);
-    if (const char* e = getenv("REID_F16_LIN_256")) c->f16_lin_256 = atoi(e);
+    // The product library reads exactly two environment variables, both SIZING knobs whose results are bit-identical by test
+    // (tests/test_host_logic.py::test_product_library_reads_only_the_whitelisted_environment): the Swin pass cap and the pair count
+    // from which k-NN takes the wide path.  Every switch that selects a kernel, an arithmetic form or a summation order is a field
+    // of the context with a fixed default; experiments flip them through libreid_hip_debug.so (reid_debug_set_switch), never
+    // through a tracker's environment.
     if (const char* e = getenv("REID_SWIN_CHUNK_MAX")) {
         const int v = atoi(e);
         if (v > 0 && v < c->swin_chunk_cap) c->swin_chunk_cap = v;
     }
-    if (const char* e = getenv("REID_F16_SPLITK")) c->f16_split_k = atoi(e);
-    if (const char* e = getenv("REID_BANK_FAST")) c->bank_fast = atoi(e);
-    if (const char* e = getenv("REID_SIDE_COPY")) c->side_copy = atoi(e);
-    if (const char* e = getenv("REID_F32_STEMPOOL")) c->f32_stem_pool = atoi(e);
-    if (const char* e = getenv("REID_STEM_SPLIT")) c->stem_split = atoi(e);
-    if (const char* e = getenv("REID_SPLIT_PAIR")) c->split_pair = atoi(e);
-    if (const char* e = getenv("REID_SPLIT_LEAN")) c->split_lean_epi = atoi(e);
-    if (const char* e = getenv("REID_KNN_WIDE")) c->knn_wide = atoi(e);
     if (const char* e = getenv("REID_KNN_WIDE_MIN")) c->knn_wide_min = atoll(e);
-    if (const char* e = getenv("REID_F16_LOADER_PRIO")) c->f16_loader_prio = atoi(e);
-    if (const char* e = getenv("REID_F16_FRAG_AHEAD")) c->f16_frag_ahead = atoi(e);
-    if (const char* e = getenv("REID_PACK_EPILOGUE")) c->pack_epilogue = atoi(e);
-    if (const char* e = getenv("REID_F16_WIDE_SPLITK")) c->f16_wide_splitk = atoi(e);
-    if (const char* e = getenv("REID_F32_SPLITK")) c->f32_split_k = atoi(e);
-    if (const char* e = getenv("REID_SWIN_FOLD")) c->swin_fold = atoi(e);
-    if (const char* e = getenv("REID_SWIN_STOP")) c->swin_stop = atoi(e);
-    if (const char* e = getenv("REID_SELECT_TWO_PASS")) c->select_two_pass = atoi(e);
-    if (const char* e = getenv("REID_SPLIT_TERMS")) c->split_terms = atoi(e) == 4 ? 4 : 3;
-    if (const char* e = getenv("REID_F32_CONV")) c->f32_conv = atoi(e);
-    if (const char* e = getenv("REID_SWIN_ATTN")) c->swin_attn_mfma = atoi(e);
-    if (const char* e = getenv("REID_SWIN_ATTN_SPLIT")) c->swin_attn_split = atoi(e);
-    if (const char* e = getenv("REID_SWIN_TWO_LINEAR")) c->swin_two_linear = atoi(e);
-    if (const char* e = getenv("REID_F16_LOADERS")) c->f16_loader_waves = atoi(e) != 0;
-    if (const char* e = getenv("REID_F16_HALO")) c->f16_halo = atoi(e);   // 0 off, 1 heuristic, 2 always
-    if (const char* e = getenv("REID_F16_STEMPOOL")) c->f16_stem_fused = atoi(e);   // 0 GEMM + pool, 1 fused, 2 fused reading uint8 crops
-    if (const char* e = getenv("REID_F16_SETAIL")) c->f16_se_tail = atoi(e) != 0;
-    if (const char* e = getenv("REID_F16_C64")) c->f16_c64 = atoi(e);   // 0 implicit GEMM, 1 layer-1 kernel, 2 + fused SE tail
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipHostMalloc((void**)&c->fault, 64, hipHostMallocMapped));   // the fault word kernels raise (reid_internal.h)

@@ -5,6 +5,59 @@
 #include <stdlib.h>
 #include <vector>
 
+// ------------------------------------------------------------------------------------------------ experiment switches
+// Every kernel-selection / arithmetic-form / summation-order switch of a context, by the name of its reid_ctx field.  Until round 5
+// these were environment variables read by reid_ctx_create in the PRODUCT library (a stray REID_* in a tracker's environment
+// silently changed embeddings); now the product library has fixed defaults and only this library can move them.
+namespace {
+struct Switch { const char* name; int reid_ctx::* field; };
+const Switch kSwitches[] = {
+    {"f16_cfg", &reid_ctx::f16_cfg}, {"f16_lin_256", &reid_ctx::f16_lin_256}, {"f16_split_k", &reid_ctx::f16_split_k},
+    {"bank_fast", &reid_ctx::bank_fast}, {"side_copy", &reid_ctx::side_copy}, {"f32_stem_pool", &reid_ctx::f32_stem_pool},
+    {"stem_split", &reid_ctx::stem_split}, {"split_pair", &reid_ctx::split_pair}, {"split_lean_epi", &reid_ctx::split_lean_epi},
+    {"knn_wide", &reid_ctx::knn_wide}, {"f16_loader_prio", &reid_ctx::f16_loader_prio}, {"f16_frag_ahead", &reid_ctx::f16_frag_ahead},
+    {"pack_epilogue", &reid_ctx::pack_epilogue}, {"f16_wide_splitk", &reid_ctx::f16_wide_splitk}, {"f32_split_k", &reid_ctx::f32_split_k},
+    {"swin_fold", &reid_ctx::swin_fold}, {"swin_stop", &reid_ctx::swin_stop}, {"select_two_pass", &reid_ctx::select_two_pass},
+    {"split_terms", &reid_ctx::split_terms}, {"f32_conv", &reid_ctx::f32_conv}, {"swin_attn_mfma", &reid_ctx::swin_attn_mfma},
+    {"swin_attn_split", &reid_ctx::swin_attn_split}, {"swin_two_linear", &reid_ctx::swin_two_linear},
+    {"f16_loader_waves", &reid_ctx::f16_loader_waves}, {"f16_halo", &reid_ctx::f16_halo}, {"f16_stem_fused", &reid_ctx::f16_stem_fused},
+    {"f16_se_tail", &reid_ctx::f16_se_tail}, {"f16_c64", &reid_ctx::f16_c64}, {"swin_chunk_cap", &reid_ctx::swin_chunk_cap},
+};
+}  // namespace
+
+extern "C" int reid_debug_set_switch(reid_ctx* ctx, const char* name, long long value) {
+    ARG_CHECK(ctx && name);
+    CTX_GUARD(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));       // nothing in flight may see the switch move
+    if (!strcmp(name, "knn_wide_min")) {
+        ctx->knn_wide_min = value;
+        return REID_OK;
+    }
+    for (const Switch& s : kSwitches)
+        if (!strcmp(name, s.name)) {
+            if (!strcmp(name, "split_terms") && value != 3 && value != 4) break;
+            ctx->*(s.field) = (int)value;
+            return REID_OK;
+        }
+    reid_set_error("reid_debug_set_switch: no switch '%s' (or a value it does not take)", name);
+    return REID_ERR_ARG;
+}
+
+extern "C" int reid_debug_get_switch(reid_ctx* ctx, const char* name, long long* value) {
+    ARG_CHECK(ctx && name && value);
+    if (!strcmp(name, "knn_wide_min")) {
+        *value = ctx->knn_wide_min;
+        return REID_OK;
+    }
+    for (const Switch& s : kSwitches)
+        if (!strcmp(name, s.name)) {
+            *value = ctx->*(s.field);
+            return REID_OK;
+        }
+    reid_set_error("reid_debug_get_switch: no switch '%s'", name);
+    return REID_ERR_ARG;
+}
+
 // ------------------------------------------------------------------------------------------------ kernel experiments
 // Times `iters` launches of one fp16 implicit-GEMM convolution on random device data (not part of the public header).
 extern "C" int reid_debug_conv_f16(reid_ctx* ctx, int n, int h, int w, int cin, int cout, int r, int stride, int pad, int cfg,

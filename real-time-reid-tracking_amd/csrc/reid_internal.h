@@ -344,6 +344,9 @@ struct reid_ctx {
     std::map<std::string, std::pair<void*, size_t>> ws;
     std::map<std::string, std::pair<void*, size_t>> pinned;   // pinned host staging buffers (ctx_pinned)
     std::map<const void*, void*> split_w;   // precision 2: conv weights (fp32, in the blob) -> their [wh * 2^11 | wh | wl'] f16 form
+    // Switches below: fixed defaults in the product library.  The REID_* names in their comments are the environment variables that
+    // set them until round 4; since round 5 the product library reads none of them (api.hip, reid_ctx_create) and experiments move a
+    // field by its NAME through libreid_hip_debug.so: reid_debug_set_switch(ctx, "split_pair", 1) (debug.hip, kSwitches).
     int bank_fast = 1;                    // d = 512 feature-bank cost on the register-tiled kernel (REID_BANK_FAST=0: generic kernel)
     Se18Weights se18;
     int last_n = 0;  // crops in the last embed chunk (for reid_debug_stage)

@@ -340,6 +340,25 @@ class Engine:
         check(self.lib.reid_embed_u8_dev(self.h, C.c_void_p(d_crops), int(n), C.c_void_p(d_emb),
                                          C.c_void_p(d_logits or 0)))
 
+    def debug_switch(self, name, value=None):
+        """Experiment switch of this context through libreid_hip_debug.so (include/reid_hip_debug.h: reid_debug_set_switch); with
+        ``value`` None returns the current value.  The product library itself takes no such switch from the environment."""
+        dbg = _ffi.debug_lib()
+        if value is None:
+            v = C.c_longlong()
+            check(dbg.reid_debug_get_switch(self.h, name.encode(), C.byref(v)))
+            return v.value
+        check(dbg.reid_debug_set_switch(self.h, name.encode(), C.c_longlong(int(value))))
+
+    def debug_switches_from_env(self):
+        """A/B tools: REID_DEBUG_SWITCHES="name=value,name=value" -> debug_switch calls (read by the TOOL, in Python)."""
+        import os
+        spec = os.environ.get("REID_DEBUG_SWITCHES", "")
+        for item in filter(None, (t.strip() for t in spec.split(","))):
+            name, _, val = item.partition("=")
+            self.debug_switch(name.strip(), int(val))
+        return spec
+
     def debug_keep(self, on):
         check(self.lib.reid_ctx_set_debug_keep(self.h, int(on)))
 

@@ -914,7 +914,8 @@ def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, c
     SERse18_IBN + cosine_dist produced (tests/golden/config1.npz, oracle/gen_golden.py:gen_config1).  The arg-min vector is
     compared on ALL 256 rows: the number of differing rows is printed and every one of them must be a row whose top-2 gap in the
     reference is inside the arithmetic's own noise (north_star: "argmin ranks bit-exact" - a rank can only be decided where the
-    reference itself separates the two candidates by more than one rounding of the distance)."""
+    reference itself separates the two candidates by more than one rounding of the distance); on the realistic set no row may
+    differ at all in the exact-fp32 and the fp32-class mode."""
     eng, _ = eng_w0
     g = np.load(os.path.join(golden_dir, "config1.npz"))
     ref, gap = g[tag + "_emb"], g[tag + "_gap"]
@@ -941,9 +942,17 @@ def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, c
     if tag == "smooth5":
         assert decided >= (150 if f16s else 250)                          # realistic crops: (nearly) every row is decided
     if not f16s:
-        # the bar for a headline arithmetic (round-2 verdict): the exact-fp32 and the fp32-class mode reproduce the reference's
-        # arg-min on ALL 256 rows of BOTH sets (the kernels are deterministic, so this holds on every MI355X)
-        assert len(flips) == 0, (flips, gap[flips])
+        # the bar for a headline arithmetic (restated in round 5 - round-4 verdict, SURVEY.md Q15 / section 7 "hard parts"): no flip
+        # where the reference separates the two candidates by more than the arithmetic's noise (asserted above, both sets), and
+        # none at ALL on the realistic set (smooth5: smallest reference gap 6.5e-6).  The noise set (rand0) has one row whose
+        # reference top-2 gap is 2.7e-7 - the size of the reference's OWN batch-size instability (2.4e-7): whether a
+        # kernel agrees there is a property of its summation order, not of its parity, so such rows are printed, not failed
+        # (rounds 2-4 asserted 0 of 256 on both sets, which vetoed every kernel that sums in another order on a coin flip).
+        if tag == "smooth5":
+            assert len(flips) == 0, (flips, gap[flips])
+        elif len(flips):
+            print("config1 rand0 precision %d chunk %d: sub-noise rows that differ (row, reference gap): %s"
+                  % (precision, chunk, [(int(r), float(gap[r])) for r in flips]))
 
 
 @pytest.mark.parametrize("tag,sigma", [("s03", 0.3), ("s30", 3.0)])
@@ -1443,30 +1452,38 @@ def test_swin_stage_taps_match_reference_fixture(eng, golden_dir, precision, tol
 
 def test_swin_window_attention_mfma_equals_valu_kernel(eng):
     """The matrix-core window attention (S^T = K.Q^T, softmax in the accumulator layout, P.V with the accumulator tile as the
-    MFMA operand) against round 1's one-lane-per-query VALU kernel (REID_SWIN_ATTN=0), both arithmetic modes, on 448x224 so that
-    shifted blocks see inner windows as well as the masked last row / column."""
-    import subprocess, sys, json as _json
-    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from reid_amd import synth, weights; from reid_amd.engine import get_engine;"
-            "eng = get_engine(0); eng.load_swin(*weights.pack_swin(synth.swin_state_dict(0))[:2]); x = synth.images_f32(3, 9, h=448, w=224);"
-            "a = eng.swin_embed_f32_nchw(x); eng.set_precision(1); b = eng.swin_embed_f32_nchw(x); print(json.dumps([a.tolist(), b.tolist()]))"
-            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    res = {}
-    for mode in ("0", "2"):                 # 0 = VALU kernel in both modes, 2 = matrix-core kernel in both
-        env = dict(os.environ, REID_SWIN_ATTN=mode)
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
-        res[mode] = [np.asarray(v, np.float32) for v in _json.loads(out.strip().splitlines()[-1])]
-    for i, tol in ((0, 2e-5), (1, 2e-3)):
-        a, b = res["0"][i], res["2"][i]
-        assert np.abs(a - b).max() <= tol * np.abs(a).max(), (i, np.abs(a - b).max(), np.abs(a).max())
-    # fp32-class mode: the split-operand matrix-core kernel (opt-in, REID_SWIN_ATTN_SPLIT=1: measured 5 % slower end to end than the
-    # exact-fp32 VALU kernel it would replace) gives that kernel's result at the mode's own error level
-    code2 = code.replace("eng.set_precision(1)", "eng.set_precision(2)")
-    r2 = {}
-    for flag in ("0", "1"):
-        out = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, REID_SWIN_ATTN_SPLIT=flag), capture_output=True, text=True,
-                             check=True).stdout
-        r2[flag] = np.asarray(_json.loads(out.strip().splitlines()[-1])[1], np.float32)
-    assert np.abs(r2["0"] - r2["1"]).max() <= 4e-6 * np.abs(r2["0"]).max(), np.abs(r2["0"] - r2["1"]).max() / np.abs(r2["0"]).max()
+    MFMA operand) against round 1's one-lane-per-query VALU kernel (debug switch swin_attn_mfma = 0), both arithmetic modes, on
+    448x224 so that shifted blocks see inner windows as well as the masked last row / column.  The switches are fields of the
+    context that only libreid_hip_debug.so can move (reid_debug_set_switch); the product library reads none of them from the
+    environment."""
+    eng.load_swin(*weights.pack_swin(synth.swin_state_dict(0))[:2])
+    x = synth.images_f32(3, 9, h=448, w=224)
+
+    def run(mode, **switches):
+        for k, v in switches.items():
+            eng.debug_switch(k, v)
+        eng.set_precision(mode)
+        try:
+            return eng.swin_embed_f32_nchw(x)
+        finally:
+            eng.set_precision(0)
+
+    try:
+        res = {m: (run(0, swin_attn_mfma=m), run(1, swin_attn_mfma=m)) for m in (0, 2)}   # 0 = VALU kernel in both modes, 2 = matrix cores in both
+        for i, tol in ((0, 2e-5), (1, 2e-3)):
+            a, b = res[0][i], res[2][i]
+            assert np.abs(a - b).max() <= tol * np.abs(a).max(), (i, np.abs(a - b).max(), np.abs(a).max())
+        eng.debug_switch("swin_attn_mfma", 1)
+        # fp32-class mode: the split-operand matrix-core kernel (opt-in switch swin_attn_split: measured 5 % slower end to end than the
+        # exact-fp32 VALU kernel it would replace) gives that kernel's result at the mode's own error level
+        r0, r1 = run(2, swin_attn_split=0), run(2, swin_attn_split=1)
+        assert not np.array_equal(r0, r1)                                   # the switch did select the other kernel
+        assert np.abs(r0 - r1).max() <= 4e-6 * np.abs(r0).max(), np.abs(r0 - r1).max() / np.abs(r0).max()
+    finally:
+        eng.debug_switch("swin_attn_mfma", 1)
+        eng.debug_switch("swin_attn_split", 0)
+        with pytest.raises(_ffi.ReidHipError):
+            eng.debug_switch("no_such_switch", 1)
 
 
 # ----------------------------------------------------------------------------- sibling backbones (SURVEY.md 8(f)-4)
@@ -2103,11 +2120,12 @@ def test_fused_pair_of_linears_matches_float64_and_is_position_invariant(eng_w0,
 
 
 @pytest.mark.gpu
-def test_swin_embeddings_do_not_depend_on_the_pass_size():
-    """reid_swin_embed_* walks a batch in passes of up to 1024 images (swin.hip); REID_SWIN_CHUNK_MAX lowers the cap.  Images are
-    independent in eval mode (swin_transformer.py:248-260), so 12 images embedded in passes of 2, 5 and 12 must agree bit for bit, in
-    the exact and in the fp32-class mode (whose stage 1-2 launches are the fused kernels of two_linear_f16.hip in every one of these
-    passes, and plain gemm_f16 launches when REID_SWIN_TWO_LINEAR=0 - which must agree with them at the mode's error level)."""
+def test_swin_embeddings_do_not_depend_on_the_pass_size(eng):
+    """reid_swin_embed_* walks a batch in passes of up to 1024 images (swin.hip); REID_SWIN_CHUNK_MAX - one of the two environment
+    variables the product library reads, both sizing knobs - lowers the cap.  Images are independent in eval mode
+    (swin_transformer.py:248-260), so 12 images embedded in passes of 2, 5 and 12 must agree bit for bit, in the exact and in the
+    fp32-class mode (whose stage 1-2 launches are the fused kernels of two_linear_f16.hip in every one of these passes, and plain
+    gemm_f16 launches with the debug switch swin_two_linear = 0 - which must agree with them at the mode's error level)."""
     import subprocess, sys, json as _json
     code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from reid_amd import synth, weights; from reid_amd.engine import get_engine;"
             "eng = get_engine(0); eng.load_swin(*weights.pack_swin(synth.swin_state_dict(0))[:2]); eng.set_chunk(4096); x = synth.images_f32(12, 4);"
@@ -2122,7 +2140,20 @@ def test_swin_embeddings_do_not_depend_on_the_pass_size():
     for cap in ("2", "5"):
         got = run(REID_SWIN_CHUNK_MAX=cap)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), cap
-    unfused = run(REID_SWIN_CHUNK_MAX="12", REID_SWIN_TWO_LINEAR="0")
-    assert np.array_equal(unfused[0], ref[0])                                  # the exact mode has no fused launches
-    assert np.abs(unfused[1] - ref[1]).max() <= 2e-6 * np.abs(ref[1]).max()   # same roundings, another summation order
+    # the same through reid_ctx_set_chunk in this process, and with the fused stage 1-2 launches switched off
+    eng.load_swin(*weights.pack_swin(synth.swin_state_dict(0))[:2])
+    x = synth.images_f32(12, 4)
+    try:
+        eng.set_chunk(5)
+        assert np.array_equal(eng.swin_embed_f32_nchw(x), ref[0])
+        eng.set_precision(2)
+        assert np.array_equal(eng.swin_embed_f32_nchw(x), ref[1])
+        eng.debug_switch("swin_two_linear", 0)
+        unfused = eng.swin_embed_f32_nchw(x)
+        assert not np.array_equal(unfused, ref[1])                             # the switch did select the other launches
+        assert np.abs(unfused - ref[1]).max() <= 2e-6 * np.abs(ref[1]).max()   # same roundings, another summation order
+    finally:
+        eng.debug_switch("swin_two_linear", 1)
+        eng.set_precision(0)
+        eng.set_chunk(1024)
     assert np.abs(ref[1] - ref[0]).max() <= 2e-6 * np.abs(ref[0]).max()       # fp32-class against exact fp32

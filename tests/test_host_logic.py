@@ -43,6 +43,33 @@ def test_debug_library_matches_its_header(built_lib):
     assert declared == set(_ffi.DEBUG_EXPORTS)
 
 
+def test_product_library_reads_only_the_whitelisted_environment(built_lib):
+    """libreid_hip.so takes TWO environment variables, both sizing knobs whose results are bit-identical by test
+    (REID_SWIN_CHUNK_MAX: test_swin_embeddings_do_not_depend_on_the_pass_size; REID_KNN_WIDE_MIN:
+    test_wide_knn_equals_the_fused_fp32_search_bit_for_bit); REID_CHUNK / REID_PRECISION are read by the Python host side
+    (bench.py, precision.py) and passed through the C ABI.  Every switch that selects a kernel, an arithmetic form or a summation
+    order is a context field that only libreid_hip_debug.so can move - a stray REID_* variable in a tracker's environment cannot
+    change embeddings."""
+    import subprocess
+    allowed = {"REID_SWIN_CHUNK_MAX", "REID_KNN_WIDE_MIN"}
+    names = set(re.findall(r"^REID_[A-Z0-9_]+$", subprocess.run(["strings", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout,
+                           flags=re.M))
+    names -= {n for n in names if n.startswith(("REID_ERR_", "REID_OK", "REID_K_"))}
+    assert names == allowed, names ^ allowed
+    csrc = os.path.join(ROOT, "real-time-reid-tracking_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".h")) or fn in ("debug.hip", "microbench.hip"):
+            continue
+        for var in re.findall(r'getenv\(\s*"([^"]+)"', open(os.path.join(csrc, fn)).read()):
+            assert var in allowed, (fn, var)
+    # the host side: names it reads, all of them sizing / arithmetic-by-name / launch plumbing
+    host = set()
+    for fn in ["bench.py"] + [os.path.join("real-time-reid-tracking_amd", f) for f in os.listdir(os.path.join(ROOT, "real-time-reid-tracking_amd")) if f.endswith(".py")]:
+        host |= set(re.findall(r'environ(?:\.get|\.setdefault)?[\(\[]\s*"(REID_[A-Z0-9_]+)"', open(os.path.join(ROOT, fn)).read()))
+    assert host <= {"REID_CHUNK", "REID_PRECISION", "REID_HIP_LIB", "REID_BENCH_COMM1", "REID_BENCH_LIMIT_SCALE", "REID_ALLOW_LATE_TORCH",
+                    "REID_DEBUG_SWITCHES"}, host
+
+
 def test_no_gpu_means_loud_failure(built_lib):
     """The product path must fail loudly, not fall back, when it cannot run on the device."""
     import torch

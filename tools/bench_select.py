@@ -1,6 +1,6 @@
 """Fused distance + selection (dist_select.hip) against the two-pass form (distance matrix + topk_rows / argmin_rows) at the
 BASELINE sizes: Market-size search 3368 x 15913 x 512 (arg-min and top-20) and 4096 x 4096 x 512 (arg-min).
-python tools/bench_select.py            (REID_SELECT_TWO_PASS=1 python tools/bench_select.py  for the two-pass numbers)"""
+python tools/bench_select.py            (REID_DEBUG_SWITCHES=select_two_pass=1 python tools/bench_select.py  for the two-pass numbers)"""
 import json
 import os
 import sys
@@ -13,7 +13,8 @@ from reid_amd import _ffi, parallel, synth
 from reid_amd.engine import get_engine
 
 eng = get_engine(0)
-out = {"two_pass": os.environ.get("REID_SELECT_TWO_PASS", "0")}
+eng.debug_switches_from_env()
+out = {"two_pass": eng.debug_switch("select_two_pass")}
 for tag, m, n, k in (("market_top20", 3368, 15913, 20), ("market_argmin", 3368, 15913, 1), ("sq4096_argmin", 4096, 4096, 1),
                      ("gallery_self_top20", 15913, 15913, 20)):
     qf, _, _, gf, _, _ = synth.clustered_embeddings(m, n, d=512, n_ids=751, n_cams=6, seed=4, sigma=3.0)

@@ -1,12 +1,13 @@
 """Swin fp16-storage mode: is an image's embedding independent of the batch it comes in, and are repeated runs identical?
 (The 64- and 128-wide instantiations of a linear round their epilogues differently: the tile shape must not depend on the batch.)
-    python tools/swin_batch_check.py            REID_F16_CFG=128323 forces one tile shape"""
+    python tools/swin_batch_check.py            REID_DEBUG_SWITCHES=f16_cfg=128323 forces one tile shape"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reid_amd import synth, weights
 from reid_amd.engine import get_engine
 eng = get_engine(0)
+eng.debug_switches_from_env()
 sd = synth.swin_state_dict(0) if hasattr(synth, "swin_state_dict") else None
 from reid_amd import weights as W
 blob, manifest = W.pack_swin(sd)[:2]

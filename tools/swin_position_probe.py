@@ -1,5 +1,5 @@
 """Where does an image's Swin result start to depend on its POSITION in the pass?  Copies of three images are spread over a pass;
-REID_SWIN_STOP freezes the forward after a phase of a block (block * 10 + phase: 0 = attention branch done, 2 = LayerNorm 2 written,
+the debug switch swin_stop freezes the forward after a phase of a block (block * 10 + phase: 0 = attention branch done, 2 = LayerNorm 2 written,
 3 = fc1 + GELU written, 5 = whole block) and the scratch buffers are compared between copies, element by element.  Prints the first
 phase whose buffer differs, with the differing elements' (token, column), their tile row (token index mod 256) and both values.
     python tools/swin_position_probe.py [precision] [n_images] [blocks]"""
@@ -26,8 +26,8 @@ STAGE_OF_BLOCK = [0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3]
 
 
 def run(stop, stage):
-    os.environ["REID_SWIN_STOP"] = str(stop)
     eng = Engine(0)
+    eng.debug_switch("swin_stop", stop)
     eng.load_swin(blob, manifest)
     eng.set_precision(prec)
     eng.set_chunk(256)
