@@ -1,0 +1,658 @@
+// fp32-class 3x3 / stride-1 / pad-1 convolution on the f16 matrix pipe, second form (round 5): TWO independent blocks per CU.
+//
+// conv3x3_f16.hip's SPLIT build is one 12-wave block per CU (138 KB of LDS): eight MFMA waves and four loader waves in ONE barrier
+// domain.  Stamps of that kernel at 1024 crops (tools/diag_conv_f16.py, layer 4): per (chunk, tap) tile a compute wave spends 1 350
+// cycles in fragment reads + MFMAs (1 024 of matrix pipe per SIMD: after every barrier all eight waves compute addresses, read
+// their first fragments and wait for them TOGETHER, ~300 cycles in which the pipe is idle) and 410-450 cycles at the barrier
+// (waiting for the loaders): 1 760 cycles per 1 024 of pipe, and nothing else on the CU to fill the holes.
+// Here a block is FOUR waves (256 x BN tile, a wave owns 64 rows x BN columns: 128 accumulator registers at BN = 128) with
+// 32-channel chunks (halo 2 x 23 KB + four 8-KB weight slots = 78 KB), so two blocks share a CU and each one's barrier waits,
+// fragment-read latencies, prologue and epilogue lie under the other's MFMAs.  No loader waves: a wave issues its share of the
+// tile three steps ahead (2 weight pieces + at most one halo piece per tile) right after the barrier, counted vmcnt.
+//
+// Arithmetic: x.w = xh.wh + (xl'.wh + xh.wl') 2^-11 as ONE fp32 accumulation over the weight parts [wh 2^11 | wh | wl']
+// (Gemm16Params), per real 32-channel chunk c in the order  xh_c.(wh 2^11), xh_c.wl'  (halo buffer 0, 18 tiles),  xl'_c.wh  (halo
+// buffer 1, 9 tiles): the xh halo is loaded once for its two products (conv3x3_f16.hip walks the 3 C virtual channels and loads it
+// twice).  Another summation order than that kernel's, the same three products and roundings.
+// Reference shapes: reid/backbones/SERes18_IBN.py:120-128 (BasicBlock convs), :250-276.
+#include "reid_internal.h"
+#include "conv3x3_geom.h"
+#include <type_traits>
+
+typedef _Float16 f16;
+typedef f16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(uintptr_t)(p))
+#define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait2(half8& x, half8& y) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void lgkm_wait1(half8& x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N)); }
+
+__device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt takes an immediate
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int TW, int IMGS, int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const Gemm16Params p) {
+    constexpr int TH = 256 / (IMGS * TW);            // tile rows per image
+    constexpr int WP = TW + 2, HP = TH + 2;          // halo pitch / rows
+    constexpr int NPX = IMGS * HP * WP;              // halo pixels per block
+    constexpr int NPI = (NPX + 15) / 16;             // halo pieces: 16 pixels x 64 B (32 channels)
+    static_assert(NPI <= 24, "one halo piece per wave and tile over six tiles");
+    constexpr int HALO_BYTES = NPI * 1024;
+    constexpr int B_BYTES = BN * 64;                 // weight tile [BN][32]
+    constexpr int BJ = BN / 64;                      // weight pieces per wave per tile
+    constexpr int TM = 2, TN = BN / 32;              // wave tile 64 rows x BN columns
+    constexpr int NSLOT = 4;
+    static_assert(2 * (2 * HALO_BYTES + NSLOT * B_BYTES) <= 160 * 1024, "two blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + NSLOT * B_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nnt = p.N / BN;
+    int mtile, ntile;
+    {   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD): the N tiles of one M tile (same halo) sit on one XCD
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        mtile = L / nnt;
+        ntile = L - mtile * nnt;
+    }
+    const int n_blk = ntile * BN;
+    const int tiles_per_img = p.H / TH;              // IMGS == 2 -> 1
+    const int img0 = IMGS == 2 ? mtile * 2 : mtile / tiles_per_img;
+    const int y0 = IMGS == 2 ? 0 : (mtile - img0 * tiles_per_img) * TH;
+    const int n_img = p.M / (p.H * p.W);
+    const int C = p.Cin / 3;                         // real channels; A = [xh | xl'] (2 C per pixel), weights [wh 2^11 | wh | wl'] per tap
+    const int a_cin = 2 * C;
+    const int ncr = C / 32;
+    const int nt = ncr * 27;
+
+    const unsigned halo32 = (unsigned)(uintptr_t)lds, ring32 = halo32 + 2 * HALO_BYTES;
+
+    // ---- halo pieces: piece q covers halo pixels 16 q .. +16 (lane / 4), 16-byte position lane % 4 (source-side XOR swizzle)
+    auto issue_halo_piece = [&](int q, int vchunk, int buf) {
+        const int hp = q * 16 + (lane >> 2);
+        const int im = hp / (HP * WP), rem = hp - im * (HP * WP);
+        const int hy = rem / WP, hx = rem - hy * WP;
+        const int gy = y0 - 1 + hy, gx = hx - 1, gi = img0 + im;
+        const bool ok = hp < NPX && gi < n_img && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const int cg = (lane & 3) ^ ((hp >> 2) & 3);
+        const f16* src = ok ? p.A + (((long long)gi * p.H + gy) * p.W + gx) * a_cin + vchunk * 32 + cg * 8 : p.zero_page;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(lds + buf * HALO_BYTES + q * 1024), 16, 0, 0);
+    };
+    // ---- weight pieces: piece (wm * BJ + j) = rows 16 .. of the tile, lane / 4 = row, lane % 4 = position
+    long long b_base[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (wm * BJ + j) * 16 + (lane >> 2);
+        const int cg = (lane & 3) ^ ((row >> 2) & 3);
+        b_base[j] = (long long)(n_blk + row) * p.ldb + cg * 8;
+    }
+    auto issue_w = [&](int c, int r, int slot) {     // tile (chunk c, step r): part 0 (wh 2^11) r < 9, part 2 (wl') r < 18, part 1 (wh) else
+        const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
+        const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+        const int k0 = tap * p.Cin + part * C + c * 32;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0), LPTR(lds + 2 * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, 0, 0);
+    };
+
+    // ---- A fragments: halo pixel of this lane's row in MFMA tile a at tap (0,0); B fragments: this lane's column
+    int hp0[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        int im, y, x;
+        row_to_pixel<TW, IMGS>(wm, a, li, im, y, x);
+        hp0[a] = im * HP * WP + y * WP + x;
+    }
+    unsigned bx[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) bx[kk] = ring32 + li * 64 + (((kk * 2 + lh) ^ ((li >> 2) & 3)) * 16);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // ---- prologue: xh of chunk 0 (every piece), weight tiles 0 .. 2
+    for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, 0, 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    issue_w(0, 2, 2);
+
+    int c = 0, r = 0, c3 = 0, r3 = 3, h1 = 0, h2 = 0;
+    for (int t = 0; t < nt; ++t) {
+        // in-order landing: everything but the pieces of the last two steps (tiles t + 1, t + 2 and their halo pieces) has landed,
+        // i.e. this wave's share of tile t and of every older halo piece
+        wait_vm(t + 2 >= nt ? 0 : 2 * BJ + h1 + h2);
+        RAW_BARRIER();              // ... and every wave's share; every wave has finished tile t - 1: its slot and halo buffer are free
+        if (t + 3 < nt) issue_w(c3, r3, (t + 3) & 3);
+        const int hh = (r < 6 || (r >= 18 && r < 24)) ? 1 : 0;
+        if (hh) {
+            // steps 0 .. 5: xl' of this chunk into buffer 1 (last read in step 26 of the previous chunk); steps 18 .. 23: xh of the next
+            // chunk into buffer 0 (last read in step 17; after the last chunk the same chunk again, read by nobody: every wave issues
+            // exactly one piece per such step, so that the counted waits stay uniform)
+            const int q = (r < 6 ? r : r - 18) * 4 + wm;
+            const int cn = c + 1 < ncr ? c + 1 : c;
+            issue_halo_piece(q < NPI ? q : NPI - 1, r < 6 ? ncr + c : cn, r < 6 ? 1 : 0);
+        }
+        {   // ---- tile (c, r): 2 k-steps of 16, 2 A + TN B fragments each, every read issued up front, waits counted per MFMA
+            const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+            const int ty = tap / 3, tx = tap - ty * 3;
+            const unsigned abuf = halo32 + (r >= 18 ? HALO_BYTES : 0);
+            const unsigned boff = (unsigned)((t & 3) * B_BYTES);
+            half8 fa[2][TM], fb[2][TN];
+            unsigned aa[TM][2];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int hp = hp0[a] + ty * WP + tx;
+                const unsigned base = abuf + hp * 64;
+                const int swz = (hp >> 2) & 3;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) aa[a][kk] = base + (((kk * 2 + lh) ^ swz) * 16);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                LDS_READ(fa[kk][0], aa[0][kk], 0);
+                const unsigned ba = bx[kk] + boff;
+                LDS_READ(fb[kk][0], ba, 0);
+                LDS_READ(fb[kk][1], ba, 2048);
+                if constexpr (TN == 4) {
+                    LDS_READ(fb[kk][2], ba, 4096);
+                    LDS_READ(fb[kk][3], ba, 6144);
+                }
+                LDS_READ(fa[kk][1], aa[1][kk], 0);
+            }
+            // Reads return in order: of a k-step's PER reads fragment A0 is read 0, B_b read 1 + b, A1 the last.  Every wait names the
+            // fragments it releases as in/out operands, so the MFMAs that consume them cannot be scheduled in front of it.
+            constexpr int PER = TM + TN;
+#define MM0(kk, b)                                                                                             \
+    do {                                                                                                       \
+        lgkm_wait2<((kk) == 0 ? 2 * PER : PER) - 2 - (b)>(fa[kk][0], fb[kk][b]);                               \
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][0], fb[kk][b], acc[0][b], 0, 0, 0);          \
+    } while (0)
+#define MM1(kk)                                                                                                \
+    do {                                                                                                       \
+        lgkm_wait1<((kk) == 0 ? PER : 0)>(fa[kk][1]);                                                          \
+        _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                         \
+            acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][1], fb[kk][b], acc[1][b], 0, 0, 0);      \
+    } while (0)
+            MM0(0, 0); MM0(0, 1);
+            if constexpr (TN == 4) { MM0(0, 2); MM0(0, 3); }
+            MM1(0);
+            MM0(1, 0); MM0(1, 1);
+            if constexpr (TN == 4) { MM0(1, 2); MM0(1, 3); }
+            MM1(1);
+#undef MM0
+#undef MM1
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        h2 = h1;
+        h1 = hh;
+        if (++r == 27) { r = 0; ++c; }
+        if (++r3 == 27) { r3 = 0; ++c3; }
+    }
+    __syncthreads();   // every wave is done with the last tile: LDS is free for the statistics
+
+    if (p.ablate & 32) return;    // experiment: no epilogue
+    // ------------------------------------------------------------------ fp32 epilogue, as conv3x3_f16.hip's SPLIT build (same
+    // arithmetic, operation for operation): BN scale (x 2^-11) and shift, fp32 residual, ReLU from column relu_from on, fp32 or
+    // [yh | yl'] stores, per-128-row column sums.  A wave owns 64 rows x BN columns here.
+    const int ldc = (int)p.ldc;
+    const int m_blk = mtile * 256;
+    const int m_valid = p.M - m_blk;
+    float s1[TN], s2[TN];
+    float vmax = 0.f;
+    const bool lean = (long long)256 * ldc * 4 < 0x7fffff00ll && (long long)256 * 2 * p.N * 2 < 0x7fffff00ll && (m_valid >= 256 || m_valid == 128);
+    if (lean) {
+        const bool wave_live = m_valid >= 256 || wm < 2;
+        const int lrow[2] = {c_row_lane<TW, IMGS>(lh, 0), c_row_lane<TW, IMGS>(lh, 1)};
+        const int col0 = n_blk + li;
+        const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C32 + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((p.res32 ? p.res32 : p.C32) + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t k_rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((p.pack16 ? p.pack16 : (f16*)p.C32) + (long long)m_blk * 2 * p.N), 0, 256 * 2 * p.N * 2, 0x00020000);
+        int voff[2], koff[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            voff[x] = (lrow[x] * ldc + col0) * 4;
+            koff[x] = (lrow[x] * 2 * p.N + col0) * 2;
+        }
+        auto run = [&](auto res_c) {
+            constexpr bool RES = decltype(res_c)::value;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = col0 + b * 32;
+                const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
+                const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+                const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+                const bool pk = p.pack16 && col >= p.pack_from;      // uniform per 32-column block
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    float rr[16];
+                    if constexpr (RES) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int x = ((e >> 2) == 1 || (e >> 2) == 2) ? 1 : 0;
+                            const int urow = c_row_uniform<TW, IMGS>(wm, a, e);
+                            rr[e] = wave_live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff[x] + b * 128, urow * ldc * 4, 0)) : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int x = ((e >> 2) == 1 || (e >> 2) == 2) ? 1 : 0;
+                        const int urow = c_row_uniform<TW, IMGS>(wm, a, e);
+                        float v = acc[a][b][e] * cs + sh;
+                        v += RES ? rr[e] : 0.f;
+                        v = fmaxf(v, lo);
+                        if (wave_live) {
+                            t1 += v;
+                            t2 += v * v;
+                            if (pk) {
+                                vmax = fmaxf(vmax, fabsf(v));
+                                const f16 hv = (f16)v;
+                                const f16 lv = (f16)((v - (float)hv) * 2048.0f);
+                                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), k_rs, koff[x] + b * 64, urow * 2 * p.N * 2, 0);
+                                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lv), k_rs, koff[x] + b * 64 + p.N * 2, urow * 2 * p.N * 2, 0);
+                            } else if (!(p.ablate & 64)) {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff[x] + b * 128, urow * ldc * 4, 0);
+                            }
+                        }
+                    }
+                }
+                s1[b] = t1;
+                s2[b] = t2;
+            }
+        };
+        if (p.res32) run(std::true_type{});
+        else run(std::false_type{});
+    } else {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n_blk + b * 32 + li;
+            const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
+            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+            const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+            const bool pk = p.pack16 && col >= p.pack_from;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = c_row_natural<TW, IMGS>(wm, a, e, lh);
+                    const int rc = row < m_valid ? row : 0;
+                    float v = acc[a][b][e] * cs + sh;
+                    v += p.res32 ? p.res32[(long long)(m_blk + rc) * ldc + col] : 0.f;
+                    v = fmaxf(v, lo);
+                    if (row < m_valid) {
+                        t1 += v;
+                        t2 += v * v;
+                        if (pk) {
+                            vmax = fmaxf(vmax, fabsf(v));
+                            const f16 hv = (f16)v;
+                            f16* dst = p.pack16 + (long long)(m_blk + row) * 2 * p.N + col;
+                            dst[0] = hv;
+                            dst[p.N] = (f16)((v - (float)hv) * 2048.0f);
+                        } else {
+                            p.C32[(long long)(m_blk + row) * ldc + col] = v;
+                        }
+                    }
+                }
+            }
+            s1[b] = t1;
+            s2[b] = t2;
+        }
+    }
+    if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;   // a packed activation f16 cannot hold: the context reports it
+    if (p.stats) {   // per 128 natural rows: waves 0,1 own rows 0..127, waves 2,3 rows 128..255 in every geometry
+        float* stat_lds = (float*)lds;  // [4][BN][2]
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = b * 32 + li;
+            const float t1 = s1[b] + __shfl_xor(s1[b], 32);
+            const float t2 = s2[b] + __shfl_xor(s2[b], 32);
+            if (lh == 0) {
+                stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
+                stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int half = t / BN, cc = t - half * BN;
+            if (half * 128 >= m_valid) continue;
+            float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + cc) * 2;
+            o[0] = stat_lds[((half * 2) * BN + cc) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 0];
+            o[1] = stat_lds[((half * 2) * BN + cc) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same block structure on v_mfma_f32_16x16x32_f16.  Why: on RANDOM operands the chip does not hold its clock under
+// v_mfma_f32_32x32x16_f16 - a registers-only loop of it runs at 1.55-1.6 PF, the 16x16x32 form at 1.95-2.0 PF (a quarter of the
+// accumulator traffic per multiply), with the convolution's fragment reads and DMA pieces beside them 1.33 against 1.57 PF
+// (tools/probes/overlap.hip, profiles/r05_overlap_probe.txt).  One 32-channel chunk is exactly one MFMA deep.
+//
+// Fragment maps.  A / B operand: lane l holds row (column) l & 15, channels 8 (l >> 4) .. + 8: ONE ds_read_b128 per lane and 16-row
+// tile.  ds_read_b128 serves a wave in four fixed groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32):
+// a group holds all 16 rows, the rows 4 .. 11 with channel group g0 ^ 1 and the others with g0.  An LDS row is 64 bytes (32
+// channels), so a 256-byte bank window is four rows x four 16-byte positions; conflict-free means: rows with equal (index mod 4)
+// sit at different positions.  Image: position of channel group g in row idx = g ^ 2 ((idx >> 3) & 1); MFMA row i <-> the tile's
+// pixel PI(i) = i with the third and fourth quad swapped (i < 8: i, 8 .. 11: i + 4, 12 .. 15: i - 4), so that "g0 ^ 1" falls on the
+// pixels whose (offset >> 2) is odd.  Then the four rows of a residue class (offsets o, o + 4, o + 8, o + 12 - or, in the 8-wide
+// geometry, the rows y and y + 4 of the image: halo offsets 0 .. 7 and 40 .. 47, 40 = 8 mod 16) read positions
+// g0 ^ ((u0 + k) & 2) ^ (k & 1), k = 0 .. 3: four different values for every u0, i.e. at every tap.
+// C / D: lane l holds column l & 15, rows 4 (l >> 4) + reg: four rows x 64-byte segments per store instruction.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int pi16(int i) { return i < 8 ? i : (i < 12 ? i + 4 : i - 4); }
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TW, int IMGS, int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Params p) {
+    constexpr int TH = 256 / (IMGS * TW);
+    constexpr int WP = TW + 2, HP = TH + 2;
+    constexpr int NPX = IMGS * HP * WP;
+    constexpr int NPI = (NPX + 15) / 16;
+    static_assert(NPI <= 24, "one halo piece per wave and tile over six tiles");
+    constexpr int HALO_BYTES = NPI * 1024;
+    constexpr int B_BYTES = BN * 64;
+    constexpr int BJ = BN / 64;
+    constexpr int TM = 4, TN = BN / 16;              // wave tile 64 rows x BN columns in 16 x 16 MFMA tiles
+    constexpr int NSLOT = 4;
+    static_assert(2 * (2 * HALO_BYTES + NSLOT * B_BYTES) <= 160 * 1024, "two blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + NSLOT * B_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;       // row / column inside a 16-wide MFMA tile, channel group (operands) = row quad (C / D)
+
+    const int nnt = p.N / BN;
+    int mtile, ntile;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        mtile = L / nnt;
+        ntile = L - mtile * nnt;
+    }
+    const int n_blk = ntile * BN;
+    const int tiles_per_img = p.H / TH;
+    const int img0 = IMGS == 2 ? mtile * 2 : mtile / tiles_per_img;
+    const int y0 = IMGS == 2 ? 0 : (mtile - img0 * tiles_per_img) * TH;
+    const int n_img = p.M / (p.H * p.W);
+    const int C = p.Cin / 3;
+    const int a_cin = 2 * C;
+    const int ncr = C / 32;
+    const int nt = ncr * 27;
+    const unsigned halo32 = (unsigned)(uintptr_t)lds, ring32 = halo32 + 2 * HALO_BYTES;
+
+    auto issue_halo_piece = [&](int q, int vchunk, int buf) {
+        const int hp = q * 16 + (lane >> 2);
+        const int im = hp / (HP * WP), rem = hp - im * (HP * WP);
+        const int hy = rem / WP, hx = rem - hy * WP;
+        const int gy = y0 - 1 + hy, gx = hx - 1, gi = img0 + im;
+        const bool ok = hp < NPX && gi < n_img && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const int cg = (lane & 3) ^ (((hp >> 3) & 1) << 1);
+        const f16* src = ok ? p.A + (((long long)gi * p.H + gy) * p.W + gx) * a_cin + vchunk * 32 + cg * 8 : p.zero_page;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(lds + buf * HALO_BYTES + q * 1024), 16, 0, 0);
+    };
+    long long b_base[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (wm * BJ + j) * 16 + (lane >> 2);
+        const int cg = (lane & 3) ^ (((row >> 3) & 1) << 1);
+        b_base[j] = (long long)(n_blk + row) * p.ldb + cg * 8;
+    }
+    auto issue_w = [&](int c, int r, int slot) {
+        const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
+        const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+        const int k0 = tap * p.Cin + part * C + c * 32;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0), LPTR(lds + 2 * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, 0, 0);
+    };
+
+    // ---- A: halo pixel of this lane's row in 16-row tile a at tap (0,0).  Tile a of wave wm = natural rows 64 wm + 16 a .. (32-
+    // and 16-wide maps) or 64 wm + 8 a + {0 .. 7, 32 .. 39} (8-wide: image rows y and y + 4)
+    const int pj = pi16(l16);                         // this lane's pixel inside the tile
+    int hp0[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        if constexpr (TW == 32) hp0[a] = (2 * wm + (a >> 1)) * WP + 16 * (a & 1) + pj;
+        else if constexpr (TW == 16) hp0[a] = (4 * wm + a) * WP + pj;
+        else hp0[a] = (wm >> 1) * HP * WP + ((wm & 1) * 8 + a + 4 * (pj >> 3)) * WP + (pj & 7);
+    }
+    // ---- B: column b * 16 + PI(l16) of the weight tile
+    const unsigned bx = ring32 + pj * 64 + ((lq ^ (((pj >> 3) & 1) << 1)) * 16);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, 0, 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    issue_w(0, 2, 2);
+
+    int c = 0, r = 0, c3 = 0, r3 = 3, h1 = 0, h2 = 0;
+    for (int t = 0; t < nt; ++t) {
+        wait_vm(t + 2 >= nt ? 0 : 2 * BJ + h1 + h2);
+        RAW_BARRIER();
+        if (t + 3 < nt) issue_w(c3, r3, (t + 3) & 3);
+        const int hh = (r < 6 || (r >= 18 && r < 24)) ? 1 : 0;
+        if (hh) {
+            const int q = (r < 6 ? r : r - 18) * 4 + wm;
+            const int cn = c + 1 < ncr ? c + 1 : c;
+            issue_halo_piece(q < NPI ? q : NPI - 1, r < 6 ? ncr + c : cn, r < 6 ? 1 : 0);
+        }
+        {   // ---- tile (c, r): one MFMA deep; 4 A + TN B fragments, all requested up front, waits counted per MFMA row
+            const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+            const int ty = tap / 3, tx = tap - ty * 3;
+            const unsigned abuf = halo32 + (r >= 18 ? HALO_BYTES : 0);
+            const unsigned ba = bx + (unsigned)((t & 3) * B_BYTES);
+            half8 fa[TM], fb[TN];
+            unsigned aa[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int hp = hp0[a] + ty * WP + tx;
+                aa[a] = abuf + hp * 64 + ((lq ^ (((hp >> 3) & 1) << 1)) * 16);
+            }
+            // order: A0, B0 .. B(TN-1), A1, A2, A3
+            LDS_READ(fa[0], aa[0], 0);
+            LDS_READ(fb[0], ba, 0);
+            LDS_READ(fb[1], ba, 1024);
+            LDS_READ(fb[2], ba, 2048);
+            LDS_READ(fb[3], ba, 3072);
+            if constexpr (TN == 8) {
+                LDS_READ(fb[4], ba, 4096);
+                LDS_READ(fb[5], ba, 5120);
+                LDS_READ(fb[6], ba, 6144);
+                LDS_READ(fb[7], ba, 7168);
+            }
+            LDS_READ(fa[1], aa[1], 0);
+            LDS_READ(fa[2], aa[2], 0);
+            LDS_READ(fa[3], aa[3], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NRD = TM + TN;
+#define MMA(a, b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[a][b], 0, 0, 0)
+#define MM0(b)                                   \
+    do {                                         \
+        lgkm_wait2<NRD - 2 - (b)>(fa[0], fb[b]); \
+        MMA(0, b);                               \
+    } while (0)
+            MM0(0); MM0(1); MM0(2); MM0(3);
+            if constexpr (TN == 8) { MM0(4); MM0(5); MM0(6); MM0(7); }
+            lgkm_wait1<2>(fa[1]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(1, b);
+            lgkm_wait1<1>(fa[2]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(2, b);
+            lgkm_wait1<0>(fa[3]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(3, b);
+#undef MM0
+#undef MMA
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        h2 = h1;
+        h1 = hh;
+        if (++r == 27) { r = 0; ++c; }
+        if (++r3 == 27) { r3 = 0; ++c3; }
+    }
+    __syncthreads();
+
+    if (p.ablate & 32) return;
+    // ------------------------------------------------------------------ fp32 epilogue: the arithmetic of conv3x3_f16.hip's SPLIT
+    // build per element (BN scale x 2^-11 + shift, + fp32 residual, ReLU from relu_from on, fp32 or [yh | yl'] stores, per-128-row
+    // column sums).  Lane: column PI(l16) of the 16-column tile, rows 4 PQ(lq) + reg of the 16-row tile (PQ = quads 2 and 3 swapped)
+    const int ldc = (int)p.ldc;
+    const int m_blk = mtile * 256;
+    const int m_valid = p.M - m_blk;
+    const bool wave_live = m_valid >= 256 || wm < 2;         // M % 128 == 0: a ragged tile has 128 rows, those of waves 0, 1
+    const int pq = lq < 2 ? lq : 5 - lq;
+    const int lrow = TW == 8 ? (pq < 2 ? 4 * pq : 32 + 4 * (pq - 2)) : 4 * pq;     // lane part of the natural row
+    const int col0 = n_blk + pj;
+    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C32 + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((p.res32 ? p.res32 : p.C32) + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t k_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((p.pack16 ? p.pack16 : (f16*)p.C32) + (long long)m_blk * 2 * p.N), 0, 256 * 2 * p.N * 2, 0x00020000);
+    const int voff = (lrow * ldc + col0) * 4;
+    const int koff = (lrow * 2 * p.N + col0) * 2;
+    float vmax = 0.f;
+    float s1[TN], s2[TN];
+    auto run = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = col0 + b * 16;
+            const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
+            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+            const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+            const bool pk = p.pack16 && col >= p.pack_from;      // uniform per 16-column tile (pack_from % 32 == 0)
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int ubase = wm * 64 + (TW == 8 ? a * 8 : a * 16);          // uniform part of the natural row
+                float rr[4];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        rr[e] = wave_live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff + b * 64, (ubase + e) * ldc * 4, 0)) : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[a][b][e] * cs + sh;
+                    v += RES ? rr[e] : 0.f;
+                    v = fmaxf(v, lo);
+                    if (wave_live) {
+                        t1 += v;
+                        t2 += v * v;
+                        if (pk) {
+                            vmax = fmaxf(vmax, fabsf(v));
+                            const f16 hv = (f16)v;
+                            const f16 lv = (f16)((v - (float)hv) * 2048.0f);
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), k_rs, koff + b * 32, (ubase + e) * 2 * p.N * 2, 0);
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lv), k_rs, koff + b * 32 + p.N * 2, (ubase + e) * 2 * p.N * 2, 0);
+                        } else if (!(p.ablate & 64)) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff + b * 64, (ubase + e) * ldc * 4, 0);
+                        }
+                    }
+                }
+            }
+            s1[b] = t1;
+            s2[b] = t2;
+        }
+    };
+    if (p.res32) run(std::true_type{});
+    else run(std::false_type{});
+    if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;
+    if (p.stats) {   // per 128 natural rows: waves 0,1 own rows 0..127, waves 2,3 rows 128..255
+        float* stat_lds = (float*)lds;  // [4][BN][2]
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = b * 16 + pj;
+            float t1 = s1[b], t2 = s2[b];
+            t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+            if (lq == 0) {
+                stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
+                stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int half = t / BN, cc = t - half * BN;
+            if (half * 128 >= m_valid) continue;
+            float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + cc) * 2;
+            o[0] = stat_lds[((half * 2) * BN + cc) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 0];
+            o[1] = stat_lds[((half * 2) * BN + cc) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 1];
+        }
+    }
+}
+
+template <int TW, int IMGS>
+void launch_x3m16(reid_ctx* ctx, const Gemm16Params& p) {
+    const int nmt = (p.M + 255) / 256;
+    if (p.N % 128 == 0) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(nmt * (p.N / 128)), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(nmt * (p.N / 64)), dim3(256), 0, ctx->stream, p);
+}
+
+template <int TW, int IMGS>
+void launch_x3(reid_ctx* ctx, const Gemm16Params& p) {
+    const int nmt = (p.M + 255) / 256;
+    if (p.N % 128 == 0) hipLaunchKernelGGL((conv3x3_x3_kernel<TW, IMGS, 128>), dim3(nmt * (p.N / 128)), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((conv3x3_x3_kernel<TW, IMGS, 64>), dim3(nmt * (p.N / 64)), dim3(256), 0, ctx->stream, p);
+}
+
+}  // namespace
+
+// Large launches only (at least two blocks for every CU): a tracking frame keeps conv3x3_f16.hip's split-K forms.
+bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p) {
+    if (!ctx->split_x3 || p.split_terms != 3 || p.Cin % 96 != 0 || p.N % 64 != 0 || p.M % 128 != 0 || !conv3x3_f16_supported(p)) return false;
+    const long long blocks = (long long)((p.M + 255) / 256) * (p.N % 128 == 0 ? p.N / 128 : p.N / 64);
+    return blocks >= ctx->split_x3_min_blocks;
+}
+
+int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p0) {
+    Gemm16Params p = p0;
+    p.fault = ctx->fault;
+    p.ablate |= ctx->x3_ablate;
+    if (ctx->split_x3 == 2) {                    // the 16x16x32 form (default)
+        if (p.W == 32) launch_x3m16<32, 1>(ctx, p);
+        else if (p.W == 16) launch_x3m16<16, 1>(ctx, p);
+        else launch_x3m16<8, 2>(ctx, p);
+    } else if (p.W == 32) launch_x3<32, 1>(ctx, p);
+    else if (p.W == 16) launch_x3<16, 1>(ctx, p);
+    else launch_x3<8, 2>(ctx, p);
+    LAUNCH_CHECK();
+    return REID_OK;
+}

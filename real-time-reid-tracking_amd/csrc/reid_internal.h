@@ -195,6 +195,8 @@ int launch_gemm_f16(reid_ctx* ctx, int amode, const Gemm16Params& p, int kind, d
 bool conv3x3_f16_supported(const Gemm16Params& p);   // conv3x3_f16.hip: 3x3 s1 p1 with the input halo tile kept in LDS
 int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);
 int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build, see Gemm16Params
+bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p);   // conv3x3_x3.hip: the same convolution as two 4-wave blocks per CU (large launches)
+int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p);
 int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build of gemm_f16 (im2col: strided / 1x1)
 bool two_linear_supported(const reid_ctx*, long long T, int C, int hid);
 int launch_two_linear(reid_ctx*, const _Float16* a16, long long T, int C, int hid, const float* w1, const float* b1, const float* w2,
@@ -369,6 +371,10 @@ struct reid_ctx {
     int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
     int pack_epilogue = 1;   // precision 2: conv1 epilogues write [yh | yl'] for conv2 themselves (REID_PACK_EPILOGUE=0: fp32 + pack passes)
     int split_lean_epi = 1;  // precision 2: buffer-instruction epilogue of the SPLIT convolution builds (REID_SPLIT_LEAN=0: general loop)
+    int split_x3 = 2;        // precision 2, large launches: the two-blocks-per-CU form of the halo convolution (conv3x3_x3.hip): 2 = on
+                             // v_mfma_f32_16x16x32_f16 (default), 1 = on 32x32x16; 0: conv3x3_f16.hip
+    int x3_ablate = 0;       // timing experiments on conv3x3_x3.hip (debug switch; WRONG results while set)
+    int split_x3_min_blocks = 512;   // ... from this many blocks on (two for every CU)
     int split_pair = 0;      // precision 2, 128-wide halo tiles (REID_SPLIT_PAIR): 0 = three passes over the virtual channels (default),
                              // 1 / 2 = the operand-sharing PAIR order of conv3x3_f16.hip (barrier behind / in front of a step's last
                              // MFMA group).  Measured at 1024 crops per pass: +1.1 % / -0.9 %; it changes the summation order, and the

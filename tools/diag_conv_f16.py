@@ -19,7 +19,7 @@ fn.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_float)]
 dg = _ffi.debug_lib().reid_debug_conv_diag
 dg.restype = C.c_int
 dg.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-n = 256
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 for name, h, w, cin, cout in (("L2 128->128 32x16", 32, 16, 128, 128), ("L3 256->256 16x8", 16, 8, 256, 256), ("L4 512->512 16x8", 16, 8, 512, 512),
                               ("L4 as split: 1536->512 16x8", 16, 8, 1536, 512), ("L1 as split: 192->64 64x32", 64, 32, 192, 64)):
     check(dg(eng.h, 1, None))
