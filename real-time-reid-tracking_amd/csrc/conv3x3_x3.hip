@@ -384,9 +384,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
     constexpr int B_BYTES = BN * 64;
     constexpr int BJ = BN / 64;
     constexpr int TM = 4, TN = BN / 16;              // wave tile 64 rows x BN columns in 16 x 16 MFMA tiles
-    constexpr int NSLOT = 4;
-    static_assert(2 * (2 * HALO_BYTES + NSLOT * B_BYTES) <= 160 * 1024, "two blocks per CU");
-    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + NSLOT * B_BYTES];
+    constexpr int G = BN == 64 ? 3 : 1;              // tiles per block barrier
+    constexpr int NS = G == 1 ? 4 : 3, LEAD = NS - 1;   // ring slots (of G weight tiles each), groups in flight
+    static_assert(2 * (2 * HALO_BYTES + NS * G * B_BYTES) <= 160 * 1024, "two blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + NS * G * B_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -428,15 +429,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
         const int cg = (lane & 3) ^ (((row >> 3) & 1) << 1);
         b_base[j] = (long long)(n_blk + row) * p.ldb + cg * 8;
     }
-    auto issue_w = [&](int c, int r, int slot) {
-        const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
-        const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
-        const int k0 = tap * p.Cin + part * C + c * 32;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0), LPTR(lds + 2 * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, 0, 0);
-    };
-
     // ---- A: halo pixel of this lane's row in 16-row tile a at tap (0,0).  Tile a of wave wm = natural rows 64 wm + 16 a .. (32-
     // and 16-wide maps) or 64 wm + 8 a + {0 .. 7, 32 .. 39} (8-wide: image rows y and y + 4)
     const int pj = pi16(l16);                         // this lane's pixel inside the tile
@@ -455,6 +447,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (G == 1) {
+    auto issue_w = [&](int c, int r, int slot) {
+        const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
+        const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+        const int k0 = tap * p.Cin + part * C + c * 32;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0), LPTR(lds + 2 * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, 0, 0);
+    };
 
     for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, 0, 0);
     issue_w(0, 0, 0);
@@ -526,6 +528,125 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
         h1 = hh;
         if (++r == 27) { r = 0; ++c; }
         if (++r3 == 27) { r3 = 0; ++c3; }
+    }
+    } else {
+    // ---- main loop at BN = 64 (layer 1): GROUPS of G = 3 tiles per block barrier - there a tile is 16 MFMAs per wave, and one barrier
+    // + DMA issue per tile cost more than the tile (751 us per launch against 697 for the 12-wave kernel).  A ring of NS slots of G weight tiles, LEAD = NS - 1 groups in flight; a chunk's 27 tiles are 18 / G groups on
+    // the xh halo (buffer 0) and 9 / G on xl' (buffer 1).  Halo pieces: xl' of this chunk during the chunk's first groups (buffer 1
+    // was last read in the previous chunk's last group), xh of the next chunk during the first groups of the xl' phase (buffer 0 was
+    // last read in the group before); every wave issues the same number per group (24 pieces cover NPI; the surplus ones repeat the
+    // last piece), so that the counted waits are uniform: 6 pieces per wave and phase, HX per group of the xh phase, HL of the xl' one.
+    constexpr int GX = 18 / G, GL = 9 / G, GC = GX + GL;             // groups per phase / chunk
+    constexpr int HX = G == 1 ? 1 : 2, HL = G == 1 ? 1 : 3;            // halo pieces per wave and group: 6 per phase in the phase's first groups
+    constexpr int NHX = 6 / HX, NHL = 6 / HL;                           // groups of a phase that carry halo pieces
+    // a halo piece must have left the window of the counted wait (the pieces of the last LEAD - 1 iterations may be in flight) before
+    // its buffer is read: the last group that issues one lies at least LEAD groups before the phase that reads it
+    static_assert(NHX - 1 <= GX - LEAD && GX + NHL - 1 <= GC - LEAD, "halo pieces land before their phase starts");
+    const int nu = ncr * GC;
+    auto issue_group = [&](int cc, int gg, int slot) {                 // group gg of chunk cc: tiles r = gg * G .. + G
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int r = gg * G + j;
+            const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
+            const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+            const int k0 = tap * p.Cin + part * C + cc * 32;
+#pragma unroll
+            for (int jj = 0; jj < BJ; ++jj)
+                __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[jj] + k0), LPTR(lds + 2 * HALO_BYTES + (slot * G + j) * B_BYTES + (wm * BJ + jj) * 1024), 16, 0, 0);
+        }
+    };
+    for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, 0, 0);
+    {
+        int cc = 0, gg = 0;
+        for (int v = 0; v < LEAD; ++v) {
+            issue_group(cc, gg, v);
+            if (++gg == GC) { gg = 0; ++cc; }
+        }
+    }
+    int c = 0, g = 0, cl = LEAD / GC, gl = LEAD % GC, hist[LEAD > 1 ? LEAD - 1 : 1] = {0};
+    for (int u = 0; u < nu; ++u) {
+        // in-order landing: all but the pieces of the last LEAD - 1 iterations (groups u + 1 .. and their halo pieces) have landed
+        int allow = 0;
+#pragma unroll
+        for (int i = 0; i < LEAD - 1; ++i) allow += G * BJ + hist[i];
+        wait_vm(u - 1 + LEAD < nu ? allow : 0);
+        RAW_BARRIER();              // ... every wave's share; every wave has finished group u - 1: its slot and halo buffer are free
+        if (u + LEAD < nu) issue_group(cl, gl, (u + LEAD) % NS);
+        int hh = 0;
+        if (g < NHX) {
+#pragma unroll
+            for (int k = 0; k < HX; ++k) {
+                const int q = (g * HX + k) * 4 + wm;
+                issue_halo_piece(q < NPI ? q : NPI - 1, ncr + c, 1);
+            }
+            hh = HX;
+        } else if (g >= GX && g < GX + NHL) {
+            const int cn = c + 1 < ncr ? c + 1 : c;                    // after the last chunk: the same chunk again, read by nobody
+#pragma unroll
+            for (int k = 0; k < HL; ++k) {
+                const int q = ((g - GX) * HL + k) * 4 + wm;
+                issue_halo_piece(q < NPI ? q : NPI - 1, cn, 0);
+            }
+            hh = HL;
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {   // ---- tile r = g * G + j of chunk c: one MFMA deep; 4 A + TN B fragments requested up front
+            const int r = g * G + j;
+            const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+            const int ty = tap / 3, tx = tap - ty * 3;
+            const unsigned abuf = halo32 + (r >= 18 ? HALO_BYTES : 0);
+            const unsigned ba = bx + (unsigned)(((u % NS) * G + j) * B_BYTES);
+            half8 fa[TM], fb[TN];
+            unsigned aa[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int hp = hp0[a] + ty * WP + tx;
+                aa[a] = abuf + hp * 64 + ((lq ^ (((hp >> 3) & 1) << 1)) * 16);
+            }
+            // order: A0, B0 .. B(TN-1), A1, A2, A3
+            LDS_READ(fa[0], aa[0], 0);
+            LDS_READ(fb[0], ba, 0);
+            LDS_READ(fb[1], ba, 1024);
+            LDS_READ(fb[2], ba, 2048);
+            LDS_READ(fb[3], ba, 3072);
+            if constexpr (TN == 8) {
+                LDS_READ(fb[4], ba, 4096);
+                LDS_READ(fb[5], ba, 5120);
+                LDS_READ(fb[6], ba, 6144);
+                LDS_READ(fb[7], ba, 7168);
+            }
+            LDS_READ(fa[1], aa[1], 0);
+            LDS_READ(fa[2], aa[2], 0);
+            LDS_READ(fa[3], aa[3], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NRD = TM + TN;
+#define MMA(a, b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[a][b], 0, 0, 0)
+#define MM0(b)                                   \
+    do {                                         \
+        lgkm_wait2<NRD - 2 - (b)>(fa[0], fb[b]); \
+        MMA(0, b);                               \
+    } while (0)
+            MM0(0); MM0(1); MM0(2); MM0(3);
+            if constexpr (TN == 8) { MM0(4); MM0(5); MM0(6); MM0(7); }
+            lgkm_wait1<2>(fa[1]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(1, b);
+            lgkm_wait1<1>(fa[2]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(2, b);
+            lgkm_wait1<0>(fa[3]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(3, b);
+#undef MM0
+#undef MMA
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = LEAD - 2; i > 0; --i) hist[i] = hist[i - 1];
+        if (LEAD > 1) hist[0] = hh;
+        if (++g == GC) { g = 0; ++c; }
+        if (++gl == GC) { gl = 0; ++cl; }
+    }
     }
     __syncthreads();
 
@@ -623,7 +744,7 @@ template <int TW, int IMGS>
 void launch_x3m16(reid_ctx* ctx, const Gemm16Params& p) {
     const int nmt = (p.M + 255) / 256;
     if (p.N % 128 == 0) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(nmt * (p.N / 128)), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(nmt * (p.N / 64)), dim3(256), 0, ctx->stream, p);
+    else if constexpr (TW == 32) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(nmt * (p.N / 64)), dim3(256), 0, ctx->stream, p);
 }
 
 template <int TW, int IMGS>
@@ -638,6 +759,9 @@ void launch_x3(reid_ctx* ctx, const Gemm16Params& p) {
 // Large launches only (at least two blocks for every CU): a tracking frame keeps conv3x3_f16.hip's split-K forms.
 bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p) {
     if (!ctx->split_x3 || p.split_terms != 3 || p.Cin % 96 != 0 || p.N % 64 != 0 || p.M % 128 != 0 || !conv3x3_f16_supported(p)) return false;
+    // 64-wide tiles (layer 1, 32-wide maps only): form 3.  Measured at 1024 crops: 666 us per launch against 652 for the 12-wave kernel
+    // - layer 1 moves 1.3-1.6 GB per convolution for 0.31 ms of matrix pipe and is bound by neither alone -, so it stays there
+    if (p.N % 128 != 0 && (p.W != 32 || ctx->split_x3 < 3)) return false;
     const long long blocks = (long long)((p.M + 255) / 256) * (p.N % 128 == 0 ? p.N / 128 : p.N / 64);
     return blocks >= ctx->split_x3_min_blocks;
 }
@@ -646,7 +770,7 @@ int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
     p.fault = ctx->fault;
     p.ablate |= ctx->x3_ablate;
-    if (ctx->split_x3 == 2) {                    // the 16x16x32 form (default)
+    if (ctx->split_x3 >= 2) {                    // the 16x16x32 form (default)
         if (p.W == 32) launch_x3m16<32, 1>(ctx, p);
         else if (p.W == 16) launch_x3m16<16, 1>(ctx, p);
         else launch_x3m16<8, 2>(ctx, p);

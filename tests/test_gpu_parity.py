@@ -131,6 +131,36 @@ def _seres18_fixture_check(eng, golden_dir, tag, crops_fn, precision=0):
     np.testing.assert_allclose(emb_c, emb, rtol=1e-6, atol=1e-6 * np.abs(emb).max())
 
 
+@pytest.mark.parametrize("form", [1, 2, 3])
+@pytest.mark.parametrize("tag,crops_fn", [("seed0", synth.crops_u8), ("smooth1", synth.smooth_crops_u8)])
+def test_two_blocks_per_cu_convolution_matches_reference_fixture(eng, golden_dir, tag, crops_fn, form):
+    """csrc/conv3x3_x3.hip - the fp32-class 3x3 convolution of LARGE launches (two 4-wave blocks per CU; form 2, the default, on
+    v_mfma_f32_16x16x32_f16 with 64-byte-row LDS images, form 1 on 32x32x16, form 3 = form 2 with layer 1's 64-wide tiles in groups
+    of three taps per barrier) - forced onto the fixture's small batch (debug switch split_x3_min_blocks = 1), against the
+    REFERENCE's stage taps, embeddings and logits at the exact-fp32 mode's thresholds (SERes18_IBN.py:120-128,250-276); the
+    full-size configs[1] test runs it at its own launch sizes.  Another summation order than conv3x3_f16.hip's (per 32-channel
+    chunk: xh.wh 2^11, xh.wl', xl'.wh), the same three products."""
+    eng.set_precision(2)
+    eng.debug_switch("split_x3_min_blocks", 1)
+    eng.debug_switch("split_x3", form)
+    try:
+        _seres18_fixture_check(eng, golden_dir, tag, crops_fn, 2)
+        # ragged and odd batches: a last 256-row tile of 128 rows (odd image counts in the 8-wide maps), single images
+        sd = synth.seres18_state_dict(0)
+        eng.load_seres18(*weights.pack_seres18(sd)[:2])
+        crops = synth.smooth_crops_u8(7, 11)
+        got = eng.embed_u8(crops)
+        eng.debug_switch("split_x3", 0)
+        want = eng.embed_u8(crops)
+        assert not np.array_equal(got, want) and np.abs(got - want).max() <= 5e-6 * np.abs(want).max()
+        eng.debug_switch("split_x3", form)
+        assert np.array_equal(eng.embed_u8(crops[:1]), got[:1]) and np.array_equal(eng.embed_u8(crops[2:5]), got[2:5])   # images are independent
+    finally:
+        eng.debug_switch("split_x3", 2)
+        eng.debug_switch("split_x3_min_blocks", 512)
+        eng.set_precision(0)
+
+
 def test_fused_stem_pool_is_the_same_for_whole_images_and_strips(eng_w0):
     """stem_f32.hip with the max-pool on its accumulators: 520 crops in one pass (a block walks a whole image) and in chunks of
     260 (32-tile strips, each recomputing the tile above it) run the same arithmetic per pixel - bit-identical embeddings.
