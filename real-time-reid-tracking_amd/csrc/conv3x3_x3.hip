@@ -394,12 +394,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
     const int l16 = lane & 15, lq = lane >> 4;       // row / column inside a 16-wide MFMA tile, channel group (operands) = row quad (C / D)
 
     const int nnt = p.N / BN;
-    int mtile, ntile;
+    // Split-K (few output tiles - a tracking frame): SK blocks share one output tile, each summing C / SK of the real channels; the
+    // one that arrives last adds the fp32 partials in split order (deterministic) and runs the epilogue (as conv3x3_f16.hip).
+    const int SK = p.split_k > 1 ? p.split_k : 1;
+    int mtile, ntile, tile_id, ksplit;
     {
         const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-        mtile = L / nnt;
-        ntile = L - mtile * nnt;
+        tile_id = L / SK;
+        ksplit = L - tile_id * SK;
+        mtile = tile_id / nnt;
+        ntile = tile_id - mtile * nnt;
     }
     const int n_blk = ntile * BN;
     const int tiles_per_img = p.H / TH;
@@ -408,7 +413,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
     const int n_img = p.M / (p.H * p.W);
     const int C = p.Cin / 3;
     const int a_cin = 2 * C;
-    const int ncr = C / 32;
+    const int ncr_all = C / 32;
+    const int ncr = ncr_all / SK, c0 = ksplit * ncr;     // real 32-channel chunks of this block: [c0, c0 + ncr)
     const int nt = ncr * 27;
     const unsigned halo32 = (unsigned)(uintptr_t)lds, ring32 = halo32 + 2 * HALO_BYTES;
 
@@ -452,13 +458,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
     auto issue_w = [&](int c, int r, int slot) {
         const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
         const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
-        const int k0 = tap * p.Cin + part * C + c * 32;
+        const int k0 = tap * p.Cin + part * C + (c0 + c) * 32;
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
             __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0), LPTR(lds + 2 * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, 0, 0);
     };
 
-    for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, 0, 0);
+    for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, c0, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
     issue_w(0, 2, 2);
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
         if (hh) {
             const int q = (r < 6 ? r : r - 18) * 4 + wm;
             const int cn = c + 1 < ncr ? c + 1 : c;
-            issue_halo_piece(q < NPI ? q : NPI - 1, r < 6 ? ncr + c : cn, r < 6 ? 1 : 0);
+            issue_halo_piece(q < NPI ? q : NPI - 1, r < 6 ? ncr_all + c0 + c : c0 + cn, r < 6 ? 1 : 0);
         }
         {   // ---- tile (c, r): one MFMA deep; 4 A + TN B fragments, all requested up front, waits counted per MFMA row
             const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
@@ -503,20 +509,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
             LDS_READ(fa[3], aa[3], 0);
             __builtin_amdgcn_sched_barrier(0);
             constexpr int NRD = TM + TN;
-#define MMA(a, b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[a][b], 0, 0, 0)
+            // (inline asm: the waits are asm volatile statements, and only asm volatile statements keep their order among each other -
+            // hipcc moved builtin MFMAs below later waits, through sched_barriers.  Accumulators are only ever MFMA SrcC / vDst inside
+            // the loop: back-to-back issue needs no wait states; the epilogue reads them behind the loop's closing barrier + s_nops.)
+#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fa[a]), "v"(fb[b]))
 #define MM0(b)                                   \
     do {                                         \
-        lgkm_wait2<NRD - 2 - (b)>(fa[0], fb[b]); \
+        lgkm_wait1<NRD - 2 - (b)>(fb[b]);        \
         MMA(0, b);                               \
     } while (0)
+            lgkm_wait1<NRD - 1>(fa[0]);           // (every wait names what it releases: tying fa[0] to each of them made hipcc copy it per MFMA)
             MM0(0); MM0(1); MM0(2); MM0(3);
             if constexpr (TN == 8) { MM0(4); MM0(5); MM0(6); MM0(7); }
             lgkm_wait1<2>(fa[1]);
 #pragma unroll
             for (int b = 0; b < TN; ++b) MMA(1, b);
+            __builtin_amdgcn_sched_barrier(0);
             lgkm_wait1<1>(fa[2]);
 #pragma unroll
             for (int b = 0; b < TN; ++b) MMA(2, b);
+            __builtin_amdgcn_sched_barrier(0);
             lgkm_wait1<0>(fa[3]);
 #pragma unroll
             for (int b = 0; b < TN; ++b) MMA(3, b);
@@ -549,13 +561,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
             const int r = gg * G + j;
             const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
             const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
-            const int k0 = tap * p.Cin + part * C + cc * 32;
+            const int k0 = tap * p.Cin + part * C + (c0 + cc) * 32;
 #pragma unroll
             for (int jj = 0; jj < BJ; ++jj)
                 __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[jj] + k0), LPTR(lds + 2 * HALO_BYTES + (slot * G + j) * B_BYTES + (wm * BJ + jj) * 1024), 16, 0, 0);
         }
     };
-    for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, 0, 0);
+    for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, c0, 0);
     {
         int cc = 0, gg = 0;
         for (int v = 0; v < LEAD; ++v) {
@@ -577,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
 #pragma unroll
             for (int k = 0; k < HX; ++k) {
                 const int q = (g * HX + k) * 4 + wm;
-                issue_halo_piece(q < NPI ? q : NPI - 1, ncr + c, 1);
+                issue_halo_piece(q < NPI ? q : NPI - 1, ncr_all + c0 + c, 1);
             }
             hh = HX;
         } else if (g >= GX && g < GX + NHL) {
@@ -585,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
 #pragma unroll
             for (int k = 0; k < HL; ++k) {
                 const int q = ((g - GX) * HL + k) * 4 + wm;
-                issue_halo_piece(q < NPI ? q : NPI - 1, cn, 0);
+                issue_halo_piece(q < NPI ? q : NPI - 1, c0 + cn, 0);
             }
             hh = HL;
         }
@@ -620,20 +632,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
             LDS_READ(fa[3], aa[3], 0);
             __builtin_amdgcn_sched_barrier(0);
             constexpr int NRD = TM + TN;
-#define MMA(a, b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[a][b], 0, 0, 0)
+            // (inline asm: the waits are asm volatile statements, and only asm volatile statements keep their order among each other -
+            // hipcc moved builtin MFMAs below later waits, through sched_barriers.  Accumulators are only ever MFMA SrcC / vDst inside
+            // the loop: back-to-back issue needs no wait states; the epilogue reads them behind the loop's closing barrier + s_nops.)
+#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fa[a]), "v"(fb[b]))
 #define MM0(b)                                   \
     do {                                         \
-        lgkm_wait2<NRD - 2 - (b)>(fa[0], fb[b]); \
+        lgkm_wait1<NRD - 2 - (b)>(fb[b]);        \
         MMA(0, b);                               \
     } while (0)
+            lgkm_wait1<NRD - 1>(fa[0]);           // (every wait names what it releases: tying fa[0] to each of them made hipcc copy it per MFMA)
             MM0(0); MM0(1); MM0(2); MM0(3);
             if constexpr (TN == 8) { MM0(4); MM0(5); MM0(6); MM0(7); }
             lgkm_wait1<2>(fa[1]);
 #pragma unroll
             for (int b = 0; b < TN; ++b) MMA(1, b);
+            __builtin_amdgcn_sched_barrier(0);
             lgkm_wait1<1>(fa[2]);
 #pragma unroll
             for (int b = 0; b < TN; ++b) MMA(2, b);
+            __builtin_amdgcn_sched_barrier(0);
             lgkm_wait1<0>(fa[3]);
 #pragma unroll
             for (int b = 0; b < TN; ++b) MMA(3, b);
@@ -648,7 +666,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
         if (++gl == GC) { gl = 0; ++cl; }
     }
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (inline asm: hipcc does not count their wait states)
     __syncthreads();
+
+    if (SK > 1) {
+        // partial tile in register order [TM * TN * 4][256 lanes]: coalesced both ways.  Device-scope (sc1) stores are written through
+        // to the point all XCDs share and the loads below bypass this XCD's L2: no L2 write-back / invalidate fence (conv3x3_f16.hip)
+        constexpr int PART = 256 * BN;
+        float* part = p.splitk_ws + (long long)tile_id * SK * PART;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __hip_atomic_store(part + (long long)ksplit * PART + ((a * TN + b) * 4 + e) * 256 + tid, acc[a][b][e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)lds;
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = old == SK - 1;
+            if (old == SK - 1) __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        if (!*flag) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < SK; ++sidx)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[a][b][e] += __hip_atomic_load(part + (long long)sidx * PART + ((a * TN + b) * 4 + e) * 256 + tid, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();   // the flag word is about to be overwritten by the statistics
+    }
 
     if (p.ablate & 32) return;
     // ------------------------------------------------------------------ fp32 epilogue: the arithmetic of conv3x3_f16.hip's SPLIT
@@ -741,10 +799,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
 }
 
 template <int TW, int IMGS>
-void launch_x3m16(reid_ctx* ctx, const Gemm16Params& p) {
+int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
+    Gemm16Params p = p0;
     const int nmt = (p.M + 255) / 256;
-    if (p.N % 128 == 0) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(nmt * (p.N / 128)), dim3(256), 0, ctx->stream, p);
-    else if constexpr (TW == 32) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(nmt * (p.N / 64)), dim3(256), 0, ctx->stream, p);
+    const bool wide = p.N % 128 == 0;
+    const int tiles = nmt * (wide ? p.N / 128 : p.N / 64);
+    // few output tiles (a tracking frame): split the real 32-channel chunks over sk blocks per tile, up to two blocks for every CU
+    const int ncr = p.Cin / 3 / 32;
+    int sk = 1;
+    while (ctx->f16_split_k && tiles * sk * 2 <= 512 && ncr % (sk * 2) == 0 && sk < 8) sk *= 2;
+    if (sk > 1) {
+        float* ws;
+        int* cnt;
+        const bool fresh = ctx->ws.find("x3.splitk_cnt") == ctx->ws.end();
+        REID_TRY(ctx_ws(ctx, "x3.splitk_ws", (size_t)tiles * sk * 256 * (wide ? 128 : 64) * sizeof(float), (void**)&ws));
+        REID_TRY(ctx_ws(ctx, "x3.splitk_cnt", 512 * sizeof(int), (void**)&cnt));
+        if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, 512 * sizeof(int), ctx->stream));
+        p.split_k = sk; p.splitk_ws = ws; p.splitk_cnt = cnt;
+    } else {
+        p.split_k = 1;
+    }
+    if (wide) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    else if constexpr (TW == 32) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    return REID_OK;
 }
 
 template <int TW, int IMGS>
@@ -763,7 +840,7 @@ bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p) {
     // - layer 1 moves 1.3-1.6 GB per convolution for 0.31 ms of matrix pipe and is bound by neither alone -, so it stays there
     if (p.N % 128 != 0 && (p.W != 32 || ctx->split_x3 < 3)) return false;
     const long long blocks = (long long)((p.M + 255) / 256) * (p.N % 128 == 0 ? p.N / 128 : p.N / 64);
-    return blocks >= ctx->split_x3_min_blocks;
+    return blocks >= ctx->split_x3_min_blocks || (ctx->split_x3_small && ctx->split_x3 >= 2);   // small launches: split-K forms of the 16x16x32 kernel
 }
 
 int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p0) {
@@ -771,9 +848,9 @@ int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p0) {
     p.fault = ctx->fault;
     p.ablate |= ctx->x3_ablate;
     if (ctx->split_x3 >= 2) {                    // the 16x16x32 form (default)
-        if (p.W == 32) launch_x3m16<32, 1>(ctx, p);
-        else if (p.W == 16) launch_x3m16<16, 1>(ctx, p);
-        else launch_x3m16<8, 2>(ctx, p);
+        if (p.W == 32) REID_TRY((launch_x3m16<32, 1>(ctx, p)));
+        else if (p.W == 16) REID_TRY((launch_x3m16<16, 1>(ctx, p)));
+        else REID_TRY((launch_x3m16<8, 2>(ctx, p)));
     } else if (p.W == 32) launch_x3<32, 1>(ctx, p);
     else if (p.W == 16) launch_x3<16, 1>(ctx, p);
     else launch_x3<8, 2>(ctx, p);

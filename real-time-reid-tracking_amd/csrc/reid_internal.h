@@ -374,6 +374,7 @@ struct reid_ctx {
     int split_x3 = 2;        // precision 2, large launches: the two-blocks-per-CU form of the halo convolution (conv3x3_x3.hip): 2 = on
                              // v_mfma_f32_16x16x32_f16 for the 128-wide tiles (default), 3 = and the 64-wide ones (layer 1), 1 = on 32x32x16;
                              // 0: conv3x3_f16.hip
+    int split_x3_small = 0;  // ... and small launches too (a tracking frame), K split over up to 8 blocks per tile
     int x3_ablate = 0;       // timing experiments on conv3x3_x3.hip (debug switch; WRONG results while set)
     int split_x3_min_blocks = 512;   // ... from this many blocks on (two for every CU)
     int split_pair = 0;      // precision 2, 128-wide halo tiles (REID_SPLIT_PAIR): 0 = three passes over the virtual channels (default),
