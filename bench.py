@@ -85,6 +85,18 @@ def traffic_source(tag):
         return None
 
 
+def sustained_mfma(eng):
+    """Registers-only f16 MFMA loops on this device (libreid_hip_debug.so: reid_debug_mfma_bare), TFLOP/s: both instruction shapes,
+    random and all-zero operands.  `peak` in the roofline objects stays the nominal figure of MI355X_MICROARCH.md; this is the
+    ceiling a kernel with free operands would meet on THIS device, measured in the same process."""
+    try:
+        return {"unit": "TFLOP/s on the f16 pipe, registers only, measured in this run",
+                "random_32x32x16": round(eng.debug_mfma_bare(32, False), 1), "random_16x16x32": round(eng.debug_mfma_bare(16, False), 1),
+                "zero_32x32x16": round(eng.debug_mfma_bare(32, True), 1), "zero_16x16x32": round(eng.debug_mfma_bare(16, True), 1)}
+    except Exception:     # noqa: BLE001 - the debug library is optional
+        return None
+
+
 def cpu_baseline_embed(sd, budget_s=12.0):
     """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload:
     batch 64 (reference default --bs 64), all host cores."""
@@ -258,6 +270,15 @@ def run_embed(job, args):
 
     main_res = run(args.precision, args.steps, args.warmup)
     others = {} if args.single else {o: run(o, max(1, min(3, args.steps)), 1) for o in ("f32", "f16x3", "f16") if o != args.precision}
+    sustained = sustained_mfma(eng)
+    if sustained is not None:
+        for res, prec in [(main_res, args.precision)] + [(r, o) for o, r in others.items()]:
+            if prec in ("f16", "f16x3"):
+                # what the f16 matrix pipe of THIS device sustains on random operands, registers only (the nominal 2.5 PF is not
+                # reachable on such data: the chip lowers its clock); the fp32-class kernels of large launches run 16x16x32
+                per_flop = sustained["random_16x16x32"] / (3.0 if prec == "f16x3" else 1.0)
+                res["roofline"]["sustained_mfma"] = dict(sustained, per_algorithmic_flop=round(per_flop, 1),
+                                                         frac_of_sustained=round(res["roofline"]["achieved"] / per_flop, 4))
 
     # parity inside the bench: the arithmetic modes agree on the embeddings of this rank (cosine against exact fp32)
     e = {}

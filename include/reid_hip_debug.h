@@ -60,6 +60,9 @@ int reid_debug_knn_wide(reid_ctx* ctx, int enable, int force);
 int reid_debug_conv_diag(reid_ctx* ctx, int enable, unsigned long long* out_host);
 /* Bare MFMA loop with fragments re-read from LDS (shape 32 = 32x32x16 f16, 16 = 16x16x32 f16). */
 int reid_debug_mfma_shape(reid_ctx* ctx, int shape, int iters, int blocks, float* tflops);
+/* Registers-only MFMA loop (no LDS, no memory; 512 blocks x 4 waves): what the matrix pipe of THIS device sustains.  shape 32 =
+ * v_mfma_f32_32x32x16_f16, 16 = v_mfma_f32_16x16x32_f16; zero != 0: all-zero operands (the chip holds its clock); else random. */
+int reid_debug_mfma_bare(reid_ctx* ctx, int shape, int zero, int iters, float* tflops);
 /* Operand-feed microbenchmark: rows of `rowb` bytes at `stride` from a `footprint`-byte buffer, LDS-DMA or register loads. */
 int reid_debug_feed(reid_ctx* ctx, int mode, size_t footprint, int rowb, size_t stride, int iters, int inflight,
                     float* gbs_per_cu, float* tbs_chip);

@@ -102,7 +102,7 @@ EXPORTS = tuple(sorted(_SIGS))
 
 DEBUG_LIB_PATH = os.path.join(_HERE, "libreid_hip_debug.so")
 DEBUG_EXPORTS = ("reid_debug_coissue", "reid_debug_comm_loopback", "reid_debug_conv_c64", "reid_debug_conv_split", "reid_debug_conv_diag", "reid_debug_conv_f16", "reid_debug_conv_f32",
-                 "reid_debug_feed", "reid_debug_gemm_f16", "reid_debug_knn_merge", "reid_debug_knn_wide", "reid_debug_linear", "reid_debug_linear_rows", "reid_debug_mfma_shape", "reid_debug_select_exp", "reid_debug_set_switch", "reid_debug_get_switch", "reid_debug_two_linear", "reid_debug_two_linear_ablate")   # include/reid_hip_debug.h
+                 "reid_debug_feed", "reid_debug_gemm_f16", "reid_debug_knn_merge", "reid_debug_knn_wide", "reid_debug_linear", "reid_debug_linear_rows", "reid_debug_mfma_bare", "reid_debug_mfma_shape", "reid_debug_select_exp", "reid_debug_set_switch", "reid_debug_get_switch", "reid_debug_two_linear", "reid_debug_two_linear_ablate")   # include/reid_hip_debug.h
 
 _lib = None
 _dbg = None

@@ -125,6 +125,78 @@ __global__ __launch_bounds__(512) void mfma_shape_kernel(int iters, float* __res
 
 }  // namespace
 
+// Registers-only MFMA loop: what the matrix pipe sustains on THIS device with nothing else going on - no LDS, no memory.  On random
+// operands the chip does not hold its clock under f16 MFMAs (round 5, tools/probes/overlap.hip: 1.55-1.6 PF for 32x32x16, 1.95-2.0 PF
+// for 16x16x32 against 2.3 PF on all-zero operands and 2.5 PF nominal), and devices of the pool differ by ~10 %: bench.py reports this
+// number beside the nominal peak.  512 blocks x 4 waves (two waves per SIMD), 16 independent accumulator tiles per wave.
+namespace {
+template <int SHAPE>
+__global__ __launch_bounds__(256, 2) void mfma_bare_kernel(int iters, int zero, float* __restrict__ sink) {
+    const int tid = threadIdx.x;
+    unsigned r = tid * 2654435761u + blockIdx.x * 40503u + 12345u;
+    half8mb fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            r = r * 1664525u + 1013904223u;
+            fa[i][j] = zero ? (f16mb)0.f : (f16mb)(((int)(r >> 9) & 0xffff) / 32768.0f - 1.0f);
+            r = r * 1664525u + 1013904223u;
+            fb[i][j] = zero ? (f16mb)0.f : (f16mb)(((int)(r >> 9) & 0xffff) / 32768.0f - 1.0f);
+        }
+    float total = 0.f;
+    if constexpr (SHAPE == 32) {
+        f32x16mb acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a & 1], fb[a >> 1], acc[a], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) total += acc[a][e];
+    } else {
+        typedef float f32x4mb2 __attribute__((ext_vector_type(4)));
+        f32x4mb2 acc[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) acc[a] = f32x4mb2{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int a = 0; a < 16; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a & 1], fb[(a >> 1) & 1], acc[a], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) total += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
+    }
+    if (total == 123.456f) sink[tid] = total;
+}
+}  // namespace
+
+// shape 32 (v_mfma_f32_32x32x16_f16) or 16 (v_mfma_f32_16x16x32_f16); zero != 0: all-zero operands; *tflops over ~`iters` x 16 (32) MFMAs per wave
+extern "C" int reid_debug_mfma_bare(reid_ctx* ctx, int shape, int zero, int iters, float* tflops) {
+    ARG_CHECK(ctx && tflops && (shape == 32 || shape == 16) && iters > 0);
+    CTX_GUARD(ctx);
+    float* sink;
+    REID_TRY(ctx_ws(ctx, "dbg.sink", 4096, (void**)&sink));
+    const int blocks = 512;
+    for (int rep = 0; rep < 2; ++rep) {
+        if (rep == 1) REID_TRY(reid_timer_start(ctx));
+        if (shape == 32) hipLaunchKernelGGL(mfma_bare_kernel<32>, dim3(blocks), dim3(256), 0, ctx->stream, iters, zero, sink);
+        else hipLaunchKernelGGL(mfma_bare_kernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, iters, zero, sink);
+    }
+    float ms = 0.f;
+    REID_TRY(reid_timer_stop(ctx, &ms));
+    LAUNCH_CHECK();
+    // per wave and iteration: 16 x 32x32x16 or 32 x 16x16x32 = 16 x 32768 multiply-adds
+    *tflops = (float)((double)blocks * 4 * iters * 16.0 * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e12);
+    return REID_OK;
+}
+
 // shape 32 or 16; returns TFLOP/s of the chip over a launch of `iters` 32-k steps per wave (64 x 64 wave tile, 8 waves, 256+ blocks)
 extern "C" int reid_debug_mfma_shape(reid_ctx* ctx, int shape, int iters, int blocks, float* tflops) {
     ARG_CHECK(ctx && tflops && (shape == 32 || shape == 16) && iters > 0 && blocks > 0);

@@ -350,6 +350,13 @@ class Engine:
             return v.value
         check(dbg.reid_debug_set_switch(self.h, name.encode(), C.c_longlong(int(value))))
 
+    def debug_mfma_bare(self, shape, zero=False, iters=20000):
+        """TFLOP/s of a registers-only f16 MFMA loop on this device (libreid_hip_debug.so, microbench.hip): shape 32 = 32x32x16,
+        16 = 16x16x32; random operands unless ``zero``."""
+        tf = C.c_float()
+        check(_ffi.debug_lib().reid_debug_mfma_bare(self.h, int(shape), int(bool(zero)), int(iters), C.byref(tf)))
+        return tf.value
+
     def debug_switches_from_env(self):
         """A/B tools: REID_DEBUG_SWITCHES="name=value,name=value" -> debug_switch calls (read by the TOOL, in Python)."""
         import os
