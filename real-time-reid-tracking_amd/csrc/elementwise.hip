@@ -275,6 +275,10 @@ __global__ void se_combine_kernel(const float* __restrict__ y, const float* __re
 // ---- SE gate + combine in ONE launch (SERes18_IBN.py:32-41 + :123-128): grid (slices, images).  Every block recomputes its
 // image's gate from the conv2 epilogue's partial sums exactly as se_finalize_kernel does (a few microseconds), then streams its
 // slice of the image: out = relu(gate * y + shortcut).  One launch instead of two, and enough blocks for a tracking-sized batch.
+// SMALL (a tracking frame: few blocks, the launch is its dependent chain): the gate's weights - w1 rows of this wave's hidden units, the
+// w2 column entries of this thread's channels - are requested BEFORE the pooled sums are formed, so the three phases of the gate wait
+// for one memory round trip instead of three (layer 4: 17-18 us per launch, 12 of them the gate).  Same operations in the same order.
+template <bool SMALL>
 __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ stats, int tiles, int c, int mid, int hw,
                                                       const float* __restrict__ w1, const float* __restrict__ w2,
                                                       const float* __restrict__ y, const float* __restrict__ sc, int rows,
@@ -283,6 +287,26 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
     __shared__ float hid[64];
     __shared__ __attribute__((aligned(16))) float gate[512];
     const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int MJ = SMALL ? 8 : 16, MW2 = 32;      // SMALL: mid <= 32 (the launcher checks): 8 hidden units per wave, 32 w2 entries per channel
+    f32x4 w1v[SMALL ? 8 : 1][2];
+    float w2v[SMALL ? 2 : 1][SMALL ? MW2 : 1];
+    if constexpr (SMALL) {
+        const int c4v = c >> 2;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int m = wave + 4 * j, c4 = lane + 64 * k;
+                if (m < mid && c4 < c4v) w1v[j][k] = *(const f32x4*)(w1 + (long long)m * c + c4 * 4);
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int m = 0; m < MW2; ++m) {
+                const int ch = tid + 256 * q;
+                if (ch < c && m < mid) w2v[q][m] = w2[m * c + ch];
+            }
+    }
     for (int ch = tid; ch < c; ch += 256) {
         double acc = 0.0;
         for (int t = 0; t < tiles; ++t) acc += (double)stats[(((long long)img * tiles + t) * c + ch) * 2];
@@ -296,12 +320,15 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             acc[j] = 0.f;
+            if (SMALL && j >= MJ) continue;
             const int m = wave + 4 * j;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int c4 = lane + 64 * k;
                 if (m < mid && c4 < c4v) {
-                    const f32x4 wv = *(const f32x4*)(w1 + (long long)m * c + c4 * 4);
+                    f32x4 wv;
+                    if constexpr (SMALL) wv = w1v[j < MJ ? j : 0][k];
+                    else wv = *(const f32x4*)(w1 + (long long)m * c + c4 * 4);
                     const f32x4 pv = *(const f32x4*)(pooled + c4 * 4);
                     acc[j] += wv.x * pv.x + wv.y * pv.y + wv.z * pv.z + wv.w * pv.w;
                 }
@@ -316,11 +343,25 @@ __global__ __launch_bounds__(256) void se_tail_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
-    for (int ch = tid; ch < c; ch += 256) {
-        float acc = 0.f;
+    if constexpr (SMALL) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ch = tid + 256 * q;
+            if (ch < c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int m = 0; m < MW2; ++m)
+                    if (m < mid) acc += w2v[q][m] * hid[m];
+                gate[ch] = 1.0f / (1.0f + expf(-acc));
+            }
+        }
+    } else {
+        for (int ch = tid; ch < c; ch += 256) {
+            float acc = 0.f;
 #pragma unroll 8
-        for (int m = 0; m < mid; ++m) acc += w2[m * c + ch] * hid[m];
-        gate[ch] = 1.0f / (1.0f + expf(-acc));
+            for (int m = 0; m < mid; ++m) acc += w2[m * c + ch] * hid[m];
+            gate[ch] = 1.0f / (1.0f + expf(-acc));
+        }
     }
     __syncthreads();
     const int c4n = c >> 2;
@@ -521,8 +562,14 @@ int launch_se_tail(reid_ctx* ctx, const float* stats, int n_img, int tiles, int 
     ARG_CHECK(c % 4 == 0 && c <= 512 && mid <= 64 && (out || packed));
     const int slices = tail_slices(n_img, hw);
     prof_begin(ctx, REID_K_ELEMENTWISE, 0, (double)n_img * hw * c * 12.0);
-    hipLaunchKernelGGL(se_tail_kernel, dim3(slices, n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2, y, sc,
-                       hw / slices, out, packed, ctx->fault);
+    // a tracking frame, layer 4 (64 KB of w1 + 64 KB of w2 per gate): the gate's weights requested up front, 18 -> 14 us per launch;
+    // the smaller layers' launches have more blocks than gate work and lose with it (layer 1: 16 -> 31 us)
+    if ((long long)slices * n_img <= 512 && c >= 512 && mid <= 32)
+        hipLaunchKernelGGL(se_tail_kernel<true>, dim3(slices, n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2, y, sc,
+                           hw / slices, out, packed, ctx->fault);
+    else
+        hipLaunchKernelGGL(se_tail_kernel<false>, dim3(slices, n_img), dim3(256), 0, ctx->stream, stats, tiles, c, mid, hw, w1, w2, y, sc,
+                           hw / slices, out, packed, ctx->fault);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
