@@ -89,6 +89,9 @@ def sustained_mfma(eng):
     """Registers-only f16 MFMA loops on this device (libreid_hip_debug.so: reid_debug_mfma_bare), TFLOP/s: both instruction shapes,
     random and all-zero operands.  `peak` in the roofline objects stays the nominal figure of MI355X_MICROARCH.md; this is the
     ceiling a kernel with free operands would meet on THIS device, measured in the same process."""
+    import ctypes
+    if not isinstance(eng.lib, ctypes.CDLL):      # tests/standin_lib.py: no device behind the handle
+        return None
     try:
         return {"unit": "TFLOP/s on the f16 pipe, registers only, measured in this run",
                 "random_32x32x16": round(eng.debug_mfma_bare(32, False), 1), "random_16x16x32": round(eng.debug_mfma_bare(16, False), 1),
