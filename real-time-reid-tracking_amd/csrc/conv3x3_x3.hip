@@ -374,7 +374,7 @@ template <int N>
 __device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int TW, int IMGS, int BN>
-__global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Params p) {
+__global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(const Gemm16Params p) {
     constexpr int TH = 256 / (IMGS * TW);
     constexpr int WP = TW + 2, HP = TH + 2;
     constexpr int NPX = IMGS * HP * WP;
@@ -384,10 +384,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
     constexpr int B_BYTES = BN * 64;
     constexpr int BJ = BN / 64;
     constexpr int TM = 4, TN = BN / 16;              // wave tile 64 rows x BN columns in 16 x 16 MFMA tiles
-    constexpr int G = BN == 64 ? 3 : 1;              // tiles per block barrier
-    constexpr int NS = G == 1 ? 4 : 3, LEAD = NS - 1;   // ring slots (of G weight tiles each), groups in flight
-    static_assert(2 * (2 * HALO_BYTES + NS * G * B_BYTES) <= 160 * 1024, "two blocks per CU");
-    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + NS * G * B_BYTES];
+    // BN = 128 (layers 2-4): two blocks per CU, two halo buffers, four weight slots.  BN = 64 (layer 1, form 3): FOUR blocks per CU - a
+    // layer-1 block is 54 tiles of 16 MFMAs per wave between a prologue and an epilogue that move 215 KB, so what it needs is other
+    // blocks to run under its memory phases, not prefetch depth: ONE halo buffer (a phase change waits for its halo), 38.5 KB per block
+    constexpr int NS = 4;
+    constexpr int NHB = BN == 64 ? 1 : 2;            // halo buffers
+    static_assert((BN == 64 ? 4 : 2) * (NHB * HALO_BYTES + NS * B_BYTES) <= 160 * 1024, "blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[NHB * HALO_BYTES + NS * B_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
     const int ncr_all = C / 32;
     const int ncr = ncr_all / SK, c0 = ksplit * ncr;     // real 32-channel chunks of this block: [c0, c0 + ncr)
     const int nt = ncr * 27;
-    const unsigned halo32 = (unsigned)(uintptr_t)lds, ring32 = halo32 + 2 * HALO_BYTES;
+    const unsigned halo32 = (unsigned)(uintptr_t)lds, ring32 = halo32 + NHB * HALO_BYTES;
 
     auto issue_halo_piece = [&](int q, int vchunk, int buf) {
         const int hp = q * 16 + (lane >> 2);
@@ -454,16 +457,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (G == 1) {
     auto issue_w = [&](int c, int r, int slot) {
         const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
         const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
         const int k0 = tap * p.Cin + part * C + (c0 + c) * 32;
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
-            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0), LPTR(lds + 2 * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[j] + k0), LPTR(lds + NHB * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, 0, 0);
     };
 
+    if constexpr (BN != 64) {
     for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, c0, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
@@ -542,72 +545,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
         if (++r3 == 27) { r3 = 0; ++c3; }
     }
     } else {
-    // ---- main loop at BN = 64 (layer 1): GROUPS of G = 3 tiles per block barrier - there a tile is 16 MFMAs per wave, and one barrier
-    // + DMA issue per tile cost more than the tile (751 us per launch against 697 for the 12-wave kernel).  A ring of NS slots of G weight tiles, LEAD = NS - 1 groups in flight; a chunk's 27 tiles are 18 / G groups on
-    // the xh halo (buffer 0) and 9 / G on xl' (buffer 1).  Halo pieces: xl' of this chunk during the chunk's first groups (buffer 1
-    // was last read in the previous chunk's last group), xh of the next chunk during the first groups of the xl' phase (buffer 0 was
-    // last read in the group before); every wave issues the same number per group (24 pieces cover NPI; the surplus ones repeat the
-    // last piece), so that the counted waits are uniform: 6 pieces per wave and phase, HX per group of the xh phase, HL of the xl' one.
-    constexpr int GX = 18 / G, GL = 9 / G, GC = GX + GL;             // groups per phase / chunk
-    constexpr int HX = G == 1 ? 1 : 2, HL = G == 1 ? 1 : 3;            // halo pieces per wave and group: 6 per phase in the phase's first groups
-    constexpr int NHX = 6 / HX, NHL = 6 / HL;                           // groups of a phase that carry halo pieces
-    // a halo piece must have left the window of the counted wait (the pieces of the last LEAD - 1 iterations may be in flight) before
-    // its buffer is read: the last group that issues one lies at least LEAD groups before the phase that reads it
-    static_assert(NHX - 1 <= GX - LEAD && GX + NHL - 1 <= GC - LEAD, "halo pieces land before their phase starts");
-    const int nu = ncr * GC;
-    auto issue_group = [&](int cc, int gg, int slot) {                 // group gg of chunk cc: tiles r = gg * G .. + G
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int r = gg * G + j;
-            const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
-            const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
-            const int k0 = tap * p.Cin + part * C + (c0 + cc) * 32;
-#pragma unroll
-            for (int jj = 0; jj < BJ; ++jj)
-                __builtin_amdgcn_global_load_lds(GPTR(p.B + b_base[jj] + k0), LPTR(lds + 2 * HALO_BYTES + (slot * G + j) * B_BYTES + (wm * BJ + jj) * 1024), 16, 0, 0);
-        }
-    };
-    for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, c0, 0);
-    {
-        int cc = 0, gg = 0;
-        for (int v = 0; v < LEAD; ++v) {
-            issue_group(cc, gg, v);
-            if (++gg == GC) { gg = 0; ++cc; }
-        }
-    }
-    int c = 0, g = 0, cl = LEAD / GC, gl = LEAD % GC, hist[LEAD > 1 ? LEAD - 1 : 1] = {0};
-    for (int u = 0; u < nu; ++u) {
-        // in-order landing: all but the pieces of the last LEAD - 1 iterations (groups u + 1 .. and their halo pieces) have landed
-        int allow = 0;
-#pragma unroll
-        for (int i = 0; i < LEAD - 1; ++i) allow += G * BJ + hist[i];
-        wait_vm(u - 1 + LEAD < nu ? allow : 0);
-        RAW_BARRIER();              // ... every wave's share; every wave has finished group u - 1: its slot and halo buffer are free
-        if (u + LEAD < nu) issue_group(cl, gl, (u + LEAD) % NS);
-        int hh = 0;
-        if (g < NHX) {
-#pragma unroll
-            for (int k = 0; k < HX; ++k) {
-                const int q = (g * HX + k) * 4 + wm;
-                issue_halo_piece(q < NPI ? q : NPI - 1, ncr_all + c0 + c, 1);
+        // ---- BN = 64: one halo buffer.  Per chunk: xh (18 tiles), then xl' (9 tiles); a phase starts with barrier (every wave has read
+        // the old halo), this wave's six halo pieces, vmcnt(0); inside a phase only the weight ring is in flight (counted waits)
+        issue_w(0, 0, 0);
+        issue_w(0, 1, 1);
+        issue_w(0, 2, 2);
+        int c = 0, r = 0, c3 = 0, r3 = 3;
+        for (int t = 0; t < nt; ++t) {
+            const bool phase_start = r == 0 || r == 18;
+            if (phase_start) {
+                if (t > 0) RAW_BARRIER();
+                const int vch = r == 0 ? c0 + c : ncr_all + c0 + c;
+                for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, vch, 0);
             }
-            hh = HX;
-        } else if (g >= GX && g < GX + NHL) {
-            const int cn = c + 1 < ncr ? c + 1 : c;                    // after the last chunk: the same chunk again, read by nobody
-#pragma unroll
-            for (int k = 0; k < HL; ++k) {
-                const int q = ((g - GX) * HL + k) * 4 + wm;
-                issue_halo_piece(q < NPI ? q : NPI - 1, c0 + cn, 0);
-            }
-            hh = HL;
-        }
-#pragma unroll
-        for (int j = 0; j < G; ++j) {   // ---- tile r = g * G + j of chunk c: one MFMA deep; 4 A + TN B fragments requested up front
-            const int r = g * G + j;
+            wait_vm((phase_start || t + 2 >= nt) ? 0 : 2 * BJ);
+            RAW_BARRIER();
+            if (t + 3 < nt) issue_w(c3, r3, (t + 3) & 3);
+        {   // ---- tile (c, r): one MFMA deep; 4 A + TN B fragments, all requested up front, waits counted per MFMA row
             const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
             const int ty = tap / 3, tx = tap - ty * 3;
-            const unsigned abuf = halo32 + (r >= 18 ? HALO_BYTES : 0);
-            const unsigned ba = bx + (unsigned)(((u % NS) * G + j) * B_BYTES);
+            const unsigned abuf = halo32;
+            const unsigned ba = bx + (unsigned)((t & 3) * B_BYTES);
             half8 fa[TM], fb[TN];
             unsigned aa[TM];
 #pragma unroll
@@ -659,12 +617,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3m16_kernel(const Gemm16Param
 #undef MMA
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int i = LEAD - 2; i > 0; --i) hist[i] = hist[i - 1];
-        if (LEAD > 1) hist[0] = hh;
-        if (++g == GC) { g = 0; ++c; }
-        if (++gl == GC) { gl = 0; ++cl; }
-    }
+            if (++r == 27) { r = 0; ++c; }
+            if (++r3 == 27) { r3 = 0; ++c3; }
+        }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (inline asm: hipcc does not count their wait states)
     __syncthreads();
@@ -802,7 +757,8 @@ template <int TW, int IMGS>
 int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
     const int nmt = (p.M + 255) / 256;
-    const bool wide = p.N % 128 == 0;
+    // 64-wide tiles (four blocks per CU): layer 1 always; switch x3_narrow: bit 0 = also the 16-wide maps (layer 2: default), bit 1 = the 8-wide ones
+    const bool wide = p.N % 128 == 0 && !((TW == 16 && (ctx->x3_narrow & 1)) || (TW == 8 && (ctx->x3_narrow & 2)));
     const int tiles = nmt * (wide ? p.N / 128 : p.N / 64);
     // few output tiles (a tracking frame): split the real 32-channel chunks over sk blocks per tile, up to two blocks for every CU
     const int ncr = p.Cin / 3 / 32;
@@ -820,7 +776,7 @@ int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
         p.split_k = 1;
     }
     if (wide) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
-    else if constexpr (TW == 32) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     return REID_OK;
 }
 
@@ -836,9 +792,9 @@ void launch_x3(reid_ctx* ctx, const Gemm16Params& p) {
 // Large launches only (at least two blocks for every CU): a tracking frame keeps conv3x3_f16.hip's split-K forms.
 bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p) {
     if (!ctx->split_x3 || p.split_terms != 3 || p.Cin % 96 != 0 || p.N % 64 != 0 || p.M % 128 != 0 || !conv3x3_f16_supported(p)) return false;
-    // 64-wide tiles (layer 1, 32-wide maps only): form 3.  Measured at 1024 crops: 666 us per launch against 652 for the 12-wave kernel
-    // - layer 1 moves 1.3-1.6 GB per convolution for 0.31 ms of matrix pipe and is bound by neither alone -, so it stays there
-    if (p.N % 128 != 0 && (p.W != 32 || ctx->split_x3 < 3)) return false;
+    // 64-wide tiles exist for the 32-wide maps (layer 1) only, in form 3: four blocks per CU, one halo buffer.  Measured at 1024 crops:
+    // 570 us per launch against 729 for the 12-wave kernel (and 666 for a two-blocks-per-CU form with groups of three taps per barrier)
+    if (p.N % 128 != 0 && ctx->split_x3 < 3) return false;
     const long long blocks = (long long)((p.M + 255) / 256) * (p.N % 128 == 0 ? p.N / 128 : p.N / 64);
     return blocks >= ctx->split_x3_min_blocks || (ctx->split_x3_small && ctx->split_x3 >= 2);   // small launches: split-K forms of the 16x16x32 kernel
 }

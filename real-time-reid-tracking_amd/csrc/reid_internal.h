@@ -371,10 +371,12 @@ struct reid_ctx {
     int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
     int pack_epilogue = 1;   // precision 2: conv1 epilogues write [yh | yl'] for conv2 themselves (REID_PACK_EPILOGUE=0: fp32 + pack passes)
     int split_lean_epi = 1;  // precision 2: buffer-instruction epilogue of the SPLIT convolution builds (REID_SPLIT_LEAN=0: general loop)
-    int split_x3 = 2;        // precision 2, large launches: the two-blocks-per-CU form of the halo convolution (conv3x3_x3.hip): 2 = on
-                             // v_mfma_f32_16x16x32_f16 for the 128-wide tiles (default), 3 = and the 64-wide ones (layer 1), 1 = on 32x32x16;
-                             // 0: conv3x3_f16.hip
+    int split_x3 = 3;        // precision 2, large launches: conv3x3_x3.hip instead of conv3x3_f16.hip's 12-wave kernel: 3 (default) = on
+                             // v_mfma_f32_16x16x32_f16, two blocks per CU for the 128-wide tiles (layers 2-4) and FOUR for the 64-wide ones
+                             // (layer 1); 2 = the 128-wide tiles only; 1 = the first form on 32x32x16; 0 = off
     int split_x3_small = 0;  // ... and small launches too (a tracking frame), K split over up to 8 blocks per tile
+    int x3_narrow = 1;       // conv3x3_x3.hip, 64-wide tiles (four blocks per CU) beyond layer 1: bit 0 = the 16-wide maps (layer 2: 14.03 -> 13.87 ms per
+                             // 1024-crop pass; default), bit 1 = the 8-wide ones (layers 3-4: 14.03 -> 14.70, off)
     int x3_ablate = 0;       // timing experiments on conv3x3_x3.hip (debug switch; WRONG results while set)
     int split_x3_min_blocks = 512;   // ... from this many blocks on (two for every CU)
     int split_pair = 0;      // precision 2, 128-wide halo tiles (REID_SPLIT_PAIR): 0 = three passes over the virtual channels (default),

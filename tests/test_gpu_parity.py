@@ -134,9 +134,9 @@ def _seres18_fixture_check(eng, golden_dir, tag, crops_fn, precision=0):
 @pytest.mark.parametrize("form", [1, 2, 3])
 @pytest.mark.parametrize("tag,crops_fn", [("seed0", synth.crops_u8), ("smooth1", synth.smooth_crops_u8)])
 def test_two_blocks_per_cu_convolution_matches_reference_fixture(eng, golden_dir, tag, crops_fn, form):
-    """csrc/conv3x3_x3.hip - the fp32-class 3x3 convolution of LARGE launches (two 4-wave blocks per CU; form 2, the default, on
-    v_mfma_f32_16x16x32_f16 with 64-byte-row LDS images, form 1 on 32x32x16, form 3 = form 2 with layer 1's 64-wide tiles in groups
-    of three taps per barrier) - forced onto the fixture's small batch (debug switch split_x3_min_blocks = 1), against the
+    """csrc/conv3x3_x3.hip - the fp32-class 3x3 convolution of LARGE launches (4-wave blocks, several per CU; form 3, the default: on
+    v_mfma_f32_16x16x32_f16 with 64-byte-row LDS images, two blocks per CU for the 128-wide tiles and four - one halo buffer - for
+    layer 1's 64-wide ones; form 2 = the 128-wide tiles only; form 1 on 32x32x16) - forced onto the fixture's small batch (debug switch split_x3_min_blocks = 1), against the
     REFERENCE's stage taps, embeddings and logits at the exact-fp32 mode's thresholds (SERes18_IBN.py:120-128,250-276); the
     full-size configs[1] test runs it at its own launch sizes.  Another summation order than conv3x3_f16.hip's (per 32-channel
     chunk: xh.wh 2^11, xh.wl', xl'.wh), the same three products."""
@@ -156,7 +156,7 @@ def test_two_blocks_per_cu_convolution_matches_reference_fixture(eng, golden_dir
         eng.debug_switch("split_x3", form)
         assert np.array_equal(eng.embed_u8(crops[:1]), got[:1]) and np.array_equal(eng.embed_u8(crops[2:5]), got[2:5])   # images are independent
     finally:
-        eng.debug_switch("split_x3", 2)
+        eng.debug_switch("split_x3", 3)
         eng.debug_switch("split_x3_min_blocks", 512)
         eng.set_precision(0)
 

@@ -3,7 +3,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r5
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for v in 0 2; do
+for v in 2 3; do
   export REID_DEBUG_SWITCHES=split_x3=$v
   rocprofv3 --kernel-trace --stats -d $OUT/x3_trace_$v -o p -- python3 $ROOT/tools/time_pass.py 2 1024 > $OUT/x3_trace_$v.log 2>&1
   python3 $ROOT/tools/rocprof_summary.py $OUT/x3_trace_$v/p_results.db 16 > $OUT/x3_stats_$v.csv
