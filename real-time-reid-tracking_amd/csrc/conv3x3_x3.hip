@@ -18,6 +18,7 @@
 #include "reid_internal.h"
 #include "conv3x3_geom.h"
 #include <type_traits>
+#include <utility>
 
 typedef _Float16 f16;
 typedef f16 half8 __attribute__((ext_vector_type(8)));
@@ -373,6 +374,146 @@ __device__ __forceinline__ int pi16(int i) { return i < 8 ? i : (i < 12 ? i + 4 
 template <int N>
 __device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Everything behind the main loop of the 16x16x32 kernels: split-K reduction (last arriver), fp32 epilogue, statistics.
+template <int TW, int IMGS, int BN>
+__device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4][BN / 16], char* lds, int tid, int wm, int mtile, int n_blk,
+                                           int tile_id, int ksplit, int SK) {
+    constexpr int TM = 4, TN = BN / 16;
+    const int lane = tid & 63;
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int pj = pi16(l16);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (inline asm: hipcc does not count their wait states)
+    __syncthreads();
+
+    if (SK > 1) {
+        // partial tile in register order [TM * TN * 4][256 lanes]: coalesced both ways.  Device-scope (sc1) stores are written through
+        // to the point all XCDs share and the loads below bypass this XCD's L2: no L2 write-back / invalidate fence (conv3x3_f16.hip)
+        constexpr int PART = 256 * BN;
+        float* part = p.splitk_ws + (long long)tile_id * SK * PART;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __hip_atomic_store(part + (long long)ksplit * PART + ((a * TN + b) * 4 + e) * 256 + tid, acc[a][b][e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)lds;
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = old == SK - 1;
+            if (old == SK - 1) __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        if (!*flag) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < SK; ++sidx)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[a][b][e] += __hip_atomic_load(part + (long long)sidx * PART + ((a * TN + b) * 4 + e) * 256 + tid, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();   // the flag word is about to be overwritten by the statistics
+    }
+
+    if (p.ablate & 32) return;
+    // ------------------------------------------------------------------ fp32 epilogue: the arithmetic of conv3x3_f16.hip's SPLIT
+    // build per element (BN scale x 2^-11 + shift, + fp32 residual, ReLU from relu_from on, fp32 or [yh | yl'] stores, per-128-row
+    // column sums).  Lane: column PI(l16) of the 16-column tile, rows 4 PQ(lq) + reg of the 16-row tile (PQ = quads 2 and 3 swapped)
+    const int ldc = (int)p.ldc;
+    const int m_blk = mtile * 256;
+    const int m_valid = p.M - m_blk;
+    const bool wave_live = m_valid >= 256 || wm < 2;         // M % 128 == 0: a ragged tile has 128 rows, those of waves 0, 1
+    const int pq = lq < 2 ? lq : 5 - lq;
+    const int lrow = TW == 8 ? (pq < 2 ? 4 * pq : 32 + 4 * (pq - 2)) : 4 * pq;     // lane part of the natural row
+    const int col0 = n_blk + pj;
+    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C32 + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((p.res32 ? p.res32 : p.C32) + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t k_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((p.pack16 ? p.pack16 : (f16*)p.C32) + (long long)m_blk * 2 * p.N), 0, 256 * 2 * p.N * 2, 0x00020000);
+    const int voff = (lrow * ldc + col0) * 4;
+    const int koff = (lrow * 2 * p.N + col0) * 2;
+    float vmax = 0.f;
+    float s1[TN], s2[TN];
+    auto run = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = col0 + b * 16;
+            const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
+            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
+            const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
+            const bool pk = p.pack16 && col >= p.pack_from;      // uniform per 16-column tile (pack_from % 32 == 0)
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int ubase = wm * 64 + (TW == 8 ? a * 8 : a * 16);          // uniform part of the natural row
+                float rr[4];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        rr[e] = wave_live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff + b * 64, (ubase + e) * ldc * 4, 0)) : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[a][b][e] * cs + sh;
+                    v += RES ? rr[e] : 0.f;
+                    v = fmaxf(v, lo);
+                    if (wave_live) {
+                        t1 += v;
+                        t2 += v * v;
+                        if (pk) {
+                            vmax = fmaxf(vmax, fabsf(v));
+                            const f16 hv = (f16)v;
+                            const f16 lv = (f16)((v - (float)hv) * 2048.0f);
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), k_rs, koff + b * 32, (ubase + e) * 2 * p.N * 2, 0);
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lv), k_rs, koff + b * 32 + p.N * 2, (ubase + e) * 2 * p.N * 2, 0);
+                        } else if (!(p.ablate & 64)) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff + b * 64, (ubase + e) * ldc * 4, 0);
+                        }
+                    }
+                }
+            }
+            s1[b] = t1;
+            s2[b] = t2;
+        }
+    };
+    if (p.res32) run(std::true_type{});
+    else run(std::false_type{});
+    if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;
+    if (p.stats) {   // per 128 natural rows: waves 0,1 own rows 0..127, waves 2,3 rows 128..255
+        float* stat_lds = (float*)lds;  // [4][BN][2]
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int lcol = b * 16 + pj;
+            float t1 = s1[b], t2 = s2[b];
+            t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+            if (lq == 0) {
+                stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
+                stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int half = t / BN, cc = t - half * BN;
+            if (half * 128 >= m_valid) continue;
+            float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + cc) * 2;
+            o[0] = stat_lds[((half * 2) * BN + cc) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 0];
+            o[1] = stat_lds[((half * 2) * BN + cc) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 1];
+        }
+    }
+}
+
 template <int TW, int IMGS, int BN>
 __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(const Gemm16Params p) {
     constexpr int TH = 256 / (IMGS * TW);
@@ -621,136 +762,194 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(co
             if (++r3 == 27) { r3 = 0; ++c3; }
         }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (inline asm: hipcc does not count their wait states)
-    __syncthreads();
+    x3m16_tail<TW, IMGS, BN>(p, acc, lds, tid, wm, mtile, n_blk, tile_id, ksplit, SK);
+}
 
-    if (SK > 1) {
-        // partial tile in register order [TM * TN * 4][256 lanes]: coalesced both ways.  Device-scope (sc1) stores are written through
-        // to the point all XCDs share and the loads below bypass this XCD's L2: no L2 write-back / invalidate fence (conv3x3_f16.hip)
-        constexpr int PART = 256 * BN;
-        float* part = p.splitk_ws + (long long)tile_id * SK * PART;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    __hip_atomic_store(part + (long long)ksplit * PART + ((a * TN + b) * 4 + e) * 256 + tid, acc[a][b][e], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = (int*)lds;
-        if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = old == SK - 1;
-            if (old == SK - 1) __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        }
-        __syncthreads();
-        if (!*flag) return;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int sidx = 0; sidx < SK; ++sidx)
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[a][b][e] += __hip_atomic_load(part + (long long)sidx * PART + ((a * TN + b) * 4 + e) * 256 + tid, __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();   // the flag word is about to be overwritten by the statistics
+// ------------------------------------------------------------------------------------------------------------------------------
+// The 128-wide form with the chunk's 27 tiles UNROLLED.  Why: PMC of conv3x3_x3m16_kernel<8,2,128> (profiles/r05_pmc_waits.txt): matrix
+// pipe busy 0.51 of the cycles at 2.27 GHz, no LDS bank conflict - and its loop spends ~60 vector + ~80 scalar instructions per tile
+// beside 32 MFMAs of 16 cycles each (tap / part decode with a division by three, four A addresses with their swizzle, 64-bit
+// source addresses per DMA piece, the halo piece's pixel -> (image, y, x) divisions): as many issue cycles as the MFMAs take.
+// With the step index a compile-time constant: the A fragment addresses of the nine taps are 36 registers made once (the halo
+// buffer is an instruction offset), DMA pieces go through buffer descriptors with per-lane offsets made once (six halo pieces and
+// BJ weight pieces per wave; padding = an offset past the descriptor, which the DMA writes as zeros - as conv_f32.hip does) and
+// the step's tap / part / channel offset in the SCALAR operand, waits are immediates.  Same tiles, same order, same arithmetic as
+// conv3x3_x3m16_kernel: bit-identical results.
+template <class F, int... Rs>
+__device__ __forceinline__ void for_each_step(F&& f, std::integer_sequence<int, Rs...>) { (f(std::integral_constant<int, Rs>{}), ...); }
+
+constexpr int x3_halo_step(int r) {                 // does step r (mod 27) of a chunk issue a halo piece?
+    r = ((r % 27) + 27) % 27;
+    return (r < 6 || (r >= 18 && r < 24)) ? 1 : 0;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TW, int IMGS, int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_x3u_kernel(const Gemm16Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-descriptor builtins exist in the device pass only)
+    static_assert(BN == 128, "the unrolled form exists for the 128-wide tiles");
+    constexpr int TH = 256 / (IMGS * TW);
+    constexpr int WP = TW + 2, HP = TH + 2;
+    constexpr int NPX = IMGS * HP * WP;
+    constexpr int NPI = (NPX + 15) / 16;
+    static_assert(NPI <= 24, "one halo piece per wave and step over six steps");
+    constexpr int HALO_BYTES = NPI * 1024;
+    constexpr int B_BYTES = BN * 64;
+    constexpr int BJ = BN / 64;
+    constexpr int TM = 4, TN = BN / 16;
+    constexpr int NS = 4;
+    static_assert(2 * (2 * HALO_BYTES + NS * B_BYTES) <= 160 * 1024, "two blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + NS * B_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int nnt = p.N / BN;
+    const int SK = p.split_k > 1 ? p.split_k : 1;
+    int mtile, ntile, tile_id, ksplit;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        tile_id = L / SK;
+        ksplit = L - tile_id * SK;
+        mtile = tile_id / nnt;
+        ntile = tile_id - mtile * nnt;
     }
+    const int n_blk = ntile * BN;
+    const int tiles_per_img = p.H / TH;
+    const int img0 = IMGS == 2 ? mtile * 2 : mtile / tiles_per_img;
+    const int y0 = IMGS == 2 ? 0 : (mtile - img0 * tiles_per_img) * TH;
+    const int n_img = p.M / (p.H * p.W);
+    const int C = p.Cin / 3;
+    const int a_cin = 2 * C;
+    const int ncr_all = C / 32;
+    const int ncr = ncr_all / SK, c0 = ksplit * ncr;
+    const unsigned halo32 = (unsigned)(uintptr_t)lds, ring32 = halo32 + 2 * HALO_BYTES;
 
-    if (p.ablate & 32) return;
-    // ------------------------------------------------------------------ fp32 epilogue: the arithmetic of conv3x3_f16.hip's SPLIT
-    // build per element (BN scale x 2^-11 + shift, + fp32 residual, ReLU from relu_from on, fp32 or [yh | yl'] stores, per-128-row
-    // column sums).  Lane: column PI(l16) of the 16-column tile, rows 4 PQ(lq) + reg of the 16-row tile (PQ = quads 2 and 3 swapped)
-    const int ldc = (int)p.ldc;
-    const int m_blk = mtile * 256;
-    const int m_valid = p.M - m_blk;
-    const bool wave_live = m_valid >= 256 || wm < 2;         // M % 128 == 0: a ragged tile has 128 rows, those of waves 0, 1
-    const int pq = lq < 2 ? lq : 5 - lq;
-    const int lrow = TW == 8 ? (pq < 2 ? 4 * pq : 32 + 4 * (pq - 2)) : 4 * pq;     // lane part of the natural row
-    const int col0 = n_blk + pj;
-    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C32 + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((p.res32 ? p.res32 : p.C32) + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t k_rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((p.pack16 ? p.pack16 : (f16*)p.C32) + (long long)m_blk * 2 * p.N), 0, 256 * 2 * p.N * 2, 0x00020000);
-    const int voff = (lrow * ldc + col0) * 4;
-    const int koff = (lrow * 2 * p.N + col0) * 2;
-    float vmax = 0.f;
-    float s1[TN], s2[TN];
-    auto run = [&](auto res_c) {
-        constexpr bool RES = decltype(res_c)::value;
+    // ---- descriptors and per-lane offsets, made once
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((long long)n_img * p.H * p.W * a_cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((long long)p.N * p.ldb * 2), 0x00020000);
+    int hv[6];                                        // this wave's halo pieces k = 0 .. 5: piece q = 4 k + wave (the surplus ones repeat the last)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int col = col0 + b * 16;
-            const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
-            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
-            const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
-            const bool pk = p.pack16 && col >= p.pack_from;      // uniform per 16-column tile (pack_from % 32 == 0)
-            float t1 = 0.f, t2 = 0.f;
+    for (int k = 0; k < 6; ++k) {
+        const int q = k * 4 + wm < NPI ? k * 4 + wm : NPI - 1;
+        const int hp = q * 16 + (lane >> 2);
+        const int im = hp / (HP * WP), rem = hp - im * (HP * WP);
+        const int hy = rem / WP, hx = rem - hy * WP;
+        const int gy = y0 - 1 + hy, gx = hx - 1, gi = img0 + im;
+        const bool ok = hp < NPX && gi < n_img && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const int cg = (lane & 3) ^ (((hp >> 3) & 1) << 1);
+        hv[k] = ok ? (int)(((((long long)gi * p.H + gy) * p.W + gx) * a_cin + cg * 8) * 2) : 0x7fffff00;   // past the descriptor: zeros
+    }
+    int wv[BJ];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int ubase = wm * 64 + (TW == 8 ? a * 8 : a * 16);          // uniform part of the natural row
-                float rr[4];
-                if constexpr (RES) {
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (wm * BJ + j) * 16 + (lane >> 2);
+        const int cg = (lane & 3) ^ (((row >> 3) & 1) << 1);
+        wv[j] = (int)((((long long)(n_blk + row) * p.ldb) + cg * 8) * 2);
+    }
+    const int pj = pi16(l16);
+    unsigned aa[9][TM];                               // A fragment address of (tap, 16-row tile) in halo buffer 0
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        rr[e] = wave_live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff + b * 64, (ubase + e) * ldc * 4, 0)) : 0.f;
-                }
+    for (int a = 0; a < TM; ++a) {
+        int h0;
+        if constexpr (TW == 32) h0 = (2 * wm + (a >> 1)) * WP + 16 * (a & 1) + pj;
+        else if constexpr (TW == 16) h0 = (4 * wm + a) * WP + pj;
+        else h0 = (wm >> 1) * HP * WP + ((wm & 1) * 8 + a + 4 * (pj >> 3)) * WP + (pj & 7);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[a][b][e] * cs + sh;
-                    v += RES ? rr[e] : 0.f;
-                    v = fmaxf(v, lo);
-                    if (wave_live) {
-                        t1 += v;
-                        t2 += v * v;
-                        if (pk) {
-                            vmax = fmaxf(vmax, fabsf(v));
-                            const f16 hv = (f16)v;
-                            const f16 lv = (f16)((v - (float)hv) * 2048.0f);
-                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), k_rs, koff + b * 32, (ubase + e) * 2 * p.N * 2, 0);
-                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lv), k_rs, koff + b * 32 + p.N * 2, (ubase + e) * 2 * p.N * 2, 0);
-                        } else if (!(p.ablate & 64)) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff + b * 64, (ubase + e) * ldc * 4, 0);
-                        }
-                    }
-                }
-            }
-            s1[b] = t1;
-            s2[b] = t2;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int hp = h0 + (tap / 3) * WP + tap % 3;
+            aa[tap][a] = halo32 + hp * 64 + ((lq ^ (((hp >> 3) & 1) << 1)) * 16);
         }
+    }
+    const unsigned bx = ring32 + pj * 64 + ((lq ^ (((pj >> 3) & 1) << 1)) * 16);
+    const int cin2 = p.Cin * 2, c2 = C * 2;           // bytes per tap / per weight part of a weight row
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue_w = [&](int cc, int r, int slot) __attribute__((always_inline)) {   // weight tile of step r of chunk cc (r compile-time at the call sites)
+        const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
+        const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+        const int soff = tap * cin2 + part * c2 + (c0 + cc) * 64;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, LPTR(lds + 2 * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, wv[j], soff, 0, 0);
     };
-    if (p.res32) run(std::true_type{});
-    else run(std::false_type{});
-    if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;
-    if (p.stats) {   // per 128 natural rows: waves 0,1 own rows 0..127, waves 2,3 rows 128..255
-        float* stat_lds = (float*)lds;  // [4][BN][2]
+    auto issue_halo = [&](int k, int vchunk, int buf) __attribute__((always_inline)) {
+        const int q = k * 4 + wm < NPI ? k * 4 + wm : NPI - 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(lds + buf * HALO_BYTES + q * 1024), 16, hv[k], vchunk * 64, 0, 0);
+    };
+
+    // ---- prologue: xh of the first chunk, weight tiles of steps 0 .. 2
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int lcol = b * 16 + pj;
-            float t1 = s1[b], t2 = s2[b];
-            t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
-            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
-            if (lq == 0) {
-                stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
-                stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
+    for (int k = 0; k < 6; ++k) issue_halo(k, c0, 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    issue_w(0, 2, 2);
+
+    for (int c = 0; c < ncr; ++c) {
+        const int tb = c * 27;
+        const bool last = c + 1 == ncr;
+        for_each_step([&](auto RC) __attribute__((always_inline)) {
+            constexpr int r = decltype(RC)::value;
+            // in-order landing: all but the pieces of the last two steps have landed (conv3x3_x3m16_kernel)
+            constexpr int allow = 2 * BJ + x3_halo_step(r - 1) + x3_halo_step(r - 2);
+            if constexpr (r + 2 >= 27) {
+                if (last) wait_vm_imm<0>(); else wait_vm_imm<allow>();
+            } else {
+                wait_vm_imm<allow>();
             }
-        }
-        __syncthreads();
-        for (int t = tid; t < 2 * BN; t += 256) {
-            const int half = t / BN, cc = t - half * BN;
-            if (half * 128 >= m_valid) continue;
-            float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + cc) * 2;
-            o[0] = stat_lds[((half * 2) * BN + cc) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 0];
-            o[1] = stat_lds[((half * 2) * BN + cc) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 1];
-        }
+            RAW_BARRIER();
+            if constexpr (r + 3 < 27) issue_w(c, r + 3, (tb + r + 3) & 3);
+            else if (!last) issue_w(c + 1, r + 3 - 27, (tb + r + 3) & 3);
+            if constexpr (r < 6) issue_halo(r, ncr_all + c0 + c, 1);
+            if constexpr (r >= 18 && r < 24) issue_halo(r - 18, c0 + (last ? c : c + 1), 0);
+            constexpr int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+            constexpr int hoff = r >= 18 ? HALO_BYTES : 0;
+            const unsigned ba = bx + (unsigned)(((tb + r) & 3) * B_BYTES);
+            half8 fa[TM], fb[TN];
+            LDS_READ(fa[0], aa[tap][0], hoff);
+            LDS_READ(fb[0], ba, 0);
+            LDS_READ(fb[1], ba, 1024);
+            LDS_READ(fb[2], ba, 2048);
+            LDS_READ(fb[3], ba, 3072);
+            LDS_READ(fb[4], ba, 4096);
+            LDS_READ(fb[5], ba, 5120);
+            LDS_READ(fb[6], ba, 6144);
+            LDS_READ(fb[7], ba, 7168);
+            LDS_READ(fa[1], aa[tap][1], hoff);
+            LDS_READ(fa[2], aa[tap][2], hoff);
+            LDS_READ(fa[3], aa[tap][3], hoff);
+            constexpr int NRD = TM + TN;
+#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fa[a]), "v"(fb[b]))
+#define MM0(b)                                   \
+    do {                                         \
+        lgkm_wait1<NRD - 2 - (b)>(fb[b]);        \
+        MMA(0, b);                               \
+    } while (0)
+            lgkm_wait1<NRD - 1>(fa[0]);
+            MM0(0); MM0(1); MM0(2); MM0(3); MM0(4); MM0(5); MM0(6); MM0(7);
+            lgkm_wait1<2>(fa[1]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(1, b);
+            lgkm_wait1<1>(fa[2]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(2, b);
+            lgkm_wait1<0>(fa[3]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(3, b);
+#undef MM0
+#undef MMA
+        }, std::make_integer_sequence<int, 27>{});
     }
+    x3m16_tail<TW, IMGS, BN>(p, acc, lds, tid, wm, mtile, n_blk, tile_id, ksplit, SK);
+#endif
 }
 
 template <int TW, int IMGS>
@@ -775,7 +974,10 @@ int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
     } else {
         p.split_k = 1;
     }
-    if (wide) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    // the unrolled form reaches the input through a 32-bit buffer descriptor with 0x7fffff00 as "outside"
+    const bool unrolled = ctx->x3_unroll && (long long)p.M * (p.Cin / 3) * 4 < 0x7f000000ll && (long long)p.N * p.ldb * 2 < 0x7f000000ll;
+    if (wide && unrolled) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    else if (wide) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     else hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     return REID_OK;
 }
