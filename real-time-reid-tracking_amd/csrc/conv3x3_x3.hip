@@ -786,10 +786,10 @@ constexpr int x3_halo_step(int r) {                 // does step r (mod 27) of a
 template <int N>
 __device__ __forceinline__ void wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TW, int IMGS, int BN>
-__global__ __launch_bounds__(256, 2) void conv3x3_x3u_kernel(const Gemm16Params p) {
+template <int TW, int IMGS, int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (buffer-descriptor builtins exist in the device pass only)
-    static_assert(BN == 128, "the unrolled form exists for the 128-wide tiles");
+    static_assert((BN == 128 && OCC == 2) || (BN == 64 && (OCC == 3 || OCC == 4)), "128-wide: two blocks per CU, two halo buffers; 64-wide: one halo buffer");
     constexpr int TH = 256 / (IMGS * TW);
     constexpr int WP = TW + 2, HP = TH + 2;
     constexpr int NPX = IMGS * HP * WP;
@@ -800,8 +800,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3u_kernel(const Gemm16Params 
     constexpr int BJ = BN / 64;
     constexpr int TM = 4, TN = BN / 16;
     constexpr int NS = 4;
-    static_assert(2 * (2 * HALO_BYTES + NS * B_BYTES) <= 160 * 1024, "two blocks per CU");
-    __shared__ __attribute__((aligned(16))) char lds[2 * HALO_BYTES + NS * B_BYTES];
+    constexpr int NHB = BN == 64 ? 1 : 2;
+    static_assert(OCC * (NHB * HALO_BYTES + NS * B_BYTES) <= 160 * 1024, "blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[NHB * HALO_BYTES + NS * B_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3u_kernel(const Gemm16Params 
     const int a_cin = 2 * C;
     const int ncr_all = C / 32;
     const int ncr = ncr_all / SK, c0 = ksplit * ncr;
-    const unsigned halo32 = (unsigned)(uintptr_t)lds, ring32 = halo32 + 2 * HALO_BYTES;
+    const unsigned halo32 = (unsigned)(uintptr_t)lds, ring32 = halo32 + NHB * HALO_BYTES;
 
     // ---- descriptors and per-lane offsets, made once
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((long long)n_img * p.H * p.W * a_cin * 2), 0x00020000);
@@ -879,16 +880,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3u_kernel(const Gemm16Params 
         const int soff = tap * cin2 + part * c2 + (c0 + cc) * 64;
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, LPTR(lds + 2 * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, wv[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, LPTR(lds + NHB * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, wv[j], soff, 0, 0);
     };
     auto issue_halo = [&](int k, int vchunk, int buf) __attribute__((always_inline)) {
         const int q = k * 4 + wm < NPI ? k * 4 + wm : NPI - 1;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(lds + buf * HALO_BYTES + q * 1024), 16, hv[k], vchunk * 64, 0, 0);
     };
 
-    // ---- prologue: xh of the first chunk, weight tiles of steps 0 .. 2
+    // ---- prologue: xh of the first chunk (two halo buffers; with one, every phase loads its halo at its start), weight tiles of steps 0 .. 2
+    if constexpr (NHB == 2) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) issue_halo(k, c0, 0);
+        for (int k = 0; k < 6; ++k) issue_halo(k, c0, 0);
+    }
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
     issue_w(0, 2, 2);
@@ -898,20 +901,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3u_kernel(const Gemm16Params 
         const bool last = c + 1 == ncr;
         for_each_step([&](auto RC) __attribute__((always_inline)) {
             constexpr int r = decltype(RC)::value;
-            // in-order landing: all but the pieces of the last two steps have landed (conv3x3_x3m16_kernel)
-            constexpr int allow = 2 * BJ + x3_halo_step(r - 1) + x3_halo_step(r - 2);
-            if constexpr (r + 2 >= 27) {
-                if (last) wait_vm_imm<0>(); else wait_vm_imm<allow>();
+            if constexpr (NHB == 2) {
+                // in-order landing: all but the pieces of the last two steps have landed (conv3x3_x3m16_kernel)
+                constexpr int allow = 2 * BJ + x3_halo_step(r - 1) + x3_halo_step(r - 2);
+                if constexpr (r + 2 >= 27) {
+                    if (last) wait_vm_imm<0>(); else wait_vm_imm<allow>();
+                } else {
+                    wait_vm_imm<allow>();
+                }
+                RAW_BARRIER();
+                if constexpr (r + 3 < 27) issue_w(c, r + 3, (tb + r + 3) & 3);
+                else if (!last) issue_w(c + 1, r + 3 - 27, (tb + r + 3) & 3);
+                if constexpr (r < 6) issue_halo(r, ncr_all + c0 + c, 1);
+                if constexpr (r >= 18 && r < 24) issue_halo(r - 18, c0 + (last ? c : c + 1), 0);
             } else {
-                wait_vm_imm<allow>();
+                // one halo buffer: a phase (xh: steps 0 .. 17, xl': 18 .. 26) starts with a barrier (every wave has read the old halo),
+                // this wave's six pieces and vmcnt(0); inside a phase only the weight ring is in flight
+                constexpr bool phase_start = r == 0 || r == 18;
+                if constexpr (phase_start) {
+                    if (r == 18 || c > 0) RAW_BARRIER();
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) issue_halo(k, r == 0 ? c0 + c : ncr_all + c0 + c, 0);
+                    wait_vm_imm<0>();
+                } else if constexpr (r + 2 >= 27) {
+                    if (last) wait_vm_imm<0>(); else wait_vm_imm<2 * BJ>();
+                } else {
+                    wait_vm_imm<2 * BJ>();
+                }
+                RAW_BARRIER();
+                if constexpr (r + 3 < 27) issue_w(c, r + 3, (tb + r + 3) & 3);
+                else if (!last) issue_w(c + 1, r + 3 - 27, (tb + r + 3) & 3);
             }
-            RAW_BARRIER();
-            if constexpr (r + 3 < 27) issue_w(c, r + 3, (tb + r + 3) & 3);
-            else if (!last) issue_w(c + 1, r + 3 - 27, (tb + r + 3) & 3);
-            if constexpr (r < 6) issue_halo(r, ncr_all + c0 + c, 1);
-            if constexpr (r >= 18 && r < 24) issue_halo(r - 18, c0 + (last ? c : c + 1), 0);
             constexpr int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
-            constexpr int hoff = r >= 18 ? HALO_BYTES : 0;
+            constexpr int hoff = (NHB == 2 && r >= 18) ? HALO_BYTES : 0;
             const unsigned ba = bx + (unsigned)(((tb + r) & 3) * B_BYTES);
             half8 fa[TM], fb[TN];
             LDS_READ(fa[0], aa[tap][0], hoff);
@@ -919,10 +941,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3u_kernel(const Gemm16Params 
             LDS_READ(fb[1], ba, 1024);
             LDS_READ(fb[2], ba, 2048);
             LDS_READ(fb[3], ba, 3072);
-            LDS_READ(fb[4], ba, 4096);
-            LDS_READ(fb[5], ba, 5120);
-            LDS_READ(fb[6], ba, 6144);
-            LDS_READ(fb[7], ba, 7168);
+            if constexpr (TN == 8) {
+                LDS_READ(fb[4], ba, 4096);
+                LDS_READ(fb[5], ba, 5120);
+                LDS_READ(fb[6], ba, 6144);
+                LDS_READ(fb[7], ba, 7168);
+            }
             LDS_READ(fa[1], aa[tap][1], hoff);
             LDS_READ(fa[2], aa[tap][2], hoff);
             LDS_READ(fa[3], aa[tap][3], hoff);
@@ -934,7 +958,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3u_kernel(const Gemm16Params 
         MMA(0, b);                               \
     } while (0)
             lgkm_wait1<NRD - 1>(fa[0]);
-            MM0(0); MM0(1); MM0(2); MM0(3); MM0(4); MM0(5); MM0(6); MM0(7);
+            MM0(0); MM0(1); MM0(2); MM0(3);
+            if constexpr (TN == 8) { MM0(4); MM0(5); MM0(6); MM0(7); }
             lgkm_wait1<2>(fa[1]);
 #pragma unroll
             for (int b = 0; b < TN; ++b) MMA(1, b);
@@ -976,8 +1001,10 @@ int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
     }
     // the unrolled form reaches the input through a 32-bit buffer descriptor with 0x7fffff00 as "outside"
     const bool unrolled = ctx->x3_unroll && (long long)p.M * (p.Cin / 3) * 4 < 0x7f000000ll && (long long)p.N * p.ldb * 2 < 0x7f000000ll;
-    if (wide && unrolled) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    if (wide && unrolled) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 128, 2>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     else if (wide) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    else if (unrolled && ctx->x3_unroll == 4) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 64, 4>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    else if (unrolled && ctx->x3_unroll == 3) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 64, 3>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     else hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     return REID_OK;
 }

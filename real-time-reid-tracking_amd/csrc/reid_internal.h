@@ -377,7 +377,9 @@ struct reid_ctx {
     int split_x3_small = 0;  // ... and small launches too (a tracking frame), K split over up to 8 blocks per tile
     int x3_narrow = 1;       // conv3x3_x3.hip, 64-wide tiles (four blocks per CU) beyond layer 1: bit 0 = the 16-wide maps (layer 2: 14.03 -> 13.87 ms per
                              // 1024-crop pass; default), bit 1 = the 8-wide ones (layers 3-4: 14.03 -> 14.70, off)
-    int x3_unroll = 1;       // conv3x3_x3.hip, 128-wide tiles: the form with a chunk's 27 steps unrolled (addresses, DMA offsets and waits made once / immediates)
+    int x3_unroll = 3;       // conv3x3_x3.hip: the form with a chunk's 27 steps unrolled (addresses, DMA offsets made once, waits immediates): 1 = the
+                             // 128-wide tiles, 3 (default) = and the 64-wide ones at THREE blocks per CU (134-148 registers; at four they spill:
+                             // 12.59 / 12.32 / 14.05 ms per 1024-crop pass for 1 / 3 / 4), 0 = the looped kernels
     int x3_ablate = 0;       // timing experiments on conv3x3_x3.hip (debug switch; WRONG results while set)
     int split_x3_min_blocks = 512;   // ... from this many blocks on (two for every CU)
     int split_pair = 0;      // precision 2, 128-wide halo tiles (REID_SPLIT_PAIR): 0 = three passes over the virtual channels (default),
