@@ -786,7 +786,7 @@ constexpr int x3_halo_step(int r) {                 // does step r (mod 27) of a
 template <int N>
 __device__ __forceinline__ void wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TW, int IMGS, int BN, int OCC>
+template <int TW, int IMGS, int BN, int OCC, int GS = 1>
 __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (buffer-descriptor builtins exist in the device pass only)
     static_assert((BN == 128 && OCC == 2) || (BN == 64 && (OCC == 3 || OCC == 4)), "128-wide: two blocks per CU, two halo buffers; 64-wide: one halo buffer");
@@ -799,7 +799,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
     constexpr int B_BYTES = BN * 64;
     constexpr int BJ = BN / 64;
     constexpr int TM = 4, TN = BN / 16;
-    constexpr int NS = 4;
+    static_assert(GS == 1 || (GS == 3 && BN == 64), "groups of three steps per barrier: the 64-wide form");
+    constexpr int NS = GS == 3 ? 6 : 4;              // weight slots: four single steps in flight, or two groups of three
     constexpr int NHB = BN == 64 ? 1 : 2;
     static_assert(OCC * (NHB * HALO_BYTES + NS * B_BYTES) <= 160 * 1024, "blocks per CU");
     __shared__ __attribute__((aligned(16))) char lds[NHB * HALO_BYTES + NS * B_BYTES];
@@ -898,6 +899,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
 
     for (int c = 0; c < ncr; ++c) {
         const int tb = c * 27;
+        const int gpar = (c * 9) & 1;                // GS == 3: parity of the chunk's first group (a chunk is nine groups)
         const bool last = c + 1 == ncr;
         for_each_step([&](auto RC) __attribute__((always_inline)) {
             constexpr int r = decltype(RC)::value;
@@ -914,7 +916,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
                 else if (!last) issue_w(c + 1, r + 3 - 27, (tb + r + 3) & 3);
                 if constexpr (r < 6) issue_halo(r, ncr_all + c0 + c, 1);
                 if constexpr (r >= 18 && r < 24) issue_halo(r - 18, c0 + (last ? c : c + 1), 0);
-            } else {
+            } else if constexpr (GS == 1) {
                 // one halo buffer: a phase (xh: steps 0 .. 17, xl': 18 .. 26) starts with a barrier (every wave has read the old halo),
                 // this wave's six pieces and vmcnt(0); inside a phase only the weight ring is in flight
                 constexpr bool phase_start = r == 0 || r == 18;
@@ -931,10 +933,30 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
                 RAW_BARRIER();
                 if constexpr (r + 3 < 27) issue_w(c, r + 3, (tb + r + 3) & 3);
                 else if (!last) issue_w(c + 1, r + 3 - 27, (tb + r + 3) & 3);
+            } else {
+                // groups of three steps per barrier (a 64-wide step is 16 MFMAs per wave: 256 cycles between two barriers): at a
+                // group's start the group's weights - requested one group ago - and, at a phase's start, the halo have landed
+                // (vmcnt(0): nothing newer is in flight), one barrier, then the NEXT group's three weight tiles are requested
+                if constexpr (r % 3 == 0) {
+                    constexpr bool phase_start = r == 0 || r == 18;
+                    if constexpr (phase_start) {
+                        if (r == 18 || c > 0) RAW_BARRIER();
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) issue_halo(k, r == 0 ? c0 + c : ncr_all + c0 + c, 0);
+                    }
+                    wait_vm_imm<0>();
+                    RAW_BARRIER();
+                    const int nslot = (((gpar + r / 3) & 1) ^ 1) * 3;
+                    if constexpr (r + 3 < 27) {
+                        issue_w(c, r + 3, nslot); issue_w(c, r + 4, nslot + 1); issue_w(c, r + 5, nslot + 2);
+                    } else if (!last) {
+                        issue_w(c + 1, 0, nslot); issue_w(c + 1, 1, nslot + 1); issue_w(c + 1, 2, nslot + 2);
+                    }
+                }
             }
             constexpr int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
             constexpr int hoff = (NHB == 2 && r >= 18) ? HALO_BYTES : 0;
-            const unsigned ba = bx + (unsigned)(((tb + r) & 3) * B_BYTES);
+            const unsigned ba = bx + (unsigned)((GS == 3 ? ((gpar + r / 3) & 1) * 3 + r % 3 : (tb + r) & 3) * B_BYTES);
             half8 fa[TM], fb[TN];
             LDS_READ(fa[0], aa[tap][0], hoff);
             LDS_READ(fb[0], ba, 0);
@@ -1005,6 +1027,7 @@ int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
     else if (wide) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     else if (unrolled && ctx->x3_unroll == 4) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 64, 4>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     else if (unrolled && ctx->x3_unroll == 3) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 64, 3>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    else if (unrolled && ctx->x3_unroll == 5) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 64, 3, 3>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     else hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     return REID_OK;
 }
