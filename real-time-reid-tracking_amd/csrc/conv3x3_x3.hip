@@ -371,6 +371,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int pi16(int i) { return i < 8 ? i : (i < 12 ? i + 4 : i - 4); }
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// sum over the 16 lanes of a DPP row (every lane of the row gets it): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+    return v;
+}
+
 template <int N>
 __device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -427,14 +439,18 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
     if (p.ablate & 32) return;
     // ------------------------------------------------------------------ fp32 epilogue: the arithmetic of conv3x3_f16.hip's SPLIT
     // build per element (BN scale x 2^-11 + shift, + fp32 residual, ReLU from relu_from on, fp32 or [yh | yl'] stores, per-128-row
-    // column sums).  Lane: column PI(l16) of the 16-column tile, rows 4 PQ(lq) + reg of the 16-row tile (PQ = quads 2 and 3 swapped)
+    // column sums).  The accumulators are TRANSPOSED tiles (the MFMAs take the weight fragment as their first operand): lane
+    // (l16, lq) holds the FOUR CONSECUTIVE CHANNELS 16 b + 4 PQ(lq) + e of pixel PI(l16) of 16-pixel tile a (PQ = quads 2 and 3
+    // swapped) - so a lane's four values are 16 contiguous bytes of the NHWC output: one buffer_store_dwordx4 (or two dwordx2 of
+    // the [yh | yl'] form) and one dwordx4 residual load per tile instead of four (eight) scalar ones.  Column sums: per-lane
+    // partials over the four tiles, then four DPP adds across the 16 pixel lanes of a row.
     const int ldc = (int)p.ldc;
     const int m_blk = mtile * 256;
     const int m_valid = p.M - m_blk;
     const bool wave_live = m_valid >= 256 || wm < 2;         // M % 128 == 0: a ragged tile has 128 rows, those of waves 0, 1
     const int pq = lq < 2 ? lq : 5 - lq;
-    const int lrow = TW == 8 ? (pq < 2 ? 4 * pq : 32 + 4 * (pq - 2)) : 4 * pq;     // lane part of the natural row
-    const int col0 = n_blk + pj;
+    const int lrow = TW == 8 ? 32 * (pj >> 3) + (pj & 7) : pj;                       // lane part of the natural row (tile a: ubase)
+    const int col0 = n_blk + 4 * pq;
     const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C32 + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rs =
         __builtin_amdgcn_make_buffer_rsrc((void*)((p.res32 ? p.res32 : p.C32) + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
@@ -442,67 +458,95 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
         __builtin_amdgcn_make_buffer_rsrc((void*)((p.pack16 ? p.pack16 : (f16*)p.C32) + (long long)m_blk * 2 * p.N), 0, 256 * 2 * p.N * 2, 0x00020000);
     const int voff = (lrow * ldc + col0) * 4;
     const int koff = (lrow * 2 * p.N + col0) * 2;
+    const bool has_stats = p.stats != nullptr;
     float vmax = 0.f;
-    float s1[TN], s2[TN];
-    auto run = [&](auto res_c) {
-        constexpr bool RES = decltype(res_c)::value;
+    // every choice below (residual, [yh | yl'] or fp32 store, statistics) is uniform per wave and per 16-column tile and is taken
+    // by a scalar branch AROUND a straight-line body of four tiles: per-element selects and branches made this epilogue ~1 000
+    // vector instructions per wave, each of which waits 11-45 cycles for an issue slot beside the other blocks' MFMAs
+    // (profiles/r02_coissue.log; s_memtime stamps, round 5: 28 k cycles of a 64-wide block's 74 k-cycle life).  One flat lambda on
+    // purpose: the same body as a nested generic lambda per tile compiled (ROCm 7.2 hipcc) to code that gave wrong sums.
+    auto run = [&](auto res_c, auto st_c) {
+        constexpr bool RES = decltype(res_c)::value, ST = decltype(st_c)::value;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const int col = col0 + b * 16;
-            const float cs = (p.col_scale ? p.col_scale[col] : 1.f) * p.acc_scale;
-            const float sh = p.col_scale ? p.col_shift[col] : 0.f;
-            const float lo = (p.relu && col >= p.relu_from) ? 0.f : -INFINITY;
-            const bool pk = p.pack16 && col >= p.pack_from;      // uniform per 16-column tile (pack_from % 32 == 0)
-            float t1 = 0.f, t2 = 0.f;
+            const int col = col0 + b * 16, tcol = n_blk + b * 16;
+            f32x4 cs = f32x4{p.acc_scale, p.acc_scale, p.acc_scale, p.acc_scale}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.col_scale) {
+                cs = *(const f32x4*)(p.col_scale + col) * p.acc_scale;
+                sh = *(const f32x4*)(p.col_shift + col);
+            }
+            const float lo = (p.relu && tcol >= p.relu_from) ? 0.f : -INFINITY;   // uniform per 16-column tile (relu_from % 16 == 0)
+            const bool pk = p.pack16 && tcol >= p.pack_from;                       // (pack_from % 32 == 0)
+            // AB tiles at a time: all four for the 64-wide block (its 64 accumulator registers leave room; the four residual
+            // loads are in flight together), one for the 128-wide block (128 accumulators: more would spill)
+            constexpr int AB = BN == 64 ? 4 : 1;
+            f32x4 t1 = f32x4{0.f, 0.f, 0.f, 0.f}, t2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int ubase = wm * 64 + (TW == 8 ? a * 8 : a * 16);          // uniform part of the natural row
-                float rr[4];
-                if constexpr (RES) {
+            for (int a0 = 0; a0 < TM; a0 += AB) {
+                f32x4 v[AB];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        rr[e] = wave_live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, voff + b * 64, (ubase + e) * ldc * 4, 0)) : 0.f;
+                for (int i = 0; i < AB; ++i) {
+                    const int a = a0 + i;
+                    v[i] = acc[a][b] * cs + sh;
+                    if constexpr (RES)
+                        v[i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], lo);
+                    if constexpr (ST) {
+                        t1 += v[i];
+                        t2 += v[i] * v[i];
+                    }
                 }
+                if (pk) {
+#pragma unroll
+                    for (int i = 0; i < AB; ++i) {
+                        const int ubase = wm * 64 + (TW == 8 ? (a0 + i) * 8 : (a0 + i) * 16);       // uniform part of the natural row
+                        u32x2 hw, lw;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float v0 = v[i][2 * h], v1 = v[i][2 * h + 1];
+                            vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
+                            const f16 h0 = (f16)v0, h1 = (f16)v1;
+                            const f16 l0 = (f16)((v0 - (float)h0) * 2048.0f), l1 = (f16)((v1 - (float)h1) * 2048.0f);
+                            hw[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                            lw[h] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, koff + b * 32, ubase * 2 * p.N * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, koff + b * 32 + p.N * 2, ubase * 2 * p.N * 2, 0);
+                    }
+                } else if (!(p.ablate & 64)) {
+#pragma unroll
+                    for (int i = 0; i < AB; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), c_rs, voff + b * 64,
+                                                               (wm * 64 + (TW == 8 ? (a0 + i) * 8 : (a0 + i) * 16)) * ldc * 4, 0);
+                }
+            }
+            if constexpr (ST) {   // this wave's column sums of the tile's 64 rows: four DPP adds across the 16 pixel lanes, lane 0 of the row writes
+                float* stat_lds = (float*)lds;  // [4][BN][2]  (every wave is past the main loop's LDS reads and the split-K flag)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[a][b][e] * cs + sh;
-                    v += RES ? rr[e] : 0.f;
-                    v = fmaxf(v, lo);
-                    if (wave_live) {
-                        t1 += v;
-                        t2 += v * v;
-                        if (pk) {
-                            vmax = fmaxf(vmax, fabsf(v));
-                            const f16 hv = (f16)v;
-                            const f16 lv = (f16)((v - (float)hv) * 2048.0f);
-                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), k_rs, koff + b * 32, (ubase + e) * 2 * p.N * 2, 0);
-                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lv), k_rs, koff + b * 32 + p.N * 2, (ubase + e) * 2 * p.N * 2, 0);
-                        } else if (!(p.ablate & 64)) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, voff + b * 64, (ubase + e) * ldc * 4, 0);
-                        }
+                    const float r1 = row16_sum(t1[e]), r2 = row16_sum(t2[e]);
+                    if (l16 == 0) {
+                        const int lcol = b * 16 + 4 * pq + e;
+                        stat_lds[(wm * BN + lcol) * 2 + 0] = r1;
+                        stat_lds[(wm * BN + lcol) * 2 + 1] = r2;
                     }
                 }
             }
-            s1[b] = t1;
-            s2[b] = t2;
         }
     };
-    if (p.res32) run(std::true_type{});
-    else run(std::false_type{});
-    if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;
-    if (p.stats) {   // per 128 natural rows: waves 0,1 own rows 0..127, waves 2,3 rows 128..255
-        float* stat_lds = (float*)lds;  // [4][BN][2]
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int lcol = b * 16 + pj;
-            float t1 = s1[b], t2 = s2[b];
-            t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
-            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
-            if (lq == 0) {
-                stat_lds[(wm * BN + lcol) * 2 + 0] = t1;
-                stat_lds[(wm * BN + lcol) * 2 + 1] = t2;
-            }
+    if (wave_live) {
+        if (p.res32) {
+            if (has_stats) run(std::true_type{}, std::true_type{});
+            else run(std::true_type{}, std::false_type{});
+        } else {
+            if (has_stats) run(std::false_type{}, std::true_type{});
+            else run(std::false_type{}, std::false_type{});
         }
+    }
+    if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;
+    if (has_stats) {   // per 128 natural rows: waves 0,1 own rows 0..127, waves 2,3 rows 128..255
+        const float* stat_lds = (const float*)lds;  // [4][BN][2], written by run()
         __syncthreads();
         for (int t = tid; t < 2 * BN; t += 256) {
             const int half = t / BN, cc = t - half * BN;
@@ -656,7 +700,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(co
             // (inline asm: the waits are asm volatile statements, and only asm volatile statements keep their order among each other -
             // hipcc moved builtin MFMAs below later waits, through sched_barriers.  Accumulators are only ever MFMA SrcC / vDst inside
             // the loop: back-to-back issue needs no wait states; the epilogue reads them behind the loop's closing barrier + s_nops.)
-#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fa[a]), "v"(fb[b]))
+#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fb[b]), "v"(fa[a]))   /* weights first: D^T (x3m16_tail) */
 #define MM0(b)                                   \
     do {                                         \
         lgkm_wait1<NRD - 2 - (b)>(fb[b]);        \
@@ -734,7 +778,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(co
             // (inline asm: the waits are asm volatile statements, and only asm volatile statements keep their order among each other -
             // hipcc moved builtin MFMAs below later waits, through sched_barriers.  Accumulators are only ever MFMA SrcC / vDst inside
             // the loop: back-to-back issue needs no wait states; the epilogue reads them behind the loop's closing barrier + s_nops.)
-#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fa[a]), "v"(fb[b]))
+#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fb[b]), "v"(fa[a]))   /* weights first: D^T (x3m16_tail) */
 #define MM0(b)                                   \
     do {                                         \
         lgkm_wait1<NRD - 2 - (b)>(fb[b]);        \
@@ -973,7 +1017,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
             LDS_READ(fa[2], aa[tap][2], hoff);
             LDS_READ(fa[3], aa[tap][3], hoff);
             constexpr int NRD = TM + TN;
-#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fa[a]), "v"(fb[b]))
+#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fb[b]), "v"(fa[a]))   /* weights first: D^T (x3m16_tail) */
 #define MM0(b)                                   \
     do {                                         \
         lgkm_wait1<NRD - 2 - (b)>(fb[b]);        \

@@ -135,6 +135,7 @@ extern "C" int reid_debug_conv_split(reid_ctx* ctx, int n, int h, int w, int c, 
     q.acc_scale = 1.0f / 2048.0f;
     q.zero_page = ctx->se18.zero_page;
     q.ablate = ablate & 127;
+    q.diag = ctx->conv_diag;
     int st = REID_OK;
     for (int i = 0; i < 2 && st == REID_OK; ++i) st = launch_conv3x3_split(ctx, q, REID_K_CONV_GEMM, 0, 0);
     if (st == REID_OK) st = reid_timer_start(ctx);
