@@ -896,6 +896,28 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
         const int cg = (lane & 3) ^ (((row >> 3) & 1) << 1);
         wv[j] = (int)((((long long)(n_blk + row) * p.ldb) + cg * 8) * 2);
     }
+    const int cin2 = p.Cin * 2, c2 = C * 2;           // bytes per tap / per weight part of a weight row
+    auto issue_w = [&](int cc, int r, int slot) __attribute__((always_inline)) {   // weight tile of step r of chunk cc (r compile-time at the call sites)
+        const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
+        const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
+        const int soff = tap * cin2 + part * c2 + (c0 + cc) * 64;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, LPTR(lds + NHB * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, wv[j], soff, 0, 0);
+    };
+    auto issue_halo = [&](int k, int vchunk, int buf) __attribute__((always_inline)) {
+        const int q = k * 4 + wm < NPI ? k * 4 + wm : NPI - 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(lds + buf * HALO_BYTES + q * 1024), 16, hv[k], vchunk * 64, 0, 0);
+    };
+
+    // ---- prologue, issued BEFORE the fragment addresses below are made (~3 k cycles of setup beside the other blocks' MFMAs:
+    // s_memtime stamps, round 5 - the first loads now fly under it): xh of the first chunk and the weight tiles of steps 0 .. 2
+#pragma unroll
+    for (int k = 0; k < 6; ++k) issue_halo(k, c0, 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    issue_w(0, 2, 2);
+
     const int pj = pi16(l16);
     unsigned aa[9][TM];                               // A fragment address of (tap, 16-row tile) in halo buffer 0
 #pragma unroll
@@ -911,35 +933,12 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
         }
     }
     const unsigned bx = ring32 + pj * 64 + ((lq ^ (((pj >> 3) & 1) << 1)) * 16);
-    const int cin2 = p.Cin * 2, c2 = C * 2;           // bytes per tap / per weight part of a weight row
 
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto issue_w = [&](int cc, int r, int slot) __attribute__((always_inline)) {   // weight tile of step r of chunk cc (r compile-time at the call sites)
-        const int part = r < 9 ? 0 : r < 18 ? 2 : 1;
-        const int tap = r < 9 ? r : r < 18 ? r - 9 : r - 18;
-        const int soff = tap * cin2 + part * c2 + (c0 + cc) * 64;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, LPTR(lds + NHB * HALO_BYTES + slot * B_BYTES + (wm * BJ + j) * 1024), 16, wv[j], soff, 0, 0);
-    };
-    auto issue_halo = [&](int k, int vchunk, int buf) __attribute__((always_inline)) {
-        const int q = k * 4 + wm < NPI ? k * 4 + wm : NPI - 1;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(lds + buf * HALO_BYTES + q * 1024), 16, hv[k], vchunk * 64, 0, 0);
-    };
-
-    // ---- prologue: xh of the first chunk (two halo buffers; with one, every phase loads its halo at its start), weight tiles of steps 0 .. 2
-    if constexpr (NHB == 2) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) issue_halo(k, c0, 0);
-    }
-    issue_w(0, 0, 0);
-    issue_w(0, 1, 1);
-    issue_w(0, 2, 2);
 
     for (int c = 0; c < ncr; ++c) {
         const int tb = c * 27;
@@ -965,9 +964,11 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
                 // this wave's six pieces and vmcnt(0); inside a phase only the weight ring is in flight
                 constexpr bool phase_start = r == 0 || r == 18;
                 if constexpr (phase_start) {
-                    if (r == 18 || c > 0) RAW_BARRIER();
+                    if (r == 18 || c > 0) {            // (the first chunk's xh: requested in the prologue)
+                        RAW_BARRIER();
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) issue_halo(k, r == 0 ? c0 + c : ncr_all + c0 + c, 0);
+                        for (int k = 0; k < 6; ++k) issue_halo(k, r == 0 ? c0 + c : ncr_all + c0 + c, 0);
+                    }
                     wait_vm_imm<0>();
                 } else if constexpr (r + 2 >= 27) {
                     if (last) wait_vm_imm<0>(); else wait_vm_imm<2 * BJ>();
@@ -984,9 +985,11 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
                 if constexpr (r % 3 == 0) {
                     constexpr bool phase_start = r == 0 || r == 18;
                     if constexpr (phase_start) {
-                        if (r == 18 || c > 0) RAW_BARRIER();
+                        if (r == 18 || c > 0) {
+                            RAW_BARRIER();
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) issue_halo(k, r == 0 ? c0 + c : ncr_all + c0 + c, 0);
+                            for (int k = 0; k < 6; ++k) issue_halo(k, r == 0 ? c0 + c : ncr_all + c0 + c, 0);
+                        }
                     }
                     wait_vm_imm<0>();
                     RAW_BARRIER();
