@@ -18,7 +18,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BM = 128;
-constexpr int BK = 32;
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(uintptr_t)(p))
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
@@ -31,13 +30,21 @@ struct TileDesc {
     int m_blk, n_blk, rows_a;
 };
 
-template <int BN, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p) {
+// BK = 32: 128-byte LDS rows, eight 16-byte chunks, two blocks per CU (64 KB of LDS for the 128-wide tile).
+// BK = 16 (the 128-wide distance tile): 64-byte rows, four chunks, 32 KB of LDS and <= 168 VGPRs -> THREE blocks per CU.  Why: s_memtime
+// stamps of the Market-size matrix (3368 x 15913 x 512, profiles/r05_experiments.txt) - a block's epilogue (64 x [3 FMA, max, sqrt,
+// 4-byte store] per lane, issued beside the other block's back-to-back MFMAs) lasts LONGER than its 16-tile K loop (83-103 k against 74 k
+// cycles), so with two blocks per CU a SIMD has ONE wave feeding the matrix pipe most of the time; a third block keeps two.
+template <int BN, int EPI, int BK = 32>
+__global__ __launch_bounds__(256, BK == 16 ? 3 : 2) void gemm_f32_dma_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
     constexpr int ROWB = BK * 4;
+    constexpr int CH = ROWB / 16;                    // 16-byte chunks per LDS row: 8 or 4
+    constexpr int RPP = 1024 / ROWB;                 // rows per 1-KB DMA piece: 8 or 16
+    constexpr int KK = BK / 8;                       // ds_read_b128 steps per K-tile (a step = chunks 2 kk + lh: four MFMAs per tile pair)
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    constexpr int AJ = BM / 8 / 4, BJ = BN / 8 / 4;
+    constexpr int AJ = BM / RPP / 4, BJ = BN / RPP / 4;
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -47,6 +54,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     const int nnt = (p.N + BN - 1) / BN;
     const int nk = p.K / BK;
 
+    // XOR swizzle of the chunk position: the 16 rows a ds_read_b128 phase touches (16 lanes, one chunk each) must cover the 16
+    // bank groups - rows are 128 B (two per 256-B bank row: xor (row >> 1) & 7) or 64 B (four per bank row: xor (row >> 2) & 3)
+    auto row_swz = [](int row) { return CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3; };
     using Desc = TileDesc<AJ, BJ>;
     // Tile order: groups of GM row tiles (GM <= 8); inside a group the row tile runs fastest, so the GM A tiles (GM x BM x K floats) stay in
     // the XCD's L2 while the group sweeps the columns and every B tile is fetched once per group, not once per row tile (the
@@ -71,14 +81,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                                                    (int)((long long)(rows_b - 1) * p.ldb * 4 + (long long)p.K * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const int row = (wave * AJ + j) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const int row = (wave * AJ + j) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ row_swz(row);
             d.a_voff[j] = row < d.rows_a ? (int)(((long long)row * p.lda + chunk * 4) * 4) : (int)0x7fffff00;
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int row = (wave * BJ + j) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const int row = (wave * BJ + j) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ row_swz(row);
             d.b_voff[j] = row < rows_b ? (int)(((long long)row * p.ldb + chunk * 4) * 4) : (int)0x7fffff00;
         }
     };
@@ -93,10 +103,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
             __builtin_amdgcn_raw_ptr_buffer_load_lds(d.b_rs, LPTR(Bs + (wave * BJ + j) * 1024), 16, d.b_voff[j], kt * BK * 4, 0, 0);
     };
 
-    const int swz = (li >> 1) & 7;
-    int a_rd[4], b_rd[4];
+    const int swz = row_swz(li);
+    int a_rd[KK], b_rd[KK];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < KK; ++kk) {
         const int pos = ((kk * 2 + lh) ^ swz) * 16;
         a_rd[kk] = (wm * 64 + li) * ROWB + pos;
         b_rd[kk] = A_BYTES + (wn * WN + li) * ROWB + pos;
@@ -110,8 +120,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
 #pragma unroll
         for (int b = 0; b < TN; ++b) bf[0][b] = *(const f32x4*)(base + b_rd[0] + b * 32 * ROWB);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) {
+        for (int kk = 0; kk < KK; ++kk) {
+            if (kk < KK - 1) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a) af[(kk + 1) & 1][a] = *(const f32x4*)(base + a_rd[kk + 1] + a * 32 * ROWB);
 #pragma unroll
@@ -305,6 +315,8 @@ void launch_epi(reid_ctx* ctx, const GemmParams& p) {
     const double cost64 = ((p.N + 63) / 64) * 64 * 1.12, cost128 = ((p.N + 127) / 128) * 128;
     if (EPI == E_BIAS || p.N <= 64 || cost64 < cost128) {
         hipLaunchKernelGGL((gemm_f32_dma_kernel<64, EPI>), dim3(nmt * ((p.N + 63) / 64)), dim3(256), 0, ctx->stream, p);
+    } else if (EPI == E_DIST && ctx->f32_dist_bk16) {     // three blocks per CU (see the kernel's header)
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<128, EPI, 16>), dim3(nmt * ((p.N + 127) / 128)), dim3(256), 0, ctx->stream, p);
     } else {
         hipLaunchKernelGGL((gemm_f32_dma_kernel<128, EPI>), dim3(nmt * ((p.N + 127) / 128)), dim3(256), 0, ctx->stream, p);
     }
@@ -313,7 +325,7 @@ void launch_epi(reid_ctx* ctx, const GemmParams& p) {
 }  // namespace
 
 bool gemm_f32_dma_supported(int amode, int epi, const GemmParams& p) {
-    return amode == A_DENSE && (epi == E_BIAS || epi == E_DIST) && p.K % BK == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
+    return amode == A_DENSE && (epi == E_BIAS || epi == E_DIST) && p.K % 32 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
            (long long)BM * p.lda * 4 < 0x7fff0000ll && (long long)128 * p.ldb * 4 < 0x7fff0000ll &&
            ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0;
 }

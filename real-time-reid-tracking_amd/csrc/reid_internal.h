@@ -369,6 +369,7 @@ struct reid_ctx {
     int f32_conv = 1;        // fp32 path (REID_F32_CONV): 1 = conv_f32.hip LDS-DMA kernel, norms in the producer's epilogue / in_apply;
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
     int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
+    int f32_dist_bk16 = 1;   // distance matrix, 128-wide tiles: K-tiles of 16 -> three blocks per CU (gemm_f32_dma.hip); 0 = K-tiles of 32, two blocks
     int pack_epilogue = 1;   // precision 2: conv1 epilogues write [yh | yl'] for conv2 themselves (REID_PACK_EPILOGUE=0: fp32 + pack passes)
     int split_lean_epi = 1;  // precision 2: buffer-instruction epilogue of the SPLIT convolution builds (REID_SPLIT_LEAN=0: general loop)
     int split_x3 = 3;        // precision 2, large launches: conv3x3_x3.hip instead of conv3x3_f16.hip's 12-wave kernel: 3 (default) = on
