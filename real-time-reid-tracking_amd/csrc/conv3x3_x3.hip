@@ -849,6 +849,10 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
     static_assert(OCC * (NHB * HALO_BYTES + NS * B_BYTES) <= 160 * 1024, "blocks per CU");
     __shared__ __attribute__((aligned(16))) char lds[NHB * HALO_BYTES + NS * B_BYTES];
 
+    // diagnostics (p.diag, tools/x3_stamps.py): s_memtime at entry / loop start / around the single-halo phase waits / loop end / exit
+    unsigned long long dg_e = 0, dg_t0 = 0, dg_first = 0, dg_halo = 0, dg_t1 = 0;
+#define X3_STAMP(v) if (p.diag) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+    X3_STAMP(dg_e);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, lq = lane >> 4;
@@ -940,6 +944,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    X3_STAMP(dg_t0);
     for (int c = 0; c < ncr; ++c) {
         const int tb = c * 27;
         const int gpar = (c * 9) & 1;                // GS == 3: parity of the chunk's first group (a chunk is nine groups)
@@ -964,12 +969,18 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
                 // this wave's six pieces and vmcnt(0); inside a phase only the weight ring is in flight
                 constexpr bool phase_start = r == 0 || r == 18;
                 if constexpr (phase_start) {
+                    unsigned long long ta = 0, tb2 = 0;
+                    X3_STAMP(ta);
                     if (r == 18 || c > 0) {            // (the first chunk's xh: requested in the prologue)
                         RAW_BARRIER();
 #pragma unroll
                         for (int k = 0; k < 6; ++k) issue_halo(k, r == 0 ? c0 + c : ncr_all + c0 + c, 0);
                     }
                     wait_vm_imm<0>();
+                    if (p.diag) {
+                        X3_STAMP(tb2);
+                        if (r == 0 && c == 0) dg_first = tb2 - ta; else dg_halo += tb2 - ta;
+                    }
                 } else if constexpr (r + 2 >= 27) {
                     if (last) wait_vm_imm<0>(); else wait_vm_imm<2 * BJ>();
                 } else {
@@ -1042,7 +1053,19 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
 #undef MMA
         }, std::make_integer_sequence<int, 27>{});
     }
+    X3_STAMP(dg_t1);
     x3m16_tail<TW, IMGS, BN>(p, acc, lds, tid, wm, mtile, n_blk, tile_id, ksplit, SK);
+    if (p.diag) {   // blocks from the middle of the launch, per wave: set-up | first halo wait | later halo waits | entry -> loop end | epilogue
+        unsigned long long dg_t2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X3_STAMP(dg_t2);
+        const int bi = (int)blockIdx.x - (int)(gridDim.x / 2);
+        if (bi >= 0 && bi < 64 && lane == 0) {
+            unsigned long long* o = p.diag + ((size_t)bi * 8 + wm) * 5;
+            o[0] = dg_t0 - dg_e; o[1] = dg_first; o[2] = dg_halo; o[3] = dg_t1 - dg_e; o[4] = dg_t2 - dg_t1;
+        }
+    }
+#undef X3_STAMP
 #endif
 }
 

@@ -1,4 +1,4 @@
-"""s_memtime stamps of the single-halo unrolled convolution (conv3x3_x3u_kernel<.., 64, 3>) on layer-1 / layer-2 shapes (a build with the stamps)."""
+"""s_memtime stamps of the single-halo unrolled convolution (conv3x3_x3u_kernel<.., 64, 3>) on layer-1 / layer-2 shapes (Gemm16Params.diag: reid_debug_conv_diag)."""
 import ctypes as C
 import os
 import sys
@@ -31,5 +31,5 @@ for name, h, w, c, cout in (("L1 64->64 64x32", 64, 32, 64, 64), ("L2 128->128 3
     check(dg(eng.h, 0, raw.ctypes.data_as(C.c_void_p)))
     r = raw.reshape(64, 8, 5)[:, :4, :].astype(np.float64)
     m = r.reshape(-1, 5).mean(0)
-    print("[ablate %d] %s x %d: %.1f us per launch (%.0f TF); per block (s_memtime units, mean of 64 blocks x 4 waves): first halo+weights %.0f | setup (entry -> loop) %.0f | later halo waits %.0f | entry->loop end %.0f | epilogue+drain %.0f"
+    print("[ablate %d] %s x %d: %.1f us per launch (%.0f TF); per block (s_memtime units, mean of 64 blocks x 4 waves): set-up %.0f | first halo wait %.0f | later halo waits %.0f | entry->loop end %.0f | epilogue+drain %.0f"
           % (abl, name, n, t_plain * 1e3, 2.0 * n * h * w * cout * 27 * c / (t_plain * 1e-3) / 1e12, m[0], m[1], m[2], m[3], m[4]), flush=True)
