@@ -234,6 +234,26 @@ def test_distmat_shapes(eng, m, n, d):
     assert eng.distmat(x[:0], y).shape == (0, n)        # empty inputs
 
 
+@pytest.mark.parametrize("m,n,d", [(300, 257, 512), (129, 1000, 96), (640, 384, 2048)])
+def test_distance_matrix_on_k16_tiles_equals_k32_tiles(eng, m, n, d):
+    """gemm_f32_dma.hip: the 128-wide distance tile with K-tiles of 16 (four blocks per CU, the default since round 5) runs the MFMAs of an
+    output element in the order of the K-tiles-of-32 form: bit-identical matrices, ragged edges included; both against the oracle."""
+    rng = np.random.default_rng(m + n)
+    x = rng.normal(size=(m, d)).astype(np.float32)
+    y = rng.normal(size=(n, d)).astype(np.float32)
+    try:
+        eng.debug_switch("f32_dist_bk16", 0)
+        want = eng.distmat(x, y, _ffi.METRIC_L2)
+        want_cos = eng.distmat(x, y, _ffi.METRIC_COS_HALF)
+        eng.debug_switch("f32_dist_bk16", 1)
+        got = eng.distmat(x, y, _ffi.METRIC_L2)
+        got_cos = eng.distmat(x, y, _ffi.METRIC_COS_HALF)
+    finally:
+        eng.debug_switch("f32_dist_bk16", 1)
+    assert np.array_equal(got, want) and np.array_equal(got_cos, want_cos)
+    np.testing.assert_allclose(got, matching.euclidean_dist(x, y), rtol=2e-5, atol=2e-4)
+
+
 def test_knn_matches_oracle(eng):
     rng = np.random.default_rng(2)
     xb = rng.normal(size=(700, 64)).astype(np.float32)
