@@ -233,11 +233,26 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ 
 #pragma unroll
         for (int d = 0; d < 32; d += 4) {
             const f32x4 a = ld4(base + d);
-            const f32x4 b = ld4(base + C + d);
-            const f32x4 c = ld4(base + 2 * C + d);
             q[d] = a.x; q[d + 1] = a.y; q[d + 2] = a.z; q[d + 3] = a.w;
-            *(f32x4*)&kv[wave][0][lane * 32 + d] = b;
-            *(f32x4*)&kv[wave][1][lane * 32 + d] = c;
+        }
+    }
+    if (live) {
+        // K and V of the window: the wave fills the 49 x 32 images slot by slot (slot = four channels; eight consecutive lanes = the
+        // 128 bytes of one token's head slice, consecutive lanes = consecutive LDS addresses).  A lane writing its OWN token's row
+        // (stride 128 B) was a 25-way bank conflict on every ds_write_b128 (PMC, round 5: conflict cycles = 1.05 x the LDS busy
+        // cycles of this kernel) and eight 16-byte pieces of 49 different lines per load instruction.  Same values, same places;
+        // worth 1.2 % of the kernel (689.6 -> 681.1 us per launch, same box): its time is the 3 136 FMAs + 784 broadcast reads per lane.
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int slot = lane + 64 * i;
+            if (slot < 49 * 8) {
+                const int j = slot >> 3, d = (slot & 7) * 4;
+                const int jy = j / 7, jx = j - jy * 7;
+                const int y = (wy * 7 + jy + sh) % H, x = (wx * 7 + jx + sh) % W;
+                const T* base = qkv + (((long long)img * H + y) * W + x) * ldq + head * 32 + d;
+                *(f32x4*)&kv[wave][0][slot * 4] = ld4(base + C);
+                *(f32x4*)&kv[wave][1][slot * 4] = ld4(base + 2 * C);
+            }
         }
     }
     __syncthreads();
