@@ -17,6 +17,7 @@
 // Reference shapes: reid/backbones/SERes18_IBN.py:120-128 (BasicBlock convs), :250-276.
 #include "reid_internal.h"
 #include "conv3x3_geom.h"
+#include "lin_math.h"
 #include <type_traits>
 #include <utility>
 
@@ -387,7 +388,7 @@ template <int N>
 __device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Everything behind the main loop of the 16x16x32 kernels: split-K reduction (last arriver), fp32 epilogue, statistics.
-template <int TW, int IMGS, int BN>
+template <int TW, int IMGS, int BN, bool LIN = false>
 __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4][BN / 16], char* lds, int tid, int wm, int mtile, int n_blk,
                                            int tile_id, int ksplit, int SK) {
     constexpr int TM = 4, TN = BN / 16;
@@ -447,7 +448,7 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
     const int ldc = (int)p.ldc;
     const int m_blk = mtile * 256;
     const int m_valid = p.M - m_blk;
-    const bool wave_live = m_valid >= 256 || wm < 2;         // M % 128 == 0: a ragged tile has 128 rows, those of waves 0, 1
+    const bool wave_live = wm * 64 < m_valid;               // convolutions: M % 128 == 0 (a ragged tile is the rows of waves 0, 1); linears: any M
     const int pq = lq < 2 ? lq : 5 - lq;
     const int lrow = TW == 8 ? 32 * (pj >> 3) + (pj & 7) : pj;                       // lane part of the natural row (tile a: ubase)
     const int col0 = n_blk + 4 * pq;
@@ -456,8 +457,15 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
         __builtin_amdgcn_make_buffer_rsrc((void*)((p.res32 ? p.res32 : p.C32) + (long long)m_blk * ldc), 0, 256 * ldc * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t k_rs =
         __builtin_amdgcn_make_buffer_rsrc((void*)((p.pack16 ? p.pack16 : (f16*)p.C32) + (long long)m_blk * 2 * p.N), 0, 256 * 2 * p.N * 2, 0x00020000);
-    const int voff = (lrow * ldc + col0) * 4;
-    const int koff = (lrow * 2 * p.N + col0) * 2;
+    // rows past M (ragged linear tiles): the row term of a store / residual address is in the SCALAR offset, which the descriptor's
+    // range check does not see - so such a row gets a lane offset past the descriptor instead (stores dropped, loads zero)
+    int voff_a[TM], koff_a[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const bool row_ok = wm * 64 + (TW == 8 ? a * 8 : a * 16) + lrow < m_valid;
+        voff_a[a] = row_ok ? (lrow * ldc + col0) * 4 : 0x7fffff00;
+        koff_a[a] = row_ok ? (lrow * 2 * p.N + col0) * 2 : 0x7fffff00;
+    }
     const bool has_stats = p.stats != nullptr;
     float vmax = 0.f;
     // every choice below (residual, [yh | yl'] or fp32 store, statistics) is uniform per wave and per 16-column tile and is taken
@@ -474,7 +482,10 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
             if (p.col_scale) {
                 cs = *(const f32x4*)(p.col_scale + col) * p.acc_scale;
                 sh = *(const f32x4*)(p.col_shift + col);
+            } else if (LIN && p.col_shift) {      // linear layers: bias only
+                sh = *(const f32x4*)(p.col_shift + col);
             }
+            const bool gelu = LIN && p.act == 1;  // linear layers: out = act(acc + bias) + residual (gemm_f16.hip's linear epilogue, lin_math.h)
             const float lo = (p.relu && tcol >= p.relu_from) ? 0.f : -INFINITY;   // uniform per 16-column tile (relu_from % 16 == 0)
             const bool pk = p.pack16 && tcol >= p.pack_from;                       // (pack_from % 32 == 0)
             // AB tiles at a time: all four for the 64-wide block (its 64 accumulator registers leave room; the four residual
@@ -488,8 +499,12 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
                 for (int i = 0; i < AB; ++i) {
                     const int a = a0 + i;
                     v[i] = acc[a][b] * cs + sh;
+                    if (gelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[i][e] = gelu_f16_storage(v[i][e]);
+                    }
                     if constexpr (RES)
-                        v[i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, 0));
+                        v[i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff_a[a] + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, 0));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], lo);
                     if constexpr (ST) {
@@ -506,18 +521,18 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
                         for (int h = 0; h < 2; ++h) {
                             const float v0 = v[i][2 * h], v1 = v[i][2 * h + 1];
                             vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
-                            const f16 h0 = (f16)v0, h1 = (f16)v1;
-                            const f16 l0 = (f16)((v0 - (float)h0) * 2048.0f), l1 = (f16)((v1 - (float)h1) * 2048.0f);
+                            const f16 h0 = cvt_f16_rn(v0), h1 = cvt_f16_rn(v1);      // one rounding of the materialised fp32 value (lin_math.h)
+                            const f16 l0 = cvt_f16_rn((v0 - (float)h0) * 2048.0f), l1 = cvt_f16_rn((v1 - (float)h1) * 2048.0f);
                             hw[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
                             lw[h] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
                         }
-                        __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, koff + b * 32, ubase * 2 * p.N * 2, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, koff + b * 32 + p.N * 2, ubase * 2 * p.N * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, koff_a[a0 + i] + b * 32, ubase * 2 * p.N * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, koff_a[a0 + i] + b * 32 + p.N * 2, ubase * 2 * p.N * 2, 0);
                     }
                 } else if (!(p.ablate & 64)) {
 #pragma unroll
                     for (int i = 0; i < AB; ++i)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), c_rs, voff + b * 64,
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), c_rs, voff_a[a0 + i] + b * 64,
                                                                (wm * 64 + (TW == 8 ? (a0 + i) * 8 : (a0 + i) * 16)) * ldc * 4, 0);
                 }
             }
@@ -1069,6 +1084,186 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_x3u_kernel(const Gemm16Param
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same block structure for a DENSE contraction (the Swin linears of stages 3-4 in the fp32-class mode, swin_transformer.py:23-39,
+// 191-232): C[M][N] = A[M][K] . W[N][K]^T with A = [xh | xl'] f16 [M][2 K] and W = [wh 2^11 | wh | wl'] f16 [N][3 K].
+// 256 x 128 tile, four waves (a wave: 64 rows x 128 columns, 128 accumulator registers), TWO blocks per CU, v_mfma_f32_16x16x32_f16,
+// a real 32-channel chunk = three steps: xh.wh 2^11, xh.wl' (the xh fragments stay in registers), xl'.wh.  There is no halo to re-use:
+// a chunk moves two 16-KB A parts and three 8-KB weight tiles, 14 DMA pieces per wave and chunk (gemm_f16.hip's K loop over the virtual
+// 3 K columns: 18, xh twice).  LDS: THREE A slots through which the parts h(0) l(0) h(1) l(1) ... rotate (part p in slot p % 3; part
+// p + 3 is requested at the barrier behind part p's last use) and FOUR weight slots (step s in slot s & 3), both three steps ahead;
+// counted vmcnt (in-order landing): at a step the pieces of the last two steps may still be in flight.
+// Per step: r = 0 requests weights(s + 3) and h(c + 1) (6 pieces per wave), r = 1 weights (2), r = 2 weights and l(c + 1) (6).
+// Ragged M: rows past M are an offset past the A descriptor (zeros) and a store offset past the output descriptors (dropped).
+template <int BN>
+__global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = 4, TN = BN / 16, BJ = BN / 64;
+    constexpr int A_SLOT = 256 * 64, B_SLOT = BN * 64;
+    static_assert(2 * (3 * A_SLOT + 4 * B_SLOT) <= 160 * 1024, "two blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[3 * A_SLOT + 4 * B_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int nnt = p.N / BN;
+    int mtile, ntile;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        mtile = L / nnt;
+        ntile = L - mtile * nnt;
+    }
+    const int m_blk = mtile * 256, n_blk = ntile * BN;
+    const int m_valid = p.M - m_blk < 256 ? p.M - m_blk : 256;
+    const int Kr = p.K / 3;                       // real K; A rows are [xh (Kr) | xl' (Kr)], weight rows [wh 2^11 | wh | wl'] (Kr each)
+    const int ncr = Kr / 32;
+    const unsigned a32 = (unsigned)(uintptr_t)lds, b32 = a32 + 3 * A_SLOT;
+
+    const __amdgpu_buffer_rsrc_t a_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m_blk * p.lda), 0, (int)((long long)m_valid * p.lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long long)n_blk * p.ldb), 0, (int)((long long)BN * p.ldb * 2), 0x00020000);
+    int av[4], wv[BJ];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                 // this wave's A pieces: rows (4 wm + j) 16 .. + 16 of the tile
+        const int row = (wm * 4 + j) * 16 + (lane >> 2);
+        const int cg = (lane & 3) ^ (((row >> 3) & 1) << 1);
+        av[j] = row < m_valid ? (int)(((long long)row * p.lda + cg * 8) * 2) : 0x7fffff00;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (wm * BJ + j) * 16 + (lane >> 2);
+        const int cg = (lane & 3) ^ (((row >> 3) & 1) << 1);
+        wv[j] = (int)(((long long)row * p.ldb + cg * 8) * 2);
+    }
+    auto issue_a = [&](int part, int slot) __attribute__((always_inline)) {      // part 2 c: xh of chunk c, 2 c + 1: xl'
+        const int soff = (part & 1) * Kr * 2 + (part >> 1) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(lds + slot * A_SLOT + (wm * 4 + j) * 1024), 16, av[j], soff, 0, 0);
+    };
+    auto issue_w = [&](int c, int r, int slot) __attribute__((always_inline)) {  // step r of chunk c: weight parts 0, 2, 1
+        const int part = r == 0 ? 0 : r == 1 ? 2 : 1;
+        const int soff = part * Kr * 2 + c * 64;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, LPTR(lds + 3 * A_SLOT + slot * B_SLOT + (wm * BJ + j) * 1024), 16, wv[j], soff, 0, 0);
+    };
+    // prologue = the requests of steps -3, -2, -1
+    issue_w(0, 0, 0);
+    issue_a(0, 0);
+    issue_w(0, 1, 1);
+    issue_w(0, 2, 2);
+    issue_a(1, 1);
+
+    const int pj = pi16(l16);
+    const unsigned swz = (unsigned)((lq ^ (((pj >> 3) & 1) << 1)) * 16);
+    unsigned aa[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) aa[a] = a32 + (unsigned)((wm * 64 + a * 16 + pj) * 64) + swz;
+    const unsigned bx = b32 + (unsigned)(pj * 64) + swz;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    half8 fa[TM], fb[TN];
+    int sa_h = 0, sa_l = 1;                       // A slots of this chunk's parts: (2 c) % 3, (2 c + 1) % 3
+    for (int c = 0; c < ncr; ++c) {
+        const bool last = c + 1 == ncr;
+        const int s0 = c * 3;
+#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fb[b]), "v"(fa[a]))   /* weights first: D^T (x3m16_tail) */
+#define LIN_B_READS(ba)                                   \
+    LDS_READ(fb[0], ba, 0);     LDS_READ(fb[1], ba, 1024); \
+    LDS_READ(fb[2], ba, 2048);  LDS_READ(fb[3], ba, 3072); \
+    LDS_READ(fb[4], ba, 4096);  LDS_READ(fb[5], ba, 5120); \
+    LDS_READ(fb[6], ba, 6144);  LDS_READ(fb[7], ba, 7168)
+#define LIN_MM_ALL(a)                \
+    _Pragma("unroll") for (int b = 0; b < TN; ++b) MMA(a, b)
+        static_assert(TN == 8, "fragment reads below are written for the 128-wide tile");
+        {   // ---- r = 0: xh . wh 2^11
+            wait_vm_imm<(BJ + 4) + BJ>();        // in flight at most: the pieces of steps s - 1 (weights + an A part) and s - 2 (weights)
+            RAW_BARRIER();
+            if (!last) {
+                issue_w(c + 1, 0, (s0 + 3) & 3);
+                issue_a(2 * c + 2, sa_h == 0 ? 2 : sa_h - 1);     // h(c + 1) -> slot (2 c + 2) % 3 = (sa_h + 2) % 3
+            }
+            const unsigned ao = (unsigned)(sa_h * A_SLOT), ba = bx + (unsigned)((s0 & 3) * B_SLOT);
+            LDS_READ(fa[0], aa[0] + ao, 0);
+            LIN_B_READS(ba);
+            LDS_READ(fa[1], aa[1] + ao, 0);
+            LDS_READ(fa[2], aa[2] + ao, 0);
+            LDS_READ(fa[3], aa[3] + ao, 0);
+            lgkm_wait1<11>(fa[0]);
+            lgkm_wait1<10>(fb[0]); MMA(0, 0);
+            lgkm_wait1<9>(fb[1]);  MMA(0, 1);
+            lgkm_wait1<8>(fb[2]);  MMA(0, 2);
+            lgkm_wait1<7>(fb[3]);  MMA(0, 3);
+            lgkm_wait1<6>(fb[4]);  MMA(0, 4);
+            lgkm_wait1<5>(fb[5]);  MMA(0, 5);
+            lgkm_wait1<4>(fb[6]);  MMA(0, 6);
+            lgkm_wait1<3>(fb[7]);  MMA(0, 7);
+            lgkm_wait1<2>(fa[1]);  LIN_MM_ALL(1);
+            lgkm_wait1<1>(fa[2]);  LIN_MM_ALL(2);
+            lgkm_wait1<0>(fa[3]);  LIN_MM_ALL(3);
+        }
+        {   // ---- r = 1: xh . wl' (the xh fragments are in registers)
+            if (last) wait_vm_imm<BJ + 4>(); else wait_vm_imm<2 * (BJ + 4)>();
+            RAW_BARRIER();
+            if (!last) issue_w(c + 1, 1, (s0 + 4) & 3);
+            const unsigned ba = bx + (unsigned)(((s0 + 1) & 3) * B_SLOT);
+            LIN_B_READS(ba);
+            lgkm_wait1<7>(fb[0]); MMA(0, 0);
+            lgkm_wait1<6>(fb[1]); MMA(0, 1);
+            lgkm_wait1<5>(fb[2]); MMA(0, 2);
+            lgkm_wait1<4>(fb[3]); MMA(0, 3);
+            lgkm_wait1<3>(fb[4]); MMA(0, 4);
+            lgkm_wait1<2>(fb[5]); MMA(0, 5);
+            lgkm_wait1<1>(fb[6]); MMA(0, 6);
+            lgkm_wait1<0>(fb[7]); MMA(0, 7);
+            LIN_MM_ALL(1);
+            LIN_MM_ALL(2);
+            LIN_MM_ALL(3);
+        }
+        {   // ---- r = 2: xl' . wh
+            if (last) wait_vm_imm<0>(); else wait_vm_imm<BJ + BJ + 4>();
+            RAW_BARRIER();
+            if (!last) {
+                issue_w(c + 1, 2, (s0 + 5) & 3);
+                issue_a(2 * c + 3, sa_h);                          // l(c + 1) -> slot (2 c + 3) % 3 = the slot h(c) just left
+            }
+            const unsigned ao = (unsigned)(sa_l * A_SLOT), ba = bx + (unsigned)(((s0 + 2) & 3) * B_SLOT);
+            LDS_READ(fa[0], aa[0] + ao, 0);
+            LIN_B_READS(ba);
+            LDS_READ(fa[1], aa[1] + ao, 0);
+            LDS_READ(fa[2], aa[2] + ao, 0);
+            LDS_READ(fa[3], aa[3] + ao, 0);
+            lgkm_wait1<11>(fa[0]);
+            lgkm_wait1<10>(fb[0]); MMA(0, 0);
+            lgkm_wait1<9>(fb[1]);  MMA(0, 1);
+            lgkm_wait1<8>(fb[2]);  MMA(0, 2);
+            lgkm_wait1<7>(fb[3]);  MMA(0, 3);
+            lgkm_wait1<6>(fb[4]);  MMA(0, 4);
+            lgkm_wait1<5>(fb[5]);  MMA(0, 5);
+            lgkm_wait1<4>(fb[6]);  MMA(0, 6);
+            lgkm_wait1<3>(fb[7]);  MMA(0, 7);
+            lgkm_wait1<2>(fa[1]);  LIN_MM_ALL(1);
+            lgkm_wait1<1>(fa[2]);  LIN_MM_ALL(2);
+            lgkm_wait1<0>(fa[3]);  LIN_MM_ALL(3);
+        }
+#undef LIN_MM_ALL
+#undef LIN_B_READS
+#undef MMA
+        // next chunk: h -> (2 c + 2) % 3, l -> (2 c + 3) % 3
+        const int nh = sa_h == 0 ? 2 : sa_h - 1;
+        sa_l = sa_h;
+        sa_h = nh;
+    }
+    x3m16_tail<16, 1, BN, true>(p, acc, lds, tid, wm, mtile, n_blk, 0, 0, 1);
+#endif
+}
+
 template <int TW, int IMGS>
 int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
@@ -1132,6 +1327,34 @@ int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p0) {
     } else if (p.W == 32) launch_x3<32, 1>(ctx, p);
     else if (p.W == 16) launch_x3<16, 1>(ctx, p);
     else launch_x3<8, 2>(ctx, p);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+
+// ---- dense form (Swin linears, fp32-class mode): launched for EVERY batch size of a layer it supports - which arithmetic a layer runs
+// in must not depend on how many images a pass holds
+bool lin_x3_supported(const reid_ctx* ctx, const Gemm16Params& p) {
+    const int Kr = p.K / 3;
+    return ctx->lin_x3 && ctx->split_x3 >= 2 && p.lin && p.split_terms == 3 && p.K % 96 == 0 && p.N % 128 == 0 && p.n_real == p.N && p.lda == 2 * Kr &&
+           p.ldb == 3 * Kr && !p.scat_h && !p.par4 && (p.C32 != nullptr) != (p.pack_out != 0) &&
+           256ll * p.lda * 2 < 0x7f000000ll && 128ll * p.ldb * 2 < 0x7f000000ll && 256ll * p.ldc * 4 < 0x7f000000ll;
+}
+
+int launch_lin_x3(reid_ctx* ctx, const Gemm16Params& p0, int kind, double flops, double bytes) {
+    Gemm16Params p = p0;
+    p.fault = ctx->fault;
+    p.ablate = ctx->x3_ablate;
+    p.stats = nullptr; p.col_scale = nullptr; p.relu = 0; p.split_k = 1;
+    if (p.pack_out) {            // [yh | yl'] f16 [M][2 N]
+        p.pack16 = p.C;
+        p.pack_from = 0;
+        p.C32 = nullptr;
+    } else {
+        p.pack16 = nullptr;
+    }
+    prof_begin(ctx, kind, flops, bytes);
+    hipLaunchKernelGGL((lin_x3_kernel<128>), dim3(((p.M + 255) / 256) * (p.N / 128)), dim3(256), 0, ctx->stream, p);
+    prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
 }

@@ -197,6 +197,8 @@ int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double fl
 int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build, see Gemm16Params
 bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p);   // conv3x3_x3.hip: the same convolution as two 4-wave blocks per CU (large launches)
 int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p);
+bool lin_x3_supported(const reid_ctx* ctx, const Gemm16Params& p);        // conv3x3_x3.hip: the dense form (Swin linears of stages 3-4, fp32-class mode)
+int launch_lin_x3(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);
 int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build of gemm_f16 (im2col: strided / 1x1)
 bool two_linear_supported(const reid_ctx*, long long T, int C, int hid);
 int launch_two_linear(reid_ctx*, const _Float16* a16, long long T, int C, int hid, const float* w1, const float* b1, const float* w2,
@@ -369,6 +371,7 @@ struct reid_ctx {
     int f32_conv = 1;        // fp32 path (REID_F32_CONV): 1 = conv_f32.hip LDS-DMA kernel, norms in the producer's epilogue / in_apply;
                              // 2 = conv_f32.hip register-staged kernel, norm in the loader; 0 = gemm_f32_kernel<A_IM2COL> (round 1)
     int f32_split_k = 1;     // fp32 conv: split the K-tiles over 2-4 blocks per output tile when a launch has <= 256 tiles (REID_F32_SPLITK)
+    int lin_x3 = 1;          // Swin, fp32-class mode: linears with N % 128 == 0 on conv3x3_x3.hip's dense kernel (0: gemm_f16.hip's linear build)
     int f32_dist_bk16 = 1;   // distance matrix, 128-wide tiles: K-tiles of 16 -> three blocks per CU (gemm_f32_dma.hip); 0 = K-tiles of 32, two blocks
     int pack_epilogue = 1;   // precision 2: conv1 epilogues write [yh | yl'] for conv2 themselves (REID_PACK_EPILOGUE=0: fp32 + pack passes)
     int split_lean_epi = 1;  // precision 2: buffer-instruction epilogue of the SPLIT convolution builds (REID_SPLIT_LEAN=0: general loop)

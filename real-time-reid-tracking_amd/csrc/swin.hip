@@ -966,6 +966,8 @@ int linear(reid_ctx* ctx, const float* x, long long m, int k, const float* w, co
         }
         q.col_shift = bias; q.lin = 1; q.act = act; q.n_real = n; q.res32 = residual;
         q.split_terms = 3; q.a_k = 2 * k; q.acc_scale = 1.0f / 2048.0f;
+        if (lin_x3_supported(ctx, q))     // stages 3-4 (N % 128 == 0): 4-wave blocks, two per CU, xh fragments shared by two of the three products
+            return launch_lin_x3(ctx, q, REID_K_CONV_GEMM, 2.0 * m * n * k, 4.0 * ((double)m * k + (double)n * k + (double)m * n));
         return launch_gemm_f16(ctx, A16_DENSE, q, REID_K_CONV_GEMM, 2.0 * m * n * k, 4.0 * ((double)m * k + (double)n * k + (double)m * n));
     }
     GemmParams p;

@@ -2207,3 +2207,30 @@ def test_swin_embeddings_do_not_depend_on_the_pass_size(eng):
         eng.set_precision(0)
         eng.set_chunk(1024)
     assert np.abs(ref[1] - ref[0]).max() <= 2e-6 * np.abs(ref[0]).max()       # fp32-class against exact fp32
+
+
+@pytest.mark.gpu
+def test_swin_dense_x3_kernel_agrees_with_the_gemm_f16_linear_build(eng):
+    """conv3x3_x3.hip, lin_x3_kernel (round 5): the stage 3-4 linears of the fp32-class mode (N % 128 == 0) as 4-wave blocks, two per CU,
+    on v_mfma_f32_16x16x32_f16 - the xh fragments shared by two of the three products - for EVERY batch size (ragged last tiles: 1, 3 and 7
+    images are 196-, 588- and 1372-row matrices in stage 3, 49 / 147 / 343 rows in stage 4).  Same three products per multiply, another
+    summation order than gemm_f16.hip's linear build (debug switch lin_x3 = 0): agreement at the mode's error level, both inside the
+    mode's bound against exact fp32; an image's embedding does not depend on its batch (swin_transformer.py:191-232, 248-260)."""
+    eng.load_swin(*weights.pack_swin(synth.swin_state_dict(0))[:2])
+    x = synth.images_f32(7, 9)
+    try:
+        eng.set_precision(0)
+        exact = eng.swin_embed_f32_nchw(x)
+        eng.set_precision(2)
+        eng.debug_switch("lin_x3", 0)
+        old = eng.swin_embed_f32_nchw(x)
+        eng.debug_switch("lin_x3", 1)
+        new = eng.swin_embed_f32_nchw(x)
+        assert not np.array_equal(new, old)                                      # the switch did select the other kernel
+        scale = np.abs(exact).max()
+        assert np.abs(new - old).max() <= 2e-6 * scale
+        assert np.abs(new - exact).max() <= 2e-6 * scale and np.abs(old - exact).max() <= 2e-6 * scale
+        assert np.array_equal(eng.swin_embed_f32_nchw(x[:1]), new[:1]) and np.array_equal(eng.swin_embed_f32_nchw(x[2:5]), new[2:5])
+    finally:
+        eng.debug_switch("lin_x3", 1)
+        eng.set_precision(0)
