@@ -499,14 +499,16 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
                 for (int i = 0; i < AB; ++i) {
                     const int a = a0 + i;
                     v[i] = acc[a][b] * cs + sh;
-                    if (gelu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[i][e] = gelu_f16_storage(v[i][e]);
+                    if (gelu) {      // two values per instruction: bit-identical to the scalar function (lin_math.h)
+                        const gelu_f32x2 g0 = gelu2_f16_storage(gelu_f32x2{v[i][0], v[i][1]}), g1 = gelu2_f16_storage(gelu_f32x2{v[i][2], v[i][3]});
+                        v[i] = f32x4{g0.x, g0.y, g1.x, g1.y};
                     }
                     if constexpr (RES)
                         v[i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff_a[a] + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, 0));
+                    if (!LIN) {      // (linear layers have no ReLU)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], lo);
+                        for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], lo);
+                    }
                     if constexpr (ST) {
                         t1 += v[i];
                         t2 += v[i] * v[i];
@@ -1136,13 +1138,16 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
         const int cg = (lane & 3) ^ (((row >> 3) & 1) << 1);
         wv[j] = (int)(((long long)row * p.ldb + cg * 8) * 2);
     }
+    const int abl = p.ablate;     // timing experiments (debug switch x3_ablate; WRONG results): 1 no weight DMA in the loop, 2 no A DMA, 4 no fragment reads
     auto issue_a = [&](int part, int slot) __attribute__((always_inline)) {      // part 2 c: xh of chunk c, 2 c + 1: xl'
+        if ((abl & 2) && part > 1) return;
         const int soff = (part & 1) * Kr * 2 + (part >> 1) * 64;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(lds + slot * A_SLOT + (wm * 4 + j) * 1024), 16, av[j], soff, 0, 0);
     };
     auto issue_w = [&](int c, int r, int slot) __attribute__((always_inline)) {  // step r of chunk c: weight parts 0, 2, 1
+        if ((abl & 1) && c > 0) return;
         const int part = r == 0 ? 0 : r == 1 ? 2 : 1;
         const int soff = part * Kr * 2 + c * 64;
 #pragma unroll
@@ -1190,11 +1195,13 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
                 issue_a(2 * c + 2, sa_h == 0 ? 2 : sa_h - 1);     // h(c + 1) -> slot (2 c + 2) % 3 = (sa_h + 2) % 3
             }
             const unsigned ao = (unsigned)(sa_h * A_SLOT), ba = bx + (unsigned)((s0 & 3) * B_SLOT);
-            LDS_READ(fa[0], aa[0] + ao, 0);
-            LIN_B_READS(ba);
-            LDS_READ(fa[1], aa[1] + ao, 0);
-            LDS_READ(fa[2], aa[2] + ao, 0);
-            LDS_READ(fa[3], aa[3] + ao, 0);
+            if (!(abl & 4)) {
+                LDS_READ(fa[0], aa[0] + ao, 0);
+                LIN_B_READS(ba);
+                LDS_READ(fa[1], aa[1] + ao, 0);
+                LDS_READ(fa[2], aa[2] + ao, 0);
+                LDS_READ(fa[3], aa[3] + ao, 0);
+            }
             lgkm_wait1<11>(fa[0]);
             lgkm_wait1<10>(fb[0]); MMA(0, 0);
             lgkm_wait1<9>(fb[1]);  MMA(0, 1);
@@ -1213,7 +1220,7 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
             RAW_BARRIER();
             if (!last) issue_w(c + 1, 1, (s0 + 4) & 3);
             const unsigned ba = bx + (unsigned)(((s0 + 1) & 3) * B_SLOT);
-            LIN_B_READS(ba);
+            if (!(abl & 4)) { LIN_B_READS(ba); }
             lgkm_wait1<7>(fb[0]); MMA(0, 0);
             lgkm_wait1<6>(fb[1]); MMA(0, 1);
             lgkm_wait1<5>(fb[2]); MMA(0, 2);
@@ -1234,11 +1241,13 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
                 issue_a(2 * c + 3, sa_h);                          // l(c + 1) -> slot (2 c + 3) % 3 = the slot h(c) just left
             }
             const unsigned ao = (unsigned)(sa_l * A_SLOT), ba = bx + (unsigned)(((s0 + 2) & 3) * B_SLOT);
-            LDS_READ(fa[0], aa[0] + ao, 0);
-            LIN_B_READS(ba);
-            LDS_READ(fa[1], aa[1] + ao, 0);
-            LDS_READ(fa[2], aa[2] + ao, 0);
-            LDS_READ(fa[3], aa[3] + ao, 0);
+            if (!(abl & 4)) {
+                LDS_READ(fa[0], aa[0] + ao, 0);
+                LIN_B_READS(ba);
+                LDS_READ(fa[1], aa[1] + ao, 0);
+                LDS_READ(fa[2], aa[2] + ao, 0);
+                LDS_READ(fa[3], aa[3] + ao, 0);
+            }
             lgkm_wait1<11>(fa[0]);
             lgkm_wait1<10>(fb[0]); MMA(0, 0);
             lgkm_wait1<9>(fb[1]);  MMA(0, 1);

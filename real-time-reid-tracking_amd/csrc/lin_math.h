@@ -23,6 +23,28 @@ __device__ __forceinline__ float gelu_f16_storage(float v) {
     return fmaf(h, copysignf(erfz, v), h);
 }
 
+// The same function on a PAIR of values: every multiply-add is the packed form of the scalar one (v_pk_mul_f32 / v_pk_fma_f32 /
+// v_pk_add_f32 round each half like their scalar counterparts), so the two results are bit-identical to gelu_f16_storage() of the halves -
+// at ~10 issue slots per value instead of ~17 (conv3x3_x3.hip, lin_x3_kernel: a 256 x 128 tile of fc1 is 128 values per lane, and
+// beside the other block's MFMAs every vector instruction waits 11-45 cycles for its slot).
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f32x2 gelu2_f16_storage(gelu_f32x2 v) {
+    const gelu_f32x2 z = gelu_f32x2{fabsf(v.x), fabsf(v.y)} * 0.70710678118654752440f;
+    gelu_f32x2 q = __builtin_elementwise_fma(gelu_f32x2{0.0000430638f, 0.0000430638f}, z, gelu_f32x2{0.0002765672f, 0.0002765672f});
+    q = __builtin_elementwise_fma(q, z, gelu_f32x2{0.0001520143f, 0.0001520143f});
+    q = __builtin_elementwise_fma(q, z, gelu_f32x2{0.0092705272f, 0.0092705272f});
+    q = __builtin_elementwise_fma(q, z, gelu_f32x2{0.0422820123f, 0.0422820123f});
+    q = __builtin_elementwise_fma(q, z, gelu_f32x2{0.0705230784f, 0.0705230784f});
+    q = __builtin_elementwise_fma(q, z, gelu_f32x2{1.0f, 1.0f});
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    const gelu_f32x2 erfz = gelu_f32x2{1.0f - __builtin_amdgcn_rcpf(q.x), 1.0f - __builtin_amdgcn_rcpf(q.y)};
+    const gelu_f32x2 h = v * 0.5f;
+    return __builtin_elementwise_fma(h, gelu_f32x2{copysignf(erfz.x, v.x), copysignf(erfz.y, v.y)}, h);
+}
+
 // fp32 -> f16 with the fp32 value MATERIALISED first.  Without the (empty) asm the compiler folds the conversion into the
 // instruction that produced the value - v_fma_mixlo_f16 computes fma(a, b, c) and rounds the exact result ONCE to f16 - and it
 // does so per unrolled instance: in the round-3 build 63 of the 64 GELU instances of the 128-wide linear kernel ended in
