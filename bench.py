@@ -379,8 +379,9 @@ def run_swin(job, args):
                               "algorithmic_bytes_per_launch": round(g["bytes"] / max(1, g["launches"]), 1),
                               "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / peak, 4)} if f16 else
                              {"kernel": ("Swin Linear / conv contractions, fp32-class (stages 1-2: fused pairs of linears and LayerNorm + "
-                                         "to_qkv of two_linear_f16.hip; the rest: gemm_f16 linear builds; hi/lo-split operands, "
-                                         "3 x v_mfma_f32_32x32x16_f16 per multiply; peak = f16 dense / 3)" if x3 else
+                                         "to_qkv of two_linear_f16.hip; stages 3-4: lin_x3_kernel - 4-wave blocks, two per CU, v_mfma_f32_16x16x32_f16; "
+                                         "the trunk convolutions: gemm_f16 linear builds; hi/lo-split operands, three f16 MFMA products "
+                                         "per multiply; peak = f16 dense / 3)" if x3 else
                                          "Swin Linear / conv contractions (gemm_f32_dma / conv_f32_dma, v_mfma_f32_32x32x2_f32)"),
                               "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                               "traffic": traffic_from_profile("swin_f16x3" if x3 else "swin_f32"), "launches": g["launches"],

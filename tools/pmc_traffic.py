@@ -33,8 +33,8 @@ elif MODE == "swin_f16":
     CONV = re.compile(r"gemm_f16_kernel")
     LABEL = "Swin Linear / conv contractions of the fp16-storage path (gemm_f16 linear builds)"
 elif MODE == "swin_f16x3":
-    CONV = re.compile(r"gemm_f16_kernel|two_linear_f16x3_kernel|ln_linear_f16x3_kernel")
-    LABEL = ("Swin Linear / conv contractions of the fp32-class path (gemm_f16 linear builds over hi/lo-split operands, the fused "
+    CONV = re.compile(r"gemm_f16_kernel|lin_x3_kernel|two_linear_f16x3_kernel|ln_linear_f16x3_kernel")
+    LABEL = ("Swin Linear / conv contractions of the fp32-class path (lin_x3_kernel / gemm_f16 linear builds over hi/lo-split operands, the fused "
              "pairs of linears and LayerNorm + to_qkv of stages 1-2: two_linear_f16.hip)")
 else:
     CONV = re.compile(r"conv3x3_f16_kernel|conv3x3_c64_f16_kernel|stem_pool_f16_kernel|gemm_f16_kernel")
