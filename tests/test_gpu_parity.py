@@ -161,6 +161,24 @@ def test_two_blocks_per_cu_convolution_matches_reference_fixture(eng, golden_dir
         eng.set_precision(0)
 
 
+def test_unrolled_and_looped_two_blocks_per_cu_kernels_agree_bit_for_bit(eng):
+    """conv3x3_x3.hip: conv3x3_x3u_kernel (a chunk's 27 steps unrolled, buffer descriptors: the default) and conv3x3_x3m16_kernel (run-time
+    step loop: what a pass takes whose input passes the 2-GB range of a descriptor, e.g. 4096 crops in ONE pass) run the same tiles in the
+    same order through the same epilogue: identical embeddings at the launch sizes of a 1024-crop pass (debug switch x3_unroll)."""
+    eng.load_seres18(*weights.pack_seres18(synth.seres18_state_dict(0))[:2])
+    crops = synth.crops_u8(1024, 5)
+    try:
+        eng.set_precision(2)
+        eng.set_chunk(1024)
+        unrolled = eng.embed_u8(crops)
+        eng.debug_switch("x3_unroll", 0)
+        looped = eng.embed_u8(crops)
+    finally:
+        eng.debug_switch("x3_unroll", 3)
+        eng.set_precision(0)
+    assert np.isfinite(unrolled).all() and np.array_equal(unrolled, looped)
+
+
 def test_fused_stem_pool_is_the_same_for_whole_images_and_strips(eng_w0):
     """stem_f32.hip with the max-pool on its accumulators: 520 crops in one pass (a block walks a whole image) and in chunks of
     260 (32-tile strips, each recomputing the tile above it) run the same arithmetic per pixel - bit-identical embeddings.
