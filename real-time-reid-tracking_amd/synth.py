@@ -288,6 +288,13 @@ def images_f32(n, seed=0, h=224, w=224):
     return np.clip(x, -1, 1).astype(np.float32)
 
 
+def noise_images_f32(n, seed=0, h=224, w=224):
+    """Normalised float images [n,3,h,w], every pixel uniform in [-1,1): the Swin counterpart of ``crops_u8`` (embeddings of noise
+    are nearly parallel, so the reference's top-2 gaps are tiny - the hard set of tests/golden/swin_config.npz)."""
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-1.0, 1.0, (n, 3, h, w)).astype(np.float32)
+
+
 # ------------------------------------------------------------------------------------------------ evaluation-harness problem
 def _id_pattern(rng, h, w):
     yy = np.linspace(0, 1, h, dtype=np.float32)[None, :, None]

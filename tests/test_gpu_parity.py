@@ -1023,6 +1023,60 @@ def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, c
                   % (precision, chunk, [(int(r), float(gap[r])) for r in flips]))
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("layout", ["one_pass_64", "four_passes_16", "pass_1024_shuffled_copies"])
+@pytest.mark.parametrize("precision", [0, 1, 2])
+@pytest.mark.parametrize("tag,img_fn,seed", [("noise0", synth.noise_images_f32, 0), ("smooth11", synth.images_f32, 11)])
+def test_swin_config_against_reference_vectors(eng, golden_dir, precision, tag, img_fn, seed, layout):
+    """BASELINE configs[2]'s rank parity (north_star: "argmin ranks bit-exact"), the Swin counterpart of
+    test_config1_against_reference_vectors: 64 images -> emb[64,96] -> (1 - cos) / 2 matrix -> row arg-min against vectors the
+    REFERENCE's own swin_t + cosine_dist produced (tests/golden/swin_config.npz, oracle/gen_golden.py:gen_swin_config;
+    /root/reference/reid/backbones/swin_transformer.py:397-427, reid/losses/utils.py:12-18), at three pass layouts: the 64 images as
+    one pass, as four passes of 16, and as 1024 images (64 distinct x 16, shuffled) in ONE pass of the bench's size - copies must
+    then be bit-identical and the first copy of each image gives the 64 rows.  Bar = config 1's: no arg-min may differ where the
+    reference separates the two candidates by more than the asserted matrix noise; on the structured set (every row decided) none
+    at all in the exact-fp32 and the fp32-class mode; sub-noise rows of the noise set that differ are printed."""
+    g = np.load(os.path.join(golden_dir, "swin_config.npz"))
+    ref, gap = g[tag + "_emb"], g[tag + "_gap"]
+    eng.load_swin(*weights.pack_swin(synth.swin_state_dict(0))[:2])
+    base = img_fn(64, seed)
+    eng.set_precision(precision)
+    try:
+        if layout == "pass_1024_shuffled_copies":
+            ids = np.repeat(np.arange(64), 16)
+            np.random.default_rng(31).shuffle(ids)
+            eng.set_chunk(1024)
+            big = eng.swin_embed_f32_nchw(base[ids])
+            first = np.asarray([np.flatnonzero(ids == c)[0] for c in range(64)])
+            assert np.array_equal(big, big[first][ids])                  # copies of an image: bit-identical wherever they sit
+            emb = big[first]
+        else:
+            eng.set_chunk(64 if layout == "one_pass_64" else 16)
+            emb = eng.swin_embed_f32_nchw(base)
+    finally:
+        eng.set_precision(0)
+        eng.set_chunk(1024)
+    cos = (emb * ref).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(ref, axis=1)
+    f16s = precision == 1
+    assert (1 - cos).max() < (1e-4 if f16s else 1e-5)                     # north_star allows 1e-3
+    dist = eng.distmat(emb, emb, _ffi.METRIC_COS_HALF)
+    np.testing.assert_allclose(dist, g[tag + "_cosdist"], atol=(2e-4 if f16s else 2e-6))
+    d = dist.copy()
+    np.fill_diagonal(d, np.inf)
+    flips = np.flatnonzero(d.argmin(1) != g[tag + "_argmin"])
+    noise = 2e-4 if f16s else 2e-6                                        # the distance error asserted above
+    decided = int((gap >= noise).sum())
+    print("swin_config %s precision %d %s: %d of 64 rows decided (reference top-2 gap >= %.0e), %d arg-mins differ, largest gap "
+          "among them %.2e" % (tag, precision, layout, decided, noise, len(flips), gap[flips].max() if len(flips) else 0.0))
+    assert (gap[flips] < noise).all(), (flips, gap[flips])
+    if not f16s:
+        if tag == "smooth11":
+            assert decided == 64 and len(flips) == 0, (flips, gap[flips])
+        elif len(flips):
+            print("swin_config noise0 precision %d %s: sub-noise rows that differ (row, reference gap): %s"
+                  % (precision, layout, [(int(r), float(gap[r])) for r in flips]))
+
+
 @pytest.mark.parametrize("tag,sigma", [("s03", 0.3), ("s30", 3.0)])
 def test_config5_market_full_size_against_reference(eng, golden_dir, tag, sigma):
     """BASELINE configs[4] at full size, single GPU: 3368 x 15913 x 512 similarity + evaluate_all against the REFERENCE's

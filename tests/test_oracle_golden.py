@@ -122,6 +122,30 @@ def test_swin_oracle_matches_reference(golden_dir):
     assert np.isinf(m[0, 48]) and m[0, 27] == 0 and np.isinf(m[48, 0]) and m[48, 28] == 0
 
 
+@pytest.mark.parametrize("tag,fn,seed", [("noise0", synth.noise_images_f32, 0), ("smooth11", synth.images_f32, 11)])
+def test_swin_oracle_matches_reference_rank_vectors(golden_dir, tag, fn, seed):
+    """oracle/swin.py against tests/golden/swin_config.npz (the reference's swin_t on 64 images, gen_golden.gen_swin_config):
+    the first 12 images of each set (images are independent in eval mode) - embeddings, their block of the reference's
+    (1 - cos) / 2 matrix, and the arg-min inside that block wherever the reference's own gap there exceeds the noise."""
+    from oracle import matching, swin
+    g = np.load(os.path.join(golden_dir, "swin_config.npz"))
+    n = 12
+    emb = swin.embed(synth.swin_state_dict(0), fn(64, seed)[:n])
+    ref = g[tag + "_emb"][:n]
+    cos = (emb * ref).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (1 - cos).max() < 1e-6
+    dist = matching.cosine_dist(emb, emb)
+    want = g[tag + "_cosdist"][:n, :n]
+    np.testing.assert_allclose(dist, want, atol=2e-6)
+    d, w = dist.copy(), want.copy()
+    np.fill_diagonal(d, np.inf)
+    np.fill_diagonal(w, np.inf)
+    srt = np.sort(w, axis=1)
+    decided = (srt[:, 1] - srt[:, 0]) >= 4e-6
+    assert decided.sum() >= n // 2
+    assert np.array_equal(d.argmin(1)[decided], w.argmin(1)[decided])
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_rerank_oracle_matches_reference(golden_dir, tag):
     """oracle/rerank.py against the reference's compute_jaccard_distance (faiss_utils.py:147-244) run with a numpy
