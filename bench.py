@@ -813,6 +813,8 @@ def run_all(job, args):
     state["deadline"] = None
     if out is not None:
         out["plugin_default"] = plugin_default(job, out)
+        if job.world == 1:
+            out["host_path"] = host_path(job, out, args)
     return out
 
 
@@ -847,6 +849,53 @@ def plugin_default(job, out):
         res["extractor_call_30_crops_ms"] = round(el / 200 * 1e3, 3)
         res["extractor_calls_per_s"] = round(200 / el, 1)
         res["extractor_precision_after"] = ext.precision
+    except Exception as e:     # noqa: BLE001
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    return res
+
+
+def host_path(job, out, args):
+    """The path the reference actually has - host crops in, host features out (feature_extractor.py:48-53: `.to(device)` ...
+    `.cpu().numpy()`; image_reid_inference.py:116-122 per batch): `Extractor(crops)` of the drop-in surface on 256 and on `--crops`
+    host crops, PCIe transfers INSIDE the timed calls.  Never `value` (the bench contract times device-resident inputs); reported
+    beside it as crops/s and as a fraction of `value`.  The library uploads pass k + 1 and downloads pass k - 1 on a copy stream
+    under pass k's kernels (csrc/reid_internal.h host_passes); sources: one stacked uint8 array in pinned memory (reid_host_alloc),
+    the same array in pageable memory, and a Python list of per-crop views of the pinned array (the reference's argument type)."""
+    from reid_amd import synth
+    from reid_amd.extractor import Extractor
+    res = {}
+    try:
+        eng = job.eng
+        eng.set_chunk(args.chunk)
+        n = args.crops
+        ext = Extractor(synth.seres18_state_dict(0, gem_p=3.0))
+        pageable = synth.crops_u8(n, seed=1)
+        pinned = eng.pinned(pageable.nbytes).reshape(pageable.shape)
+        pinned[...] = pageable
+        value = float(out.get("value") or 0.0)
+
+        def rate(arg, count, reps):
+            ext(arg)                                           # warm-up: workspaces, the copy stream, its events
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                feats = ext(arg)
+            el = (time.perf_counter() - t0) / reps
+            assert feats.shape == (count, 512) and np.isfinite(feats).all()
+            return {"crops": count, "ms_per_call": round(el * 1e3, 3), "crops_per_s": round(count / el, 1),
+                    "fraction_of_value": round(count / el / value, 4) if value else None}
+        res["precision"] = ext.precision
+        res["pass_size"] = args.chunk
+        res["pinned"] = rate(pinned, n, 5)
+        res["crops_per_s"] = res["pinned"]["crops_per_s"]
+        res["fraction_of_value"] = res["pinned"]["fraction_of_value"]
+        res["pinned_256"] = rate(pinned[:256], min(256, n), 20)
+        res["pageable"] = rate(pageable, n, 3)
+        res["pageable_256"] = rate(pageable[:256], min(256, n), 20)
+        views = [pinned[i] for i in range(n)]
+        res["list_of_views_pinned"] = rate(views, n, 3)         # + the per-crop Python checks of the list argument
+        res["h2d_bytes_per_call"] = int(pageable.nbytes)
+        res["note"] = ("Extractor.__call__ end to end on host memory; transfers overlap the kernels pass by pass (pass k+1 up, pass k-1 "
+                       "down under pass k); the first pass's upload and the last pass's download are exposed")
     except Exception as e:     # noqa: BLE001
         res["error"] = "%s: %s" % (type(e).__name__, e)
     return res
@@ -898,9 +947,10 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["all", "embed", "batch256", "swin", "tracking", "market"], default="all",
+    ap.add_argument("--workload", choices=["all", "embed", "batch256", "swin", "tracking", "market", "host"], default="all",
                     help="all (default) = BASELINE configs[1] as the headline + the other configurations as sub-objects of the same "
-                         "line; embed = configs[1] alone; batch256 / swin / tracking / market = that configuration as its own line")
+                         "line; embed = configs[1] alone; batch256 / swin / tracking / market = that configuration as its own line; "
+                         "host = configs[1] in the headline arithmetic only + the host_path sub-object (Extractor on host crops)")
     ap.add_argument("--crops", type=int, default=4096, help="crops (images) per GPU per step (BASELINE config 2 / 3: 4096)")
     ap.add_argument("--frames", type=int, default=600, help="--workload tracking: frames of the stream")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "1024")))
@@ -911,8 +961,8 @@ def main(argv=None):
     ap.add_argument("--precision", choices=["f32", "f16", "f16x3"], default=os.environ.get("REID_PRECISION", "f16x3"),
                     help="arithmetic of the headline: f16x3 (default) = fp32-class - fp32 storage, every convolution as "
                          "three f16 matrix-core products per multiply on hi/lo-split operands with fp32 accumulation; it meets the "
-                         "exact-fp32 mode's parity bar (stage taps < 2e-5 of the reference, 1 - cos < 1e-5, 0 of 256 arg-mins differ on "
-                         "both config-1 sets: tests/test_gpu_parity.py); f32 = exact fp32 MFMA (side run f32_path); f16 = fp16 storage / "
+                         "exact-fp32 mode's parity bar (stage taps < 2e-5 of the reference, 1 - cos < 1e-5, no arg-min differs where the "
+                         "reference's top-2 gap exceeds 2e-6 and none at all on the realistic config-1 set: tests/test_gpu_parity.py); f32 = exact fp32 MFMA (side run f32_path); f16 = fp16 storage / "
                          "fp32 accumulate (side run f16_path, north_star's 1e-3 cosine tolerance)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -932,8 +982,14 @@ def main(argv=None):
     job = Job(args)
     rc = 0
     try:
+        def run_host(job_, a):
+            a.single, a.no_cpu = True, True
+            o = run_embed(job_, a)
+            if o is not None and job_.world == 1:
+                o["host_path"] = host_path(job_, o, a)
+            return o
         fn = {"all": run_all, "embed": run_embed, "batch256": run_embed, "swin": run_swin, "tracking": run_tracking,
-              "market": run_market}[args.workload]
+              "market": run_market, "host": run_host}[args.workload]
         out = fn(job, args)
         if out is not None:
             emit(json.dumps(out))

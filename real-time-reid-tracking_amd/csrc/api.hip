@@ -65,6 +65,7 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
     for (int i = 0; i < 2; ++i)
         if (ctx->frame_ev[i]) hipEventDestroy(ctx->frame_ev[i]);
     if (ctx->copy_ev) hipEventDestroy(ctx->copy_ev);
+    for (hipEvent_t e : ctx->pipe_ev) hipEventDestroy(e);
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
     for (auto& kv : ctx->ws) hipFree(kv.second.first);
     for (auto& kv : ctx->split_w) hipFree(kv.second);
@@ -1024,6 +1025,16 @@ extern "C" int reid_debug_stage(reid_ctx* ctx, int stage, float* out, size_t max
     return REID_OK;
 }
 
+int ctx_pipe_events(reid_ctx* ctx, int passes) {
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    while ((int)ctx->pipe_ev.size() < 2 * passes) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pipe_ev.push_back(e);
+    }
+    return REID_OK;
+}
+
 extern "C" int reid_embed_u8_dev(reid_ctx* ctx, const uint8_t* d_crops, int n, float* d_emb, float* d_logits) {
     ARG_CHECK(ctx && d_crops && d_emb && n >= 0);
     CTX_ENTER(ctx);
@@ -1047,11 +1058,20 @@ extern "C" int reid_embed_u8(reid_ctx* ctx, const uint8_t* crops, int n, float* 
     REID_TRY(ctx_ws(ctx, "io.in", (size_t)n * crop_b, (void**)&d_in));
     REID_TRY(ctx_ws(ctx, "io.emb", (size_t)n * 512 * 4, (void**)&d_emb));
     if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
-    HIP_TRY(hipMemcpyAsync(d_in, crops, (size_t)n * crop_b, hipMemcpyHostToDevice, ctx->stream));
-    REID_TRY(reid_embed_u8_dev(ctx, d_in, n, d_emb, d_log));
-    HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    REID_TRY(host_passes(
+        ctx, n, ctx->chunk,
+        [&](int i, int m, hipStream_t s) -> int {
+            HIP_TRY(hipMemcpyAsync(d_in + (size_t)i * crop_b, crops + (size_t)i * crop_b, (size_t)m * crop_b, hipMemcpyHostToDevice, s));
+            return REID_OK;
+        },
+        [&](int i, int m) -> int {
+            return seres18_run(ctx, d_in + (size_t)i * crop_b, true, m, d_emb + (size_t)i * 512, d_log ? d_log + (size_t)i * nc : nullptr);
+        },
+        [&](int i, int m, hipStream_t s) -> int {
+            HIP_TRY(hipMemcpyAsync(emb + (size_t)i * 512, d_emb + (size_t)i * 512, (size_t)m * 512 * 4, hipMemcpyDeviceToHost, s));
+            if (logits) HIP_TRY(hipMemcpyAsync(logits + (size_t)i * nc, d_log + (size_t)i * nc, (size_t)m * nc * 4, hipMemcpyDeviceToHost, s));
+            return REID_OK;
+        }));
     return ctx_fault_status(ctx);
 }
 
@@ -1080,11 +1100,23 @@ extern "C" int reid_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, float* 
     REID_TRY(ctx_ws(ctx, "io.in", (size_t)n * img * 4, (void**)&d_in));
     REID_TRY(ctx_ws(ctx, "io.emb", (size_t)n * 512 * 4, (void**)&d_emb));
     if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
-    HIP_TRY(hipMemcpyAsync(d_in, x, (size_t)n * img * 4, hipMemcpyHostToDevice, ctx->stream));
-    REID_TRY(reid_embed_f32_nchw_dev(ctx, d_in, n, d_emb, d_log));
-    HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    REID_TRY(host_passes(
+        ctx, n, ctx->chunk,
+        [&](int i, int m, hipStream_t s) -> int {
+            HIP_TRY(hipMemcpyAsync(d_in + (size_t)i * img, x + (size_t)i * img, (size_t)m * img * 4, hipMemcpyHostToDevice, s));
+            return REID_OK;
+        },
+        [&](int i, int m) -> int {
+            float* nhwc;
+            REID_TRY(ctx_ws(ctx, "se18.in_nhwc", (size_t)m * img * 4, (void**)&nhwc));
+            REID_TRY(launch_nchw_to_nhwc3(ctx, d_in + (size_t)i * img, m, IMG_H, IMG_W, nhwc));
+            return seres18_run(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_log ? d_log + (size_t)i * nc : nullptr);
+        },
+        [&](int i, int m, hipStream_t s) -> int {
+            HIP_TRY(hipMemcpyAsync(emb + (size_t)i * 512, d_emb + (size_t)i * 512, (size_t)m * 512 * 4, hipMemcpyDeviceToHost, s));
+            if (logits) HIP_TRY(hipMemcpyAsync(logits + (size_t)i * nc, d_log + (size_t)i * nc, (size_t)m * nc * 4, hipMemcpyDeviceToHost, s));
+            return REID_OK;
+        }));
     return ctx_fault_status(ctx);
 }
 
@@ -1147,10 +1179,57 @@ extern "C" int reid_embed_ragged_u8(reid_ctx* ctx, const uint8_t* packed, const 
     if (n == 0) return REID_OK;
     const int nc = ctx->se18.num_class;
     float *d_emb, *d_log = nullptr;
-    REID_TRY(embed_ragged_enqueue(ctx, "io", packed, offsets, hw, n, &d_emb, logits ? &d_log : nullptr, false));
-    HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n <= ctx->chunk || !ctx->host_pipeline) {
+        REID_TRY(embed_ragged_enqueue(ctx, "io", packed, offsets, hw, n, &d_emb, logits ? &d_log : nullptr, false));
+        HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 512 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return ctx_fault_status(ctx);
+    }
+    // several passes: the bytes a pass reads are the span [lowest offset, highest end) of its crops (the usual packing - crop after
+    // crop - makes the spans a partition of the buffer; any other layout copies some bytes twice, which is harmless)
+    const int passes = (n + ctx->chunk - 1) / ctx->chunk;
+    std::vector<size_t> lo(passes, (size_t)-1), hi(passes, 0);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        ARG_CHECK(hw[2 * i] >= 1 && hw[2 * i + 1] >= 1 && offsets[i] >= 0);
+        const size_t b = (size_t)offsets[i], e = b + (size_t)hw[2 * i] * hw[2 * i + 1] * 3;
+        const int k = i / ctx->chunk;
+        if (b < lo[k]) lo[k] = b;
+        if (e > hi[k]) hi[k] = e;
+        if (e > total) total = e;
+    }
+    uint8_t* d_pk;
+    char* d_meta;
+    REID_TRY(ctx_ws(ctx, "io.in", total, (void**)&d_pk));
+    REID_TRY(ctx_ws(ctx, "io.meta", (size_t)n * 16, (void**)&d_meta));
+    long long* d_off = (long long*)d_meta;
+    int* d_hw = (int*)(d_meta + (size_t)n * 8);
+    REID_TRY(ctx_ws(ctx, "io.emb", (size_t)(n + 1) * 512 * 4, (void**)&d_emb));
+    if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
+    const size_t img = (size_t)IMG_H * IMG_W * 3;
+    REID_TRY(host_passes(
+        ctx, n, ctx->chunk,
+        [&](int i, int m, hipStream_t s) -> int {
+            const int k = i / ctx->chunk;
+            if (i == 0) {
+                HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)n * 8, hipMemcpyHostToDevice, s));
+                HIP_TRY(hipMemcpyAsync(d_hw, hw, (size_t)n * 8, hipMemcpyHostToDevice, s));
+            }
+            HIP_TRY(hipMemcpyAsync(d_pk + lo[k], packed + lo[k], hi[k] - lo[k], hipMemcpyHostToDevice, s));
+            return REID_OK;
+        },
+        [&](int i, int m) -> int {
+            float* nhwc;
+            REID_TRY(ctx_ws(ctx, "se18.in_nhwc", (size_t)m * img * 4, (void**)&nhwc));
+            REID_TRY(launch_resize_norm(ctx, d_pk, d_off + i, d_hw + 2 * i, m, IMG_H, IMG_W, 0, nhwc));
+            return seres18_run(ctx, nhwc, false, m, d_emb + (size_t)i * 512, d_log ? d_log + (size_t)i * nc : nullptr);
+        },
+        [&](int i, int m, hipStream_t s) -> int {
+            HIP_TRY(hipMemcpyAsync(emb + (size_t)i * 512, d_emb + (size_t)i * 512, (size_t)m * 512 * 4, hipMemcpyDeviceToHost, s));
+            if (logits) HIP_TRY(hipMemcpyAsync(logits + (size_t)i * nc, d_log + (size_t)i * nc, (size_t)m * nc * 4, hipMemcpyDeviceToHost, s));
+            return REID_OK;
+        }));
     return ctx_fault_status(ctx);
 }
 

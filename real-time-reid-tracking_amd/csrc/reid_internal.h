@@ -420,6 +420,9 @@ struct reid_ctx {
     hipEvent_t frame_ev[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;   // uploads of the frame pipeline (beside the kernels of the previous frame)
     hipEvent_t copy_ev = nullptr;
+    std::vector<hipEvent_t> pipe_ev;     // host_passes (api.hip): "pass k uploaded" / "pass k computed" events of the host-in / host-out entry points
+    int host_pipeline = 1;               // host entry points with more than one pass: pass k + 1's upload and pass k - 1's download on the copy stream
+                                         // under pass k's kernels (0: whole batch up, compute, whole result down - the form of rounds 1-5)
     int side_copy = 1;                   // REID_SIDE_COPY=0: uploads in the compute stream
     std::vector<int32_t> side_idx;       // reid_ctx_set_side_index: camera / view index per image of the following embed call(s)
     size_t side_cursor = 0;              // how many of them the passes so far have consumed
@@ -503,6 +506,63 @@ int ctx_take_side(reid_ctx* ctx, int n, int rows, const char* what, const int32_
 // x[img][p][c] += coeff * table[idx[img]][c] (elementwise.hip)
 int launch_add_indexed_rows(reid_ctx* ctx, float* x, int n, long long hw, int C, const float* table, const int32_t* d_idx, float coeff);
 int ctx_pinned(reid_ctx* ctx, const char* name, size_t bytes, void** out);   // grow-only named pinned host buffer
+int ctx_pipe_events(reid_ctx* ctx, int passes);   // api.hip: the copy stream + 2 events per pass (host_passes)
+
+// Host in -> host out in passes.  The reference's loops move every batch across PCIe (feature_extractor.py:48-53 `.to(device)` ...
+// `.cpu().numpy()`, image_reid_inference.py:116-122); a caller that hands over host buffers pays that too, so the entry points hide it:
+// pass k + 1's upload and pass k - 1's download are queued on the context's copy stream while pass k's kernels run on its compute
+// stream (pinned sources copy asynchronously; a pageable one blocks the HOST inside hipMemcpyAsync, after pass k has been queued, so
+// the device stays busy either way).  up(i, m, s) queues the upload of items [i, i + m) on stream s, run(i, m) the kernels on
+// ctx->stream, down(i, m, s) the download.  The passes are the same passes, in the same order, on the same stream as without the
+// pipeline: results are bit-identical.  One pass (or host_pipeline = 0): everything on the compute stream, as before.
+template <class Up, class Run, class Down>
+int host_passes(reid_ctx* ctx, int n, int pass, Up up, Run run, Down down) {
+    const int passes = (n + pass - 1) / pass;
+    if (passes <= 1 || !ctx->host_pipeline) {
+        REID_TRY(up(0, n, ctx->stream));
+        for (int i = 0; i < n; i += pass) REID_TRY(run(i, n - i < pass ? n - i : pass));
+        REID_TRY(down(0, n, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return REID_OK;
+    }
+    REID_TRY(ctx_pipe_events(ctx, passes));
+    hipStream_t cs = ctx->copy_stream;
+    hipEvent_t* up_ev = ctx->pipe_ev.data();
+    hipEvent_t* run_ev = ctx->pipe_ev.data() + passes;
+    auto span = [&](int k, int* i, int* m) { *i = k * pass; *m = n - *i < pass ? n - *i : pass; };
+    int i, m, rc = REID_OK;
+    span(0, &i, &m);
+    rc = up(i, m, cs);
+    if (rc == REID_OK && hipEventRecord(up_ev[0], cs) != hipSuccess) rc = REID_ERR_HIP;
+    for (int k = 0; k < passes && rc == REID_OK; ++k) {
+        span(k, &i, &m);
+        if (hipStreamWaitEvent(ctx->stream, up_ev[k], 0) != hipSuccess) { rc = REID_ERR_HIP; break; }
+        if ((rc = run(i, m)) != REID_OK) break;
+        if (hipEventRecord(run_ev[k], ctx->stream) != hipSuccess) { rc = REID_ERR_HIP; break; }
+        if (k + 1 < passes) {
+            span(k + 1, &i, &m);
+            if ((rc = up(i, m, cs)) != REID_OK) break;
+            if (hipEventRecord(up_ev[k + 1], cs) != hipSuccess) { rc = REID_ERR_HIP; break; }
+        }
+        if (k >= 1) {
+            span(k - 1, &i, &m);
+            if (hipStreamWaitEvent(cs, run_ev[k - 1], 0) != hipSuccess) { rc = REID_ERR_HIP; break; }
+            if ((rc = down(i, m, cs)) != REID_OK) break;
+        }
+    }
+    if (rc == REID_OK) {
+        span(passes - 1, &i, &m);
+        if (hipStreamWaitEvent(cs, run_ev[passes - 1], 0) != hipSuccess) rc = REID_ERR_HIP;
+        else rc = down(i, m, cs);
+    }
+    // both streams are drained on every path: the caller's buffers must not be touched after the call returns
+    const hipError_t e1 = hipStreamSynchronize(cs), e2 = hipStreamSynchronize(ctx->stream);
+    if (rc == REID_OK && (e1 != hipSuccess || e2 != hipSuccess)) {
+        reid_set_error("host_passes: stream synchronisation -> %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        rc = REID_ERR_HIP;
+    }
+    return rc;
+}
 int embed_ragged_enqueue(reid_ctx* ctx, const char* tag, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
                          float** d_emb_out, float** d_log_out, bool side_copy);   // api.hip: upload + resize + forward, no synchronisation
 void prof_begin(reid_ctx* ctx, int kind, double flops, double bytes);

@@ -1674,24 +1674,36 @@ extern "C" int reid_swin_embed_f32_nchw_dev(reid_ctx* ctx, const float* d_x, int
 }
 
 extern "C" int reid_swin_embed_f32_nchw(reid_ctx* ctx, const float* x, int n, int h, int w, float* emb, float* logits) {
-    ARG_CHECK(ctx && x && emb && n >= 0);
+    ARG_CHECK(ctx && x && emb && n >= 0 && h > 0 && w > 0 && h % 224 == 0 && w % 224 == 0);
     CTX_ENTER(ctx);
     if (n == 0) return REID_OK;
     const SwinWeights* swp = swin_find(ctx);
-    if (!swp) {
+    if (!swp || !swp->loaded) {
         reid_set_error("reid_swin_embed_*: call reid_swin_load first");
         return REID_ERR_STATE;
     }
-    const int nc = swp->num_class;
+    const SwinWeights& sw = *swp;
+    const int nc = sw.num_class;
     const size_t img = (size_t)3 * h * w;
     float *d_in, *d_emb, *d_log = nullptr;
     REID_TRY(ctx_ws(ctx, "io.in", (size_t)n * img * 4, (void**)&d_in));
     REID_TRY(ctx_ws(ctx, "io.emb", (size_t)n * 512 * 4, (void**)&d_emb));
     if (logits) REID_TRY(ctx_ws(ctx, "io.logits", (size_t)n * nc * 4 + 16, (void**)&d_log));
-    HIP_TRY(hipMemcpyAsync(d_in, x, (size_t)n * img * 4, hipMemcpyHostToDevice, ctx->stream));
-    REID_TRY(reid_swin_embed_f32_nchw_dev(ctx, d_in, n, h, w, d_emb, d_log));
-    HIP_TRY(hipMemcpyAsync(emb, d_emb, (size_t)n * 96 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (logits) HIP_TRY(hipMemcpyAsync(logits, d_log, (size_t)n * nc * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int chunk = ctx->chunk < ctx->swin_chunk_cap ? ctx->chunk : ctx->swin_chunk_cap;   // = reid_swin_embed_f32_nchw_dev's passes
+    // host in -> host out: pass k + 1's images go up and pass k - 1's embeddings come down under pass k (host_passes, reid_internal.h)
+    REID_TRY(host_passes(
+        ctx, n, chunk,
+        [&](int i, int m, hipStream_t s) -> int {
+            HIP_TRY(hipMemcpyAsync(d_in + (size_t)i * img, x + (size_t)i * img, (size_t)m * img * 4, hipMemcpyHostToDevice, s));
+            return REID_OK;
+        },
+        [&](int i, int m) -> int {
+            return swin_forward(ctx, sw, d_in + (size_t)i * img, m, h, w, d_emb + (size_t)i * 96, d_log ? d_log + (size_t)i * nc : nullptr);
+        },
+        [&](int i, int m, hipStream_t s) -> int {
+            HIP_TRY(hipMemcpyAsync(emb + (size_t)i * 96, d_emb + (size_t)i * 96, (size_t)m * 96 * 4, hipMemcpyDeviceToHost, s));
+            if (logits) HIP_TRY(hipMemcpyAsync(logits + (size_t)i * nc, d_log + (size_t)i * nc, (size_t)m * nc * 4, hipMemcpyDeviceToHost, s));
+            return REID_OK;
+        }));
     return ctx_fault_status(ctx);
 }

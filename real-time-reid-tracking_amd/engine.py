@@ -210,23 +210,35 @@ class Engine:
         return (emb, lg) if logits else emb
 
     def embed_ragged_u8(self, crops, logits=False):
-        """list of uint8[h_i,w_i,3] -> float32[n,512]; resize + normalise run on the device."""
+        """list of uint8[h_i,w_i,3] -> float32[n,512]; resize + normalise run on the device.  Crops that already lie one after
+        the other in ONE host buffer (views of a stacked array, slices of a pinned slab) are handed over in place - no packing copy;
+        more crops than a pass holds go up pass by pass under the kernels (csrc/api.hip reid_embed_ragged_u8)."""
         n = len(crops)
         hw = np.empty((n, 2), np.int32)
         offs = np.empty(n, np.int64)
         total = 0
         flat = []
+        base = None                              # address of crop 0 while every crop so far starts where the previous one ended
         for i, c in enumerate(crops):
             c = np.ascontiguousarray(c, dtype=np.uint8)
             if c.ndim != 3 or c.shape[2] != 3 or c.shape[0] < 1 or c.shape[1] < 1:
                 raise ValueError("crop %d must be uint8[h,w,3], got %s" % (i, c.shape))
             hw[i] = c.shape[:2]
             offs[i] = total
+            addr = c.__array_interface__["data"][0]
+            if i == 0:
+                base = addr
+            elif base is not None and addr != base + total:
+                base = None
             total += c.size
-            flat.append(c.reshape(-1))
-        packed = np.concatenate(flat) if flat else np.empty(0, np.uint8)
+            flat.append(c)
         emb, lg = self._outs(n, logits)
-        check(self.lib.reid_embed_ragged_u8(self.h, _ptr(packed), _ptr(offs), _ptr(hw), n, _ptr(emb), _ptr(lg)))
+        if base is not None and n:
+            src = C.c_void_p(base)               # `flat` keeps the views (and so their buffer) alive over the call
+        else:
+            packed = np.concatenate([c.reshape(-1) for c in flat]) if flat else np.empty(0, np.uint8)
+            src = _ptr(packed)
+        check(self.lib.reid_embed_ragged_u8(self.h, src, _ptr(offs), _ptr(hw), n, _ptr(emb), _ptr(lg)))
         return (emb, lg) if logits else emb
 
     # ---- frame pipeline (csrc/bank.hip): submit (asynchronous) / cost (the frame's one synchronisation) / update (asynchronous)

@@ -974,6 +974,9 @@ def test_f16_path_small_and_odd_batches(eng_w0, n):
 
 
 # ----------------------------------------------------------------------------- reference-held vectors at BASELINE sizes
+# (precision, pass size) -> rows of config 1's NOISE set whose arg-min is allowed to differ from the reference's because the
+# reference's own top-2 gap there is below the fp32 noise (2e-6).  Empty = "0 of 256 rows differ" holds at HEAD.
+CONFIG1_RAND0_KNOWN_SUBNOISE_ROWS = {}
 @pytest.mark.parametrize("chunk", [64, 1024])   # four passes of 64 crops (the library default of rounds 1-3) / one pass of 256
 @pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("tag,crops_fn,seed", [("rand0", synth.crops_u8, 0), ("smooth5", synth.smooth_crops_u8, 5)])
@@ -1018,9 +1021,75 @@ def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, c
         # (rounds 2-4 asserted 0 of 256 on both sets, which vetoed every kernel that sums in another order on a coin flip).
         if tag == "smooth5":
             assert len(flips) == 0, (flips, gap[flips])
-        elif len(flips):
-            print("config1 rand0 precision %d chunk %d: sub-noise rows that differ (row, reference gap): %s"
-                  % (precision, chunk, [(int(r), float(gap[r])) for r in flips]))
+        else:
+            # The published claim (README, DESIGN section 2, bench.py --precision help) is "0 of 256 rows differ on the noise set too,
+            # at HEAD".  That claim is ENFORCED here through an explicit allowlist - empty today: a kernel change that flips a
+            # sub-noise row fails this test until the row is recorded below (with the commit that moved it) and the published
+            # sentence is reworded in the same commit.  Rows above the noise can never be listed: they failed the assertion above.
+            if len(flips):
+                print("config1 rand0 precision %d chunk %d: sub-noise rows that differ (row, reference gap): %s"
+                      % (precision, chunk, [(int(r), float(gap[r])) for r in flips]))
+            unexpected = sorted(set(int(r) for r in flips) - CONFIG1_RAND0_KNOWN_SUBNOISE_ROWS.get((precision, chunk), set()))
+            assert not unexpected, ("rows %s of the noise set now differ from the reference's arg-min (reference gaps %s, all below the "
+                                    "2e-6 noise): record them in CONFIG1_RAND0_KNOWN_SUBNOISE_ROWS and reword the '0 of 256' claims"
+                                    % (unexpected, [float(gap[r]) for r in unexpected]))
+
+
+@pytest.mark.parametrize("precision", [0, 2])
+def test_host_entry_points_pipeline_passes_bit_identically(eng_w0, precision):
+    """Host in -> host out, the reference's own shape (feature_extractor.py:48-53 `.to(device)` ... `.cpu().numpy()`,
+    image_reid_inference.py:116-122): with more crops than one pass holds the entry points upload pass k + 1 and download pass
+    k - 1 on a copy stream under pass k's kernels (host_passes, csrc/reid_internal.h).  Same passes, same order, same stream:
+    the results must equal the unpipelined call (debug switch host_pipeline = 0) BIT FOR BIT - pageable and pinned sources, a
+    ragged last pass, logits, the float NCHW entry, ragged crops (contiguous views and separately allocated arrays)."""
+    eng, _ = eng_w0
+    n = 150
+    crops = synth.smooth_crops_u8(n, 71)
+    eng.set_precision(precision)
+    eng.set_chunk(32)                                      # 5 passes, the last one of 22 crops
+    try:
+        def both(fn):
+            eng.debug_switch("host_pipeline", 0)
+            a = fn()
+            eng.debug_switch("host_pipeline", 1)
+            return a, fn()
+        (e0, l0), (e1, l1) = both(lambda: eng.embed_u8(crops, logits=True))
+        assert np.array_equal(e0, e1) and np.array_equal(l0, l1) and np.isfinite(e1).all()
+        slab = eng.pinned(crops.nbytes).reshape(crops.shape)   # pinned source: real asynchronous DMA
+        slab[...] = crops
+        assert np.array_equal(eng.embed_u8(slab), e0)
+        x = ((crops[:70].astype(np.float32) / 255.0 - 0.5) / 0.5).transpose(0, 3, 1, 2).copy()
+        f0, f1 = both(lambda: eng.embed_f32_nchw(x))
+        assert np.array_equal(f0, f1)
+        rag = synth.ragged_crops_u8(70, 9)
+        r0, r1 = both(lambda: eng.embed_ragged_u8(rag))
+        assert np.array_equal(r0, r1)
+        views = [slab[i] for i in range(n)]                # consecutive views of one buffer: handed over in place
+        v0, v1 = both(lambda: eng.embed_ragged_u8(views))
+        assert np.array_equal(v0, v1)
+        assert np.array_equal(v1, eng.embed_ragged_u8([c.copy() for c in views]))   # = the packed copy of separate arrays
+        cos = (v1 * e0).sum(1) / np.linalg.norm(v1, axis=1) / np.linalg.norm(e0, axis=1)
+        assert (1 - cos).max() < 1e-6                      # resize of a 128x256 crop is the identity (float vs uint8 stem loader)
+    finally:
+        eng.debug_switch("host_pipeline", 1)
+        eng.set_chunk(1024)
+        eng.set_precision(0)
+
+
+def test_swin_host_entry_pipeline_bit_identical(eng):
+    """reid_swin_embed_f32_nchw in passes: pipelined upload / download against the unpipelined call, bit for bit."""
+    eng.load_swin(*weights.pack_swin(synth.swin_state_dict(0))[:2])
+    x = synth.images_f32(11, 3)
+    eng.set_chunk(4)
+    try:
+        eng.debug_switch("host_pipeline", 0)
+        a, la = eng.swin_embed_f32_nchw(x, logits=True)
+        eng.debug_switch("host_pipeline", 1)
+        b, lb = eng.swin_embed_f32_nchw(x, logits=True)
+        assert np.array_equal(a, b) and np.array_equal(la, lb) and np.isfinite(b).all()
+    finally:
+        eng.debug_switch("host_pipeline", 1)
+        eng.set_chunk(1024)
 
 
 @pytest.mark.timeout(900)
