@@ -242,6 +242,14 @@ int reid_frame_submit(reid_ctx* ctx, int slot, const uint8_t* packed, const int6
 int reid_frame_cost(reid_ctx* ctx, int slot, reid_bank* bank, const int32_t* slots, int t, int metric, float max_dist,
                     const double* tracks_t4, const double* dets_m4, int want_emb);
 int reid_frame_fetch(reid_ctx* ctx, int slot, float* emb, float* cost_tm, double* iou_tm);
+/* K camera streams batched into ONE pass per frame time (track_yolov5.py:178-253 runs one such loop per video; a frame of ~30
+ * crops leaves most of the chip idle, K cameras' frames in one forward do not): submit the cameras' crops one camera after the
+ * other (m_counts[g] crops of camera g, sum = the slot's m), then this cost stage in place of reid_frame_cost - camera g's
+ * t_counts[g] tracks (slots / tracks_t4: the groups' concatenations, on banks[g]) against ITS detections only.  reid_frame_fetch
+ * then returns, in cost_tm / iou_tm, the groups' t_g x m_g blocks one after the other; reid_frame_update takes slot-wide rows. */
+int reid_frame_cost_groups(reid_ctx* ctx, int slot, int groups, reid_bank* const* banks, const int32_t* t_counts,
+                           const int32_t* m_counts, const int32_t* slots, int metric, float max_dist, const double* tracks_t4,
+                           const double* dets_m4, int want_emb);
 /* multi-GPU frames (every rank embeds its round-robin share of the frame's crops): between submit and
  * cost, gather the ranks' embeddings into the slot as equal blocks of per = ceil(n / world) rows - one ncclAllGather; the slot
  * then holds world * per rows (row r * per + i = detection r + i * world; rows past a rank's share are padding) on every rank.

@@ -118,6 +118,11 @@ int ctx_fault_status(reid_ctx* ctx) {
         reid_set_error("a non-finite embedding left the neck (overflow upstream); results since the last reid_ctx_clear_fault are invalid");
         return REID_ERR_STATE;
     }
+    if (f[2]) {
+        reid_set_error("a split-K rendezvous of a convolution did not complete within its bound (conv3x3_x3.hip: the blocks of an output tile wait "
+                       "for each other); results since the last reid_ctx_clear_fault are invalid");
+        return REID_ERR_STATE;
+    }
     return REID_OK;
 }
 
@@ -125,7 +130,7 @@ extern "C" int reid_ctx_clear_fault(reid_ctx* ctx) {
     ARG_CHECK(ctx);
     CTX_GUARD(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->fault) ctx->fault[0] = ctx->fault[1] = 0;
+    if (ctx->fault) ctx->fault[0] = ctx->fault[1] = ctx->fault[2] = 0;
     return REID_OK;
 }
 

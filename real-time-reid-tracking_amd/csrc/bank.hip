@@ -474,21 +474,37 @@ extern "C" int reid_frame_submit(reid_ctx* ctx, int slot, const uint8_t* packed,
     return REID_OK;
 }
 
-extern "C" int reid_frame_cost(reid_ctx* ctx, int slot, reid_bank* b, const int32_t* slots, int t, int metric, float max_dist,
-                               const double* tracks_t4, const double* dets_m4, int want_emb) {
-    ARG_CHECK(ctx && (slot == 0 || slot == 1) && t >= 0);
+// Cost stage for `groups` camera streams batched into one frame slot (reid_frame_cost is the one-group case): the slot's m
+// detections are the cameras' detections one camera after the other (m_counts[g] each); group g's tracks are matched against ITS
+// detections only, on ITS bank.  Host arrays are the groups' concatenations; outputs are the groups' t_g x m_g blocks, concatenated.
+extern "C" int reid_frame_cost_groups(reid_ctx* ctx, int slot, int groups, reid_bank* const* banks, const int32_t* t_counts,
+                                      const int32_t* m_counts, const int32_t* slots, int metric, float max_dist, const double* tracks_t4,
+                                      const double* dets_m4, int want_emb) {
+    ARG_CHECK(ctx && (slot == 0 || slot == 1) && groups >= 1 && t_counts && m_counts);
     CTX_ENTER(ctx);
     const int m = ctx->frame_m[slot];
-    const bool want_cost = b && slots && t > 0 && m > 0, want_iou = tracks_t4 && dets_m4 && t > 0 && m > 0;
+    int t = 0, msum = 0;
+    size_t tm = 0;
+    for (int g = 0; g < groups; ++g) {
+        ARG_CHECK(t_counts[g] >= 0 && m_counts[g] >= 0);
+        t += t_counts[g];
+        msum += m_counts[g];
+        tm += (size_t)t_counts[g] * m_counts[g];
+    }
+    ARG_CHECK(msum == m);
+    const bool want_cost = banks && slots && tm > 0, want_iou = tracks_t4 && dets_m4 && tm > 0;
     if (want_cost) {
-        ARG_CHECK(b->ctx == ctx && b->d == 512);
         ARG_CHECK(metric == REID_METRIC_COS || metric == REID_METRIC_L2SQR);
-        for (int i = 0; i < t; ++i) ARG_CHECK(slots[i] >= 0 && slots[i] < b->max_tracks);
+        for (int g = 0, i = 0; g < groups; ++g) {
+            if (t_counts[g] == 0 || m_counts[g] == 0) { i += t_counts[g]; continue; }
+            ARG_CHECK(banks[g] && banks[g]->ctx == ctx && banks[g]->d == 512);
+            for (int e = i + t_counts[g]; i < e; ++i) ARG_CHECK(slots[i] >= 0 && slots[i] < banks[g]->max_tracks);
+        }
     }
     const std::string tag = slot ? "frame1" : "frame0";
-    // inputs: [tracks 32 t][dets 32 m][slots 4 t]; outputs: [iou 8 t m][cost 4 t m][emb 2048 m]
+    // inputs: [tracks 32 t][dets 32 m][slots 4 t]; outputs: [iou 8 tm][cost 4 tm][emb 2048 m]
     const size_t in_bytes = (size_t)t * 32 + (size_t)m * 32 + (size_t)t * 4;
-    const size_t tm = (size_t)t * m, out_bytes = tm * 12 + (size_t)m * 2048;
+    const size_t out_bytes = tm * 12 + (size_t)m * 2048;
     char *pin_in, *pin_out, *d_in, *d_out;
     REID_TRY(ctx_pinned(ctx, (tag + ".cin").c_str(), in_bytes + 8, (void**)&pin_in));
     REID_TRY(ctx_pinned(ctx, (tag + ".cout").c_str(), out_bytes + 8, (void**)&pin_out));
@@ -502,10 +518,22 @@ extern "C" int reid_frame_cost(reid_ctx* ctx, int slot, reid_bank* b, const int3
     if (want_iou || want_cost) HIP_TRY(hipMemcpyAsync(d_in, pin_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     double* d_iou = (double*)d_out;
     float* d_cost = (float*)(d_out + tm * 8);
-    if (want_cost)
-        REID_TRY(bank_cost_launch(ctx, b, (const int32_t*)(d_in + (size_t)t * 32 + (size_t)m * 32), t, ctx->frame_emb[slot], m,
-                                  metric == REID_METRIC_COS ? 0 : 1, max_dist, d_cost));
-    if (want_iou) REID_TRY(launch_diou_cost(ctx, (const double*)d_in, t, (const double*)(d_in + (size_t)t * 32), m, d_iou, 1));
+    const double* d_tracks = (const double*)d_in;
+    const double* d_dets = (const double*)(d_in + (size_t)t * 32);
+    const int32_t* d_slots = (const int32_t*)(d_in + (size_t)t * 32 + (size_t)m * 32);
+    size_t t_off = 0, m_off = 0, tm_off = 0;
+    for (int g = 0; g < groups; ++g) {
+        const int tg = t_counts[g], mg = m_counts[g];
+        if (tg > 0 && mg > 0) {
+            if (want_cost)
+                REID_TRY(bank_cost_launch(ctx, banks[g], d_slots + t_off, tg, ctx->frame_emb[slot] + m_off * 512, mg, metric == REID_METRIC_COS ? 0 : 1,
+                                          max_dist, d_cost + tm_off));
+            if (want_iou) REID_TRY(launch_diou_cost(ctx, d_tracks + t_off * 4, tg, d_dets + m_off * 4, mg, d_iou + tm_off, 1));
+        }
+        t_off += tg;
+        m_off += mg;
+        tm_off += (size_t)tg * mg;
+    }
     if (want_iou && want_cost) HIP_TRY(hipMemcpyAsync(pin_out, d_iou, tm * 12, hipMemcpyDeviceToHost, ctx->stream));   // adjacent: one copy
     else if (want_iou) HIP_TRY(hipMemcpyAsync(pin_out, d_iou, tm * 8, hipMemcpyDeviceToHost, ctx->stream));
     else if (want_cost) HIP_TRY(hipMemcpyAsync(pin_out + tm * 8, d_cost, tm * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -513,10 +541,18 @@ extern "C" int reid_frame_cost(reid_ctx* ctx, int slot, reid_bank* b, const int3
         HIP_TRY(hipMemcpyAsync(pin_out + tm * 12, ctx->frame_emb[slot], (size_t)m * 2048, hipMemcpyDeviceToHost, ctx->stream));
     if (!ctx->frame_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->frame_ev[slot], hipEventDisableTiming));
     HIP_TRY(hipEventRecord(ctx->frame_ev[slot], ctx->stream));
-    ctx->frame_t[slot] = t;
+    ctx->frame_tm[slot] = tm;
     ctx->frame_has[slot] = (want_iou ? 1 : 0) | (want_cost ? 2 : 0) | (want_emb && m > 0 ? 4 : 0) | 8;
     ctx->frame_out[slot] = pin_out;
     return REID_OK;
+}
+
+extern "C" int reid_frame_cost(reid_ctx* ctx, int slot, reid_bank* b, const int32_t* slots, int t, int metric, float max_dist,
+                               const double* tracks_t4, const double* dets_m4, int want_emb) {
+    ARG_CHECK(ctx && (slot == 0 || slot == 1) && t >= 0);
+    const int32_t tc = t, mc = ctx->frame_m[slot];
+    reid_bank* const banks[1] = {b};
+    return reid_frame_cost_groups(ctx, slot, 1, (b && slots) ? banks : nullptr, &tc, &mc, slots, metric, max_dist, tracks_t4, dets_m4, want_emb);
 }
 
 extern "C" int reid_frame_fetch(reid_ctx* ctx, int slot, float* emb, float* cost_tm, double* iou_tm) {
@@ -530,7 +566,7 @@ extern "C" int reid_frame_fetch(reid_ctx* ctx, int slot, float* emb, float* cost
     const int has = ctx->frame_has[slot];
     ctx->frame_has[slot] = 0;
     ctx->frame_pending[slot] = 0;
-    const size_t tm = (size_t)ctx->frame_t[slot] * ctx->frame_m[slot];
+    const size_t tm = ctx->frame_tm[slot];
     const char* pin_out = ctx->frame_out[slot];
     ARG_CHECK((!iou_tm || (has & 1)) && (!cost_tm || (has & 2)) && (!emb || (has & 4) || ctx->frame_m[slot] == 0));
     if (iou_tm) memcpy(iou_tm, pin_out, tm * 8);

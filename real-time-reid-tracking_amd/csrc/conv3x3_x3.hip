@@ -398,43 +398,44 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (inline asm: hipcc does not count their wait states)
     __syncthreads();
 
+    // Split-K (few output tiles: a tracking frame, a pass of a few camera frames) as a REDUCE-SCATTER.  Round 5's form - every block
+    // stores its partial tile, the block that arrives last re-reads all SK of them with dword loads and runs the whole epilogue - made
+    // these kernels 2-3.6x SLOWER than conv3x3_f16.hip's on a 30-crop frame: with 128 accumulator registers live the last arriver's
+    // 128 x SK loads went out in small batches, ~60 memory round trips on ONE CU per tile while the tile's other SK - 1 CUs had left.
+    // Now: every block stores its partial as 16-byte units [a][b][lane] (device scope, written through), the SK blocks of a tile meet
+    // at an arrival counter (below), and block k reduces and finishes column slice k of the tile - TN / SK sixteen-column units, the SK
+    // partials of a unit requested together and summed in split order (deterministic) - epilogue, stores and column sums included.
+    // Per block 128 / SK KB x SK of loads instead of 128 x SK KB on one; nothing is re-read.
+    bool sk_path = false;
     if (SK > 1) {
-        // partial tile in register order [TM * TN * 4][256 lanes]: coalesced both ways.  Device-scope (sc1) stores are written through
-        // to the point all XCDs share and the loads below bypass this XCD's L2: no L2 write-back / invalidate fence (conv3x3_f16.hip)
-        constexpr int PART = 256 * BN;
-        float* part = p.splitk_ws + (long long)tile_id * SK * PART;
+        sk_path = true;
+        constexpr int PART_B = 256 * BN * 4;       // bytes of one partial tile
+        char* part = (char*)(p.splitk_ws + (long long)tile_id * SK * (256 * BN));
+        const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, SK * PART_B, 0x00020000);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    __hip_atomic_store(part + (long long)ksplit * PART + ((a * TN + b) * 4 + e) * 256 + tid, acc[a][b][e], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[a][b]), w_rs, tid * 16, ksplit * PART_B + (a * TN + b) * 4096, 16 /* sc1 */);
+        // sc1 stores are written through to the point all XCDs share, sc1 loads bypass this XCD's L2 (conv3x3_f16.hip: no L2 write-back /
+        // invalidate fence); acknowledged once vmcnt reaches 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int* flag = (int*)lds;
         if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = old == SK - 1;
-            if (old == SK - 1) __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            // The tile's SK blocks have consecutive linear ids on one XCD (the remap above): blocks are dispatched in id order, so a block's
+            // mates are resident or next in line, and a launch of <= 512 of these blocks is resident as a whole.  The wait is bounded
+            // all the same: a rendezvous that never completes raises the context's fault word instead of hanging the device.
+            __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(p.splitk_cnt + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < SK) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 23)) {
+                    if (p.fault) p.fault[2] = 1;
+                    break;
+                }
+            }
         }
         __syncthreads();
-        if (!*flag) return;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int sidx = 0; sidx < SK; ++sidx)
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[a][b][e] += __hip_atomic_load(part + (long long)sidx * PART + ((a * TN + b) * 4 + e) * 256 + tid, __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();   // the flag word is about to be overwritten by the statistics
     }
 
     if (p.ablate & 32) return;
@@ -467,7 +468,7 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
         koff_a[a] = row_ok ? (lrow * 2 * p.N + col0) * 2 : 0x7fffff00;
     }
     const bool has_stats = p.stats != nullptr;
-    float vmax = 0.f;
+    unsigned vm_run = 0u;      // largest packed magnitude, as bits (NaN > inf > finite), taken BEFORE the ReLU (range_acc, reid_internal.h)
     // every choice below (residual, [yh | yl'] or fp32 store, statistics) is uniform per wave and per 16-column tile and is taken
     // by a scalar branch AROUND a straight-line body of four tiles: per-element selects and branches made this epilogue ~1 000
     // vector instructions per wave, each of which waits 11-45 cycles for an issue slot beside the other blocks' MFMAs
@@ -505,6 +506,7 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
                     }
                     if constexpr (RES)
                         v[i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff_a[a] + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, 0));
+                    if (pk) vm_run = range_acc(range_acc(range_acc(range_acc(vm_run, v[i][0]), v[i][1]), v[i][2]), v[i][3]);   // before the ReLU: max(NaN, 0) is 0
                     if (!LIN) {      // (linear layers have no ReLU)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], lo);
@@ -522,7 +524,6 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const float v0 = v[i][2 * h], v1 = v[i][2 * h + 1];
-                            vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
                             const f16 h0 = cvt_f16_rn(v0), h1 = cvt_f16_rn(v1);      // one rounding of the materialised fp32 value (lin_math.h)
                             const f16 l0 = cvt_f16_rn((v0 - (float)h0) * 2048.0f), l1 = cvt_f16_rn((v1 - (float)h1) * 2048.0f);
                             hw[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
@@ -552,7 +553,110 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
             }
         }
     };
-    if (wave_live) {
+    // ---- split-K: this block's column slice (units b = ksplit TN / SK ..): the SK partials of a unit are requested together, summed
+    // in split order, and go through the arithmetic of run() above, element for element (b is a run-time value here: the unit's
+    // column offset sits in the address registers, the body is compiled once per (SK, residual, statistics))
+    unsigned vm_sk = 0u;
+    auto run_sk = [&](auto sk_c, auto res_c, auto st_c) {
+        constexpr int SKC = decltype(sk_c)::value;
+        constexpr bool RES = decltype(res_c)::value, ST = decltype(st_c)::value;
+        constexpr int PART_B = 256 * BN * 4;
+        const __amdgpu_buffer_rsrc_t w_rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.splitk_ws + (long long)tile_id * SKC * (256 * BN)), 0, SKC * PART_B, 0x00020000);
+        constexpr int NB = TN / SKC;
+        for (int bi = 0; bi < NB; ++bi) {
+            const int b = ksplit * NB + bi;
+            f32x4 v[TM];
+            {
+                u32x4 ld[SKC][TM];
+#pragma unroll
+                for (int sidx = 0; sidx < SKC; ++sidx)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+                        ld[sidx][a] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, tid * 16, sidx * PART_B + (a * TN + b) * 4096, 16 /* sc1 */);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    v[a] = __builtin_bit_cast(f32x4, ld[0][a]);
+#pragma unroll
+                    for (int sidx = 1; sidx < SKC; ++sidx) v[a] += __builtin_bit_cast(f32x4, ld[sidx][a]);
+                }
+            }
+            const int col = col0 + b * 16, tcol = n_blk + b * 16;
+            f32x4 cs = f32x4{p.acc_scale, p.acc_scale, p.acc_scale, p.acc_scale}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.col_scale) {
+                cs = *(const f32x4*)(p.col_scale + col) * p.acc_scale;
+                sh = *(const f32x4*)(p.col_shift + col);
+            }
+            const float lo = (p.relu && tcol >= p.relu_from) ? 0.f : -INFINITY;
+            const bool pk = p.pack16 && tcol >= p.pack_from;
+            f32x4 t1 = f32x4{0.f, 0.f, 0.f, 0.f}, t2 = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 rr[TM];
+            if constexpr (RES) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+                    rr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff_a[a] + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, 0));
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                f32x4 x = v[a] * cs + sh;
+                if constexpr (RES) x += rr[a];
+                if (pk) vm_sk = range_acc(range_acc(range_acc(range_acc(vm_sk, x[0]), x[1]), x[2]), x[3]);   // before the ReLU: max(NaN, 0) is 0
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], lo);
+                if constexpr (ST) {
+                    t1 += x;
+                    t2 += x * x;
+                }
+                const int ubase = wm * 64 + (TW == 8 ? a * 8 : a * 16);
+                if (pk) {
+                    u32x2 hw, lw;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float v0 = x[2 * h], v1 = x[2 * h + 1];
+                        const f16 h0 = cvt_f16_rn(v0), h1 = cvt_f16_rn(v1);
+                        const f16 l0 = cvt_f16_rn((v0 - (float)h0) * 2048.0f), l1 = cvt_f16_rn((v1 - (float)h1) * 2048.0f);
+                        hw[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                        lw[h] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, koff_a[a] + b * 32, ubase * 2 * p.N * 2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, koff_a[a] + b * 32 + p.N * 2, ubase * 2 * p.N * 2, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), c_rs, voff_a[a] + b * 64, ubase * ldc * 4, 0);
+                }
+            }
+            if constexpr (ST) {
+                float* stat_lds = (float*)lds;  // [4][BN][2]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r1 = row16_sum(t1[e]), r2 = row16_sum(t2[e]);
+                    if (l16 == 0) {
+                        const int lcol = b * 16 + 4 * pq + e;
+                        stat_lds[(wm * BN + lcol) * 2 + 0] = r1;
+                        stat_lds[(wm * BN + lcol) * 2 + 1] = r2;
+                    }
+                }
+            }
+        }
+    };
+    auto run_sk_n = [&](auto sk_c) {
+        if (p.res32) {
+            if (has_stats) run_sk(sk_c, std::true_type{}, std::true_type{});
+            else run_sk(sk_c, std::true_type{}, std::false_type{});
+        } else {
+            if (has_stats) run_sk(sk_c, std::false_type{}, std::true_type{});
+            else run_sk(sk_c, std::false_type{}, std::false_type{});
+        }
+    };
+    if (sk_path) {
+        if constexpr (!LIN) {
+            if (wave_live) {
+                if (SK == 2) run_sk_n(std::integral_constant<int, 2>{});
+                else if (SK == 4) run_sk_n(std::integral_constant<int, 4>{});
+                else if constexpr (TN == 8) run_sk_n(std::integral_constant<int, 8>{});
+            }
+            range_raise(p.fault, vm_sk);
+        }
+    } else if (wave_live) {
         if (p.res32) {
             if (has_stats) run(std::true_type{}, std::true_type{});
             else run(std::true_type{}, std::false_type{});
@@ -561,13 +665,26 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
             else run(std::false_type{}, std::false_type{});
         }
     }
-    if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;
+    range_raise(p.fault, vm_run);
+    if (sk_path) {
+        // every load of the partials has returned (their values were used above): the block that counts the tile's last reader
+        // resets the two counters for the next launch
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.splitk_cnt + 256 + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == SK - 1) {
+                __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.splitk_cnt + 256 + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if (has_stats) {   // per 128 natural rows: waves 0,1 own rows 0..127, waves 2,3 rows 128..255
         const float* stat_lds = (const float*)lds;  // [4][BN][2], written by run()
         __syncthreads();
+        const int cc_lo = sk_path ? ksplit * (BN / SK) : 0, cc_hi = sk_path ? cc_lo + BN / SK : BN;   // split-K: this block's column slice
         for (int t = tid; t < 2 * BN; t += 256) {
             const int half = t / BN, cc = t - half * BN;
-            if (half * 128 >= m_valid) continue;
+            if (half * 128 >= m_valid || cc < cc_lo || cc >= cc_hi) continue;
             float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + cc) * 2;
             o[0] = stat_lds[((half * 2) * BN + cc) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 0];
             o[1] = stat_lds[((half * 2) * BN + cc) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 1];
@@ -1283,13 +1400,15 @@ int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
     // few output tiles (a tracking frame): split the real 32-channel chunks over sk blocks per tile, up to two blocks for every CU
     const int ncr = p.Cin / 3 / 32;
     int sk = 1;
-    while (ctx->f16_split_k && tiles * sk * 2 <= 512 && ncr % (sk * 2) == 0 && sk < 8) sk *= 2;
+    // (x3m16_tail hands the tile's sixteen-column units out to the sk blocks: sk divides their number)
+    while (ctx->f16_split_k && tiles * sk * 2 <= 512 && ncr % (sk * 2) == 0 && sk * 2 <= (wide ? 8 : 4)) sk *= 2;
+    if (sk > (ctx->x3_sk_cap > 0 ? ctx->x3_sk_cap : 4)) sk = ctx->x3_sk_cap > 0 ? ctx->x3_sk_cap : 4;   // eight ways: twice the partial traffic, 30 crops 882 -> 1175 us per pass
     if (sk > 1) {
         float* ws;
         int* cnt;
         const bool fresh = ctx->ws.find("x3.splitk_cnt") == ctx->ws.end();
         REID_TRY(ctx_ws(ctx, "x3.splitk_ws", (size_t)tiles * sk * 256 * (wide ? 128 : 64) * sizeof(float), (void**)&ws));
-        REID_TRY(ctx_ws(ctx, "x3.splitk_cnt", 512 * sizeof(int), (void**)&cnt));
+        REID_TRY(ctx_ws(ctx, "x3.splitk_cnt", 512 * sizeof(int), (void**)&cnt));   // [tile] arrivals, [256 + tile] readers done (tiles <= 128 here)
         if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, 512 * sizeof(int), ctx->stream));
         p.split_k = sk; p.splitk_ws = ws; p.splitk_cnt = cnt;
     } else {
@@ -1315,14 +1434,33 @@ void launch_x3(reid_ctx* ctx, const Gemm16Params& p) {
 
 }  // namespace
 
-// Large launches only (at least two blocks for every CU): a tracking frame keeps conv3x3_f16.hip's split-K forms.
+// output tiles of a launch in the width launch_x3m16 picks for it
+static int launch_tiles(const reid_ctx* ctx, const Gemm16Params& p) {
+    const int nmt = (p.M + 255) / 256;
+    const bool wide = p.N % 128 == 0 && !((p.W == 16 && (ctx->x3_narrow & 1)) || (p.W == 8 && (ctx->x3_narrow & 2)));
+    return nmt * (wide ? p.N / 128 : p.N / 64);
+}
+
+// Launches of at least two blocks for every CU, and (round 6) the smaller ones listed below; the smallest keep conv3x3_f16.hip's forms.
 bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p) {
     if (!ctx->split_x3 || p.split_terms != 3 || p.Cin % 96 != 0 || p.N % 64 != 0 || p.M % 128 != 0 || !conv3x3_f16_supported(p)) return false;
+    if (p.relu_from % 16 != 0 || (p.pack16 && p.pack_from % 32 != 0)) return false;   // x3m16_tail decides ReLU / the packed store per sixteen-column unit
     // 64-wide tiles exist for the 32-wide maps (layer 1) only, in form 3: four blocks per CU, one halo buffer.  Measured at 1024 crops:
     // 570 us per launch against 729 for the 12-wave kernel (and 666 for a two-blocks-per-CU form with groups of three taps per barrier)
     if (p.N % 128 != 0 && ctx->split_x3 < 3) return false;
-    const long long blocks = (long long)((p.M + 255) / 256) * (p.N % 128 == 0 ? p.N / 128 : p.N / 64);
-    return blocks >= ctx->split_x3_min_blocks || (ctx->split_x3_small && ctx->split_x3 >= 2);   // small launches: split-K forms of the 16x16x32 kernel
+    const int nmt = (p.M + 255) / 256;
+    const long long blocks = (long long)nmt * (p.N % 128 == 0 ? p.N / 128 : p.N / 64);
+    if (blocks >= ctx->split_x3_min_blocks) return true;
+    if (ctx->split_x3 < 2 || !ctx->split_x3_small) return false;
+    if (ctx->split_x3_small == 1) return true;       // every small launch (A/B)
+    // Smaller launches (round 6, split_x3_small = 2): since x3m16_tail reduces split-K partials as a reduce-scatter these kernels beat
+    // conv3x3_f16.hip's 12-wave blocks wherever a launch is not tiny - measured per layer at 30 / 64 / 120 / 200 crops
+    // (gpurun_out/r6/timeline_*): layer 4 at every size (30 crops: 45.5 / 69 / 70 / 73 -> 40 / 59 / 68 / 61 us, 200 crops: 385 -> 290 us),
+    // layer 3 from ~48 crops on (64 crops: 48 -> 41 us; 30 crops: 31 against 33 - stays), the 16- and 32-wide maps from ~400 tiles on
+    // (layer 2 at 120 crops: 65 -> 51 us; at 64 crops 37 against 42 - stays; layer 1 at 30 crops 24 against 31-35 - stays).
+    const int tiles = launch_tiles(ctx, p);
+    if (p.W == 8) return (p.N >= 512 && nmt >= 12) || nmt >= 24;     // (20 crops, layer 4: 12-wave forms 788 against 802 us per pass)
+    return tiles >= 384;
 }
 
 int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p0) {

@@ -378,7 +378,9 @@ struct reid_ctx {
     int split_x3 = 3;        // precision 2, large launches: conv3x3_x3.hip instead of conv3x3_f16.hip's 12-wave kernel: 3 (default) = on
                              // v_mfma_f32_16x16x32_f16, two blocks per CU for the 128-wide tiles (layers 2-4) and FOUR for the 64-wide ones
                              // (layer 1); 2 = the 128-wide tiles only; 1 = the first form on 32x32x16; 0 = off
-    int split_x3_small = 0;  // ... and small launches too (a tracking frame), K split over up to 8 blocks per tile
+    int x3_sk_cap = 0;       // experiments: upper bound of the split-K factor of conv3x3_x3.hip's small launches (0 = the heuristic's)
+    int split_x3_small = 2;  // ... and smaller launches: 2 (default) = where they measured faster than conv3x3_f16.hip's 12-wave kernel (conv3x3_x3_supported),
+                             // 1 = every launch, 0 = none; K split over up to 8 blocks per tile (x3m16_tail: reduce-scatter)
     int x3_narrow = 1;       // conv3x3_x3.hip, 64-wide tiles (four blocks per CU) beyond layer 1: bit 0 = the 16-wide maps (layer 2: 14.03 -> 13.87 ms per
                              // 1024-crop pass; default), bit 1 = the 8-wide ones (layers 3-4: 14.03 -> 14.70, off)
     int x3_unroll = 3;       // conv3x3_x3.hip: the form with a chunk's 27 steps unrolled (addresses, DMA offsets made once, waits immediates): 1 = the
@@ -416,7 +418,8 @@ struct reid_ctx {
     int f16_cfg = 0;         // fp16 GEMM tile/ring override: BN*1000 + BK*10 + NST, 0 = heuristic (REID_F16_CFG)
     int frame_m[2] = {0, 0};                        // frame pipeline (bank.hip): detections / device embeddings per frame slot
     float* frame_emb[2] = {nullptr, nullptr};
-    int frame_pending[2] = {0, 0}, frame_t[2] = {0, 0}, frame_has[2] = {0, 0};
+    int frame_pending[2] = {0, 0}, frame_has[2] = {0, 0};
+    size_t frame_tm[2] = {0, 0};        // elements of the cost stage's output (sum over the camera groups of tracks x detections)
     hipEvent_t frame_ev[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;   // uploads of the frame pipeline (beside the kernels of the previous frame)
     hipEvent_t copy_ev = nullptr;

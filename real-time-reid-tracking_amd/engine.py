@@ -319,6 +319,47 @@ class Engine:
         check(self.lib.reid_frame_fetch(self.h, int(slot), _ptr(emb) if m else None, _ptr(cost), _ptr(iou)))
         return emb, cost, iou
 
+    def frame_cost_groups(self, slot, groups, metric=0, max_dist=-1.0, want_emb=True):
+        """Stage 2 for K camera streams batched into one slot (reid_frame_cost_groups): ``groups`` = one (bank, slots, track_boxes,
+        det_boxes, m) per camera, in the order their crops were submitted; camera g's tracks meet ITS m detections only."""
+        k = len(groups)
+        banks = (C.c_void_p * k)()
+        tc, mc = np.zeros(k, np.int32), np.zeros(k, np.int32)
+        sl, tb, db = [], [], []
+        boxes = all(g[2] is not None and g[3] is not None for g in groups)
+        for i, (bank, slots, tboxes, dboxes, m) in enumerate(groups):
+            banks[i] = bank
+            tc[i], mc[i] = (0 if slots is None else len(slots)), int(m)
+            if slots is not None:
+                sl.append(np.asarray(slots, np.int32))
+            if boxes:
+                t4 = np.asarray(tboxes, np.float64).reshape(-1, 4)
+                d4 = np.asarray(dboxes, np.float64).reshape(-1, 4)
+                if t4.shape[0] != tc[i] or d4.shape[0] != mc[i]:
+                    raise ValueError("camera %d: %d / %d boxes for %d tracks / %d crops" % (i, t4.shape[0], d4.shape[0], tc[i], mc[i]))
+                tb.append(t4)
+                db.append(d4)
+        if int(mc.sum()) != self._frame_n[slot]:
+            raise ValueError("the groups hold %d detections, the slot %d" % (int(mc.sum()), self._frame_n[slot]))
+        sl = np.ascontiguousarray(np.concatenate(sl), np.int32) if sl else None
+        tb = np.ascontiguousarray(np.concatenate(tb)) if boxes else None
+        db = np.ascontiguousarray(np.concatenate(db)) if boxes else None
+        check(self.lib.reid_frame_cost_groups(self.h, int(slot), k, banks if sl is not None else None, _ptr(tc), _ptr(mc), _ptr(sl), int(metric),
+                                              C.c_float(max_dist), _ptr(tb), _ptr(db), 1 if want_emb else 0))
+        tm = int((tc.astype(np.int64) * mc).sum())
+        self.__dict__.setdefault("_frame_q", {})[slot] = (self._frame_n[slot], tm, want_emb, sl is not None and tm > 0, boxes and tm > 0, tc, mc)
+
+    def frame_fetch_groups(self, slot):
+        """The one wait of a batched frame: (emb[m,512] | None, [cost_g[t_g,m_g] float32 | None], [iou_g float64 | None])."""
+        m, tm, want_emb, has_cost, has_iou, tc, mc = self._frame_q.pop(slot)
+        emb = np.empty((m, 512), np.float32) if want_emb else None
+        cost = np.empty(tm, np.float32) if has_cost else None
+        iou = np.empty(tm, np.float64) if has_iou else None
+        check(self.lib.reid_frame_fetch(self.h, int(slot), _ptr(emb) if m else None, _ptr(cost), _ptr(iou)))
+        offs = np.concatenate([[0], np.cumsum(tc.astype(np.int64) * mc)])
+        cut = lambda a: [None if a is None else a[offs[g]:offs[g + 1]].reshape(int(tc[g]), int(mc[g])) for g in range(len(tc))]
+        return emb, cut(cost), cut(iou)
+
     def frame_update(self, slot, bank, rows, slots):
         """Stage 3: partial_fit from the slot's device-resident embeddings (row rows[i] -> track slot slots[i]); asynchronous."""
         rows = np.ascontiguousarray(rows, np.int32)

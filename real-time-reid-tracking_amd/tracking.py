@@ -58,6 +58,83 @@ class CameraStream:
                 self.eng.close()
 
 
+class MultiCameraStream:
+    """K camera streams of ONE GPU batched into one pass per frame time.
+
+    The reference runs one `track_yolov5.py` loop per video (modification_tracking/track_yolov5.py:178-253), each calling the
+    extractor on its own ~30 crops; K `CameraStream`s on one device overlap poorly, because every launch of a frame is one
+    wave of blocks that leaves most CUs idle for most of its life (four concurrent streams measured 1.28x one stream).  Here the
+    K cameras' crops of a frame time are concatenated into ONE `reid_frame_submit` - a forward over ~30 K crops runs its
+    convolutions as proper tiles - while everything that must stay per camera stays per camera: each has its own feature bank
+    (`metrics[c]`), its tracks meet its own detections only (`reid_frame_cost_groups`: K small cost blocks, not a (sum t) x
+    (sum m) matrix) and `commit` feeds each bank from the camera's slice of the slot.  Same call order as `CameraStream`,
+    with one list entry per camera everywhere; one host thread, one wait per frame time."""
+
+    def __init__(self, weights_blob, manifest, cameras, precision=0, max_dist=0.15, budget=100, metric="cosine", device=0,
+                 own_context=True, max_tracks=4096):
+        self._own = bool(own_context)
+        self.eng = Engine(device) if own_context else get_engine(device)
+        self.eng.load_seres18(weights_blob, manifest)
+        self.eng.set_precision(precision)
+        self.max_dist = max_dist
+        self.cameras = int(cameras)
+        self.metrics = [NearestNeighborDistanceMetric(metric, max_dist, budget, max_tracks=max_tracks, engine=self.eng)
+                        for _ in range(self.cameras)]
+        self._frame = 0
+        self._m = {}                       # slot -> detections per camera of the submitted frame
+
+    def _submit(self, slot, crops_per_camera):
+        if len(crops_per_camera) != self.cameras:
+            raise ValueError("expected %d crop lists, got %d" % (self.cameras, len(crops_per_camera)))
+        self._m[slot] = [len(c) for c in crops_per_camera]
+        self.eng.frame_submit(slot, [c for cam in crops_per_camera for c in cam])
+
+    def submit(self, crops_per_camera):
+        """Queue upload + embedding of the FIRST frame time's crops (one list per camera); later ones ride on `step`."""
+        self._submit(self._frame & 1, crops_per_camera)
+
+    def step(self, targets, track_boxes, det_boxes, next_crops=None):
+        """Per camera c: costs of its submitted detections against its confirmed tracks ``targets[c]`` (tlwh boxes for the DIoU
+        cost; ``track_boxes`` / ``det_boxes`` None = no DIoU), the next frame time's crops submitted in between.  Returns one
+        (features[m_c,512], appearance_cost[t_c,m_c] gated at max_dist, iou_cost[t_c,m_c] | None) per camera."""
+        slot = self._frame & 1
+        ms = self._m[slot]
+        groups = []
+        for c, met in enumerate(self.metrics):
+            met._ensure(512)
+            tg = list(targets[c])
+            groups.append((met._bank, met._slots_for(tg, False) if tg else np.empty(0, np.int32),
+                           None if track_boxes is None else track_boxes[c], None if det_boxes is None else det_boxes[c], ms[c]))
+        self.eng.frame_cost_groups(slot, groups, self.metrics[0]._metric, self.max_dist)
+        if next_crops is not None:
+            self._submit(slot ^ 1, next_crops)
+        emb, costs, ious = self.eng.frame_fetch_groups(slot)
+        out, off = [], 0
+        for c in range(self.cameras):
+            cost = costs[c] if costs[c] is not None else np.zeros((len(groups[c][1]), ms[c]), np.float32)
+            out.append((emb[off:off + ms[c]], cost.astype(np.float64), ious[c]))
+            off += ms[c]
+        return out
+
+    def commit(self, rows, targets, active_targets):
+        """Per camera c: detection row rows[c][i] of ITS detections becomes a sample of its track targets[c][i]; its tracks missing
+        from active_targets[c] are forgotten.  Asynchronous.  Moves on to the next frame time."""
+        slot = self._frame & 1
+        off = 0
+        for c, met in enumerate(self.metrics):
+            met.frame_partial_fit(slot, np.asarray(rows[c], np.int32) + off, targets[c], active_targets[c])
+            off += self._m[slot][c]
+        self._frame += 1
+
+    def close(self, destroy=False):
+        self.eng.sync()
+        if destroy:
+            for met in self.metrics:
+                met.close()
+            if self._own:
+                self.eng.close()
+
+
 class ShardedCameraStream:
     """One camera stream whose frames are dealt over the ranks of a multi-GPU job (BASELINE configs[3]):
     every rank embeds its round-robin share of a frame's crops (`parallel.round_robin`), ONE device-side all-gather per frame

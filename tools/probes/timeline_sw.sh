@@ -1,0 +1,12 @@
+# kernel timeline of one fp32-class forward of N crops under debug switches: bash tools/probes/timeline_sw.sh N "switches" tag
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+OUT=$ROOT/gpurun_out/r6
+N=${1:-30}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+export REID_DEBUG_SWITCHES="$2"
+rocprofv3 --kernel-trace -d $OUT/tl -o p -- python3 $ROOT/tools/profile_small_batch.py $N f16x3 > $OUT/tl.log 2>&1
+tail -1 $OUT/tl.log > $OUT/timeline_$N$3.txt
+python3 $ROOT/tools/timeline.py $OUT/tl/p_results.db stem_split 3 >> $OUT/timeline_$N$3.txt 2>&1
+rm -rf $OUT/tl
+cat $OUT/timeline_$N$3.txt
