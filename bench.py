@@ -779,8 +779,13 @@ def run_all(job, args):
                 open(flag, "w").close()
             except OSError:
                 pass
+            import atexit
+            atexit.register(lambda: os.path.exists(flag) and os.unlink(flag))   # (os._exit below skips it: the next job of this rendezvous unlinks a stale flag)
         elif job.world > 1:
-            t_end = time.monotonic() + 10.0
+            # rank 0's watchdog runs on the same limit from its own clock: wait for what is left of the current sub-workload's limit plus a
+            # margin, not a fixed 10 s (an exception on this rank can come long before rank 0's deadline)
+            left = (state["deadline"] - time.monotonic()) if state["deadline"] is not None else 0.0
+            t_end = time.monotonic() + max(10.0, left + 15.0)
             while not os.path.exists(flag) and time.monotonic() < t_end:
                 time.sleep(0.05)
         os._exit(3)                           # a lost collective / hung or failed sub-workload is a FAILED run
@@ -789,6 +794,8 @@ def run_all(job, args):
         while True:
             time.sleep(0.25)
             dl = state["deadline"]
+            if dl is not None and job.rank == 0:       # tests: force the order "another rank notices first" (seconds added to rank 0's limit)
+                dl += float(os.environ.get("REID_BENCH_TEST_RANK0_WATCHDOG_DELAY", "0"))
             if dl is not None and time.monotonic() > dl:
                 print("[bench rank %d] watchdog: %s did not come back within its time limit" % (job.rank, state["current"]),
                       file=sys.stderr, flush=True)

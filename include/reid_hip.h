@@ -93,6 +93,14 @@ int reid_ctx_set_chunk(reid_ctx* ctx, int crops_per_pass);
  *       range, and so is loading such a checkpoint into a context already in mode 2; an activation outside the range raises the
  *       context's fault word (reid_ctx_clear_fault below). */
 int reid_ctx_set_precision(reid_ctx* ctx, int mode);
+/* The shared context of a process may hold the weights of BOTH backbones.  reid_ctx_set_precision(2) refuses when either loaded
+ * checkpoint is outside the range; a host object that owns one of them asks here whether ITS checkpoint is the reason: arch 0 =
+ * ResNet18-IBN-SE family, 1 = Swin; REID_OK when that checkpoint can run in `mode` (or none is loaded), REID_ERR_ARG + the
+ * tensor's name otherwise.  reid_ctx_fault_peek: the sticky fault word without draining the stream or starting work (bit 0 range,
+ * bit 1 non-finite embedding, bit 2 split-K rendezvous) - lets a caller tell a fault that predates its call from one it raised.
+ * (No reference counterpart: the reference has one arithmetic, modification_deepsort/feature_extractor.py:15-29.) */
+int reid_ctx_precision_ok(reid_ctx* ctx, int arch, int mode);
+int reid_ctx_fault_peek(reid_ctx* ctx, int* bits);
 /* optional side information of the NEXT embed call(s): one index per image, consumed in order by the passes that follow (n images
  * in total; n = 0 clears).  ResNet18-IBN-SE: the camera of every crop - SERse18_IBN.forward(x, cam) adds cam_factor *
  * cam_bias[cam] to the BNNeck output before the classifier (reid/backbones/SERes18_IBN.py:269-270); Swin: the view of every

@@ -28,6 +28,8 @@ _SIGS = {
     "reid_ctx_clear_fault": (_i, [_vp]),
     "reid_ctx_set_chunk": (_i, [_vp, _i]),
     "reid_ctx_set_precision": (_i, [_vp, _i]),
+    "reid_ctx_precision_ok": (_i, [_vp, _i, _i]),
+    "reid_ctx_fault_peek": (_i, [_vp, C.POINTER(_i)]),
     "reid_ctx_set_side_index": (_i, [_vp, _vp, _i]),
     "reid_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "reid_free": (_i, [_vp, _vp]),

@@ -270,6 +270,7 @@ class SwinT:
     embed_dim = 96
 
     arch = "swin_transformer"
+    _arch = "swin"            # precision.run: which of the shared engine's two weight sets this object owns
 
     def __init__(self, num_classes=751, loss="softmax", pretrained=False, use_gpu=True, seed=0, camera=0, sequence=0, side_info=True,
                  side_info_coeff=1.5, precision=None, **_):

@@ -176,6 +176,24 @@ extern "C" int reid_ctx_set_precision(reid_ctx* ctx, int mode) {
     return REID_OK;
 }
 
+extern "C" int reid_ctx_precision_ok(reid_ctx* ctx, int arch, int mode) {
+    ARG_CHECK(ctx && (arch == 0 || arch == 1) && mode >= 0 && mode <= 2);
+    const std::string& bad = arch == 0 ? ctx->split_bad_se18 : ctx->split_bad_swin;
+    if (mode == 2 && !bad.empty()) {
+        reid_set_error("reid_ctx_precision_ok: weight tensor %s of the loaded %s checkpoint is outside the range the fp32-class arithmetic can "
+                       "split (|w| 2^11 < 65504)", bad.c_str(), arch == 0 ? "ResNet18-IBN" : "Swin");
+        return REID_ERR_ARG;
+    }
+    return REID_OK;
+}
+
+extern "C" int reid_ctx_fault_peek(reid_ctx* ctx, int* bits) {
+    ARG_CHECK(ctx && bits);
+    const volatile int* f = ctx->fault;
+    *bits = f ? ((f[0] ? 1 : 0) | (f[1] ? 2 : 0) | (f[2] ? 4 : 0)) : 0;
+    return REID_OK;
+}
+
 extern "C" int reid_ctx_set_side_index(reid_ctx* ctx, const int32_t* index, int n) {
     ARG_CHECK(ctx && n >= 0 && (index || n == 0));
     CTX_GUARD(ctx);
@@ -586,7 +604,7 @@ static bool conv_split_path(reid_ctx* ctx, int n, int H, int W, int Cin, int Cou
     q.Wo = (W + 2 * pad - S) / stride + 1;
     q.M = n * q.Ho * q.Wo; q.N = Cout;
     const bool halo = R == 3 && S == 3 && stride == 1 && pad == 1 && conv3x3_f16_supported(q);
-    const bool enough = halo || (Cout % 128 == 0 && (long long)(q.M / 256) * (Cout / 128) >= 128);
+    const bool enough = halo || (Cout % 128 == 0 && (long long)(q.M / 256) * (Cout / 128) >= ctx->split_gemm_min_tiles);
     return q.M % 128 == 0 && enough;
 }
 

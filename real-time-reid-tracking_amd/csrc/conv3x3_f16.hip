@@ -851,7 +851,11 @@ int launch_geom(reid_ctx* ctx, const Gemm16Params& p0) {
         return REID_OK;
     };
     const int tiles128 = p.N % 128 == 0 ? nmt * (p.N / 128) : 0;
+#ifdef REID_EXPERIMENTS
     constexpr bool CAN_PAIR = SPLIT && LW == 1;
+#else
+    constexpr bool CAN_PAIR = false;   // the operand-sharing PAIR order (switch split_pair: +1.1 % / -0.9 %, another summation order): experiment builds only
+#endif
     const bool pair = CAN_PAIR && ctx->split_pair && p.split_terms == 3;   // the operand-sharing order of the fp32-class products
     if (tiles128 > 128) {
         if constexpr (CAN_PAIR) {
@@ -919,9 +923,14 @@ int launch_conv3x3_f16(reid_ctx* ctx, const Gemm16Params& p, int kind, double fl
         else if (p.W == 16) st = launch_geom<16, 1, 1>(ctx, p);
         else st = launch_geom<8, 2, 1>(ctx, p);
     } else {
+#ifdef REID_EXPERIMENTS       // the builds without loader waves (switch f16_loader_waves = 0: 0.806 against 0.856 of peak): experiment builds only
         if (p.W == 32) st = launch_geom<32, 1, 0>(ctx, p);
         else if (p.W == 16) st = launch_geom<16, 1, 0>(ctx, p);
         else st = launch_geom<8, 2, 0>(ctx, p);
+#else
+        reid_set_error("conv3x3_f16: the builds without loader waves need a library made with -DREID_EXPERIMENTS");
+        st = REID_ERR_ARG;
+#endif
     }
     prof_end(ctx);
     return st;
@@ -1003,9 +1012,14 @@ int launch_conv3x3_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double 
         else if (p.W == 16) st = launch_geom<16, 1, 1, true>(ctx, p);
         else st = launch_geom<8, 2, 1, true>(ctx, p);
     } else {
+#ifdef REID_EXPERIMENTS       // the builds without loader waves (switch f16_loader_waves = 0: 0.806 against 0.856 of peak): experiment builds only
         if (p.W == 32) st = launch_geom<32, 1, 0, true>(ctx, p);
         else if (p.W == 16) st = launch_geom<16, 1, 0, true>(ctx, p);
         else st = launch_geom<8, 2, 0, true>(ctx, p);
+#else
+        reid_set_error("conv3x3_f16: the builds without loader waves need a library made with -DREID_EXPERIMENTS");
+        st = REID_ERR_ARG;
+#endif
     }
     prof_end(ctx);
     return st;

@@ -1418,9 +1418,11 @@ int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
     const bool unrolled = ctx->x3_unroll && (long long)p.M * (p.Cin / 3) * 4 < 0x7f000000ll && (long long)p.N * p.ldb * 2 < 0x7f000000ll;
     if (wide && unrolled) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 128, 2>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     else if (wide) hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
-    else if (unrolled && ctx->x3_unroll == 4) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 64, 4>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     else if (unrolled && ctx->x3_unroll == 3) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 64, 3>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+#ifdef REID_EXPERIMENTS   // four blocks per CU (spills: 14.05 against 12.32 ms per pass) and groups of three steps per barrier: experiment builds only
+    else if (unrolled && ctx->x3_unroll == 4) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 64, 4>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     else if (unrolled && ctx->x3_unroll == 5) hipLaunchKernelGGL((conv3x3_x3u_kernel<TW, IMGS, 64, 3, 3>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+#endif
     else hipLaunchKernelGGL((conv3x3_x3m16_kernel<TW, IMGS, 64>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
     return REID_OK;
 }

@@ -650,11 +650,17 @@ void launch_bn(reid_ctx* ctx, const GemmParams& p0) {
             }
         }
     }
-    if (!p.a_scale && ctx->f32_conv != 2 && conv_f32_dma_supported(p)) {   // REID_F32_CONV=2: register-staged kernel everywhere (A/B)
+#ifdef REID_EXPERIMENTS
+    const bool staged_everywhere = ctx->f32_conv == 2;     // switch f32_conv = 2: the register-staged kernel everywhere (A/B)
+#else
+    const bool staged_everywhere = false;
+#endif
+    if (!p.a_scale && !staged_everywhere && conv_f32_dma_supported(p)) {
         if (p.diag) hipLaunchKernelGGL((conv_f32_dma_kernel<BN, 1>), dim3(grid), dim3(256), 0, ctx->stream, p);
         else hipLaunchKernelGGL((conv_f32_dma_kernel<BN, 0>), dim3(grid), dim3(256), 0, ctx->stream, p);
         return;
     }
+#ifdef REID_EXPERIMENTS
     const bool prio = false;   // s_setprio around the staging block: measured, no gain (the MFMA holds the issue port)
 #define CONV_F32_LAUNCH(AFF, FL) hipLaunchKernelGGL((conv_f32_kernel<BN, AFF, FL>), dim3(grid), dim3(256), 0, ctx->stream, p)
     if (p.diag) {   // experiments: the same kernel with s_memtime stamps around the segments of a K-tile
@@ -665,6 +671,11 @@ void launch_bn(reid_ctx* ctx, const GemmParams& p0) {
     if (p.a_scale) { if (prio) CONV_F32_LAUNCH(true, 2); else CONV_F32_LAUNCH(true, 0); }
     else { if (prio) CONV_F32_LAUNCH(false, 2); else CONV_F32_LAUNCH(false, 0); }
 #undef CONV_F32_LAUNCH
+#else
+    // the register-staged kernel of round 1 (switch f32_conv = 2, or a transform in the loader): 16 builds, in libraries made with
+    // -DREID_EXPERIMENTS only; conv_f32_supported() keeps such convolutions away from here in the product library
+    (void)grid;
+#endif
 }
 
 }  // namespace
@@ -673,7 +684,11 @@ bool conv_f32_supported(const GemmParams& p) {
     return p.Cin % BK == 0 && p.K == p.R * p.S * p.Cin && p.M % BM == 0 && (p.Ho * p.Wo) % BM == 0 && p.N % 64 == 0 &&
            p.Wo >= 1 && p.Wo <= 32 && 32 % p.Wo == 0 &&
            p.ldb % 4 == 0 && p.ldc == p.N && (p.a_scale == nullptr) == (p.a_shift == nullptr) &&
-           (p.col_scale == nullptr) == (p.col_shift == nullptr) && (long long)p.H * p.W * p.Cin < (1ll << 31);
+           (p.col_scale == nullptr) == (p.col_shift == nullptr) && (long long)p.H * p.W * p.Cin < (1ll << 31)
+#ifndef REID_EXPERIMENTS
+           && !p.a_scale && conv_f32_dma_supported(p)      // (the register-staged kernel is not in the product library)
+#endif
+        ;
 }
 
 bool conv_f32_general_supported(const GemmParams& p) {

@@ -779,25 +779,46 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
                 case 256642: return launch_cfg<AMODE, 256, 64, 2, 0, true>(ctx, p);
                 case 128323: return launch_cfg<AMODE, 128, 32, 3, 0, true>(ctx, p);
                 case 64323: return launch_cfg<AMODE, 64, 32, 3, 0, true>(ctx, p);
+#ifdef REID_EXPERIMENTS
                 case 64642: return launch_cfg<AMODE, 64, 64, 2, 0, true>(ctx, p);
+#endif
                 default: break;
             }
         }
         reid_set_error("gemm_f16: no linear-epilogue build of tile configuration %d", cfg);
         return REID_ERR_ARG;
     }
+    // The product library carries the builds the heuristic above can pick; every other tile / ring configuration, the staggered
+    // schedule (+1000000) and the stamped diagnostic builds (+3000000) - 17 more per A mode, most of them spilling - exist in builds
+    // made with -DREID_EXPERIMENTS only (make EXPERIMENTS=1: tools/gemm_cfg_sweep.py, tools/diag_gemm_f16.py).
+    if constexpr (AMODE == A16_STEM) {           // the 7x7 stem: 64 output channels
+        switch (cfg) {
+            case 64323: return launch_cfg<AMODE, 64, 32, 3>(ctx, p);
+            case 64642: return launch_cfg<AMODE, 64, 64, 2>(ctx, p);
+            default: break;
+        }
+    } else {
+        switch (cfg) {
+            case 256324: return launch_cfg<AMODE, 256, 32, 4>(ctx, p);
+            case 256642: return launch_cfg<AMODE, 256, 64, 2>(ctx, p);
+            case 128323: return launch_cfg<AMODE, 128, 32, 3>(ctx, p);
+            case 128642: return launch_cfg<AMODE, 128, 64, 2>(ctx, p);
+            case 64323: return launch_cfg<AMODE, 64, 32, 3>(ctx, p);
+            case 64642: return launch_cfg<AMODE, 64, 64, 2>(ctx, p);
+            default: break;
+        }
+    }
+#ifdef REID_EXPERIMENTS
     switch (cfg) {
         case 256324: return launch_cfg<AMODE, 256, 32, 4>(ctx, p);
-        case 256323: return launch_cfg<AMODE, 256, 32, 3>(ctx, p);
         case 256642: return launch_cfg<AMODE, 256, 64, 2>(ctx, p);
-        case 128324: return launch_cfg<AMODE, 128, 32, 4>(ctx, p);
         case 128323: return launch_cfg<AMODE, 128, 32, 3>(ctx, p);
-        case 128643: return launch_cfg<AMODE, 128, 64, 3>(ctx, p);
         case 128642: return launch_cfg<AMODE, 128, 64, 2>(ctx, p);
-        case 64323: return launch_cfg<AMODE, 64, 32, 3>(ctx, p);
+        case 256323: return launch_cfg<AMODE, 256, 32, 3>(ctx, p);
+        case 128324: return launch_cfg<AMODE, 128, 32, 4>(ctx, p);
+        case 128643: return launch_cfg<AMODE, 128, 64, 3>(ctx, p);
         case 64324: return launch_cfg<AMODE, 64, 32, 4>(ctx, p);
         case 64643: return launch_cfg<AMODE, 64, 64, 3>(ctx, p);
-        case 64642: return launch_cfg<AMODE, 64, 64, 2>(ctx, p);
         // staggered schedule: +1000000
         case 1256324: return launch_cfg<AMODE, 256, 32, 4, 1>(ctx, p);
         case 1256323: return launch_cfg<AMODE, 256, 32, 3, 1>(ctx, p);
@@ -812,10 +833,11 @@ int launch_any(reid_ctx* ctx, const Gemm16Params& p) {
         case 3128643: return launch_cfg<AMODE, 128, 64, 3, 2>(ctx, p);
         case 3128642: return launch_cfg<AMODE, 128, 64, 2, 2>(ctx, p);
         case 3256324: return launch_cfg<AMODE, 256, 32, 4, 2>(ctx, p);
-        default:
-            reid_set_error("gemm_f16: unknown tile configuration %d", cfg);
-            return REID_ERR_ARG;
+        default: break;
     }
+#endif
+    reid_set_error("gemm_f16: no build of tile configuration %d in this library (experiment configurations need -DREID_EXPERIMENTS)", cfg);
+    return REID_ERR_ARG;
 }
 
 }  // namespace

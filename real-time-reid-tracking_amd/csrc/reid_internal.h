@@ -378,6 +378,7 @@ struct reid_ctx {
     int split_x3 = 3;        // precision 2, large launches: conv3x3_x3.hip instead of conv3x3_f16.hip's 12-wave kernel: 3 (default) = on
                              // v_mfma_f32_16x16x32_f16, two blocks per CU for the 128-wide tiles (layers 2-4) and FOUR for the 64-wide ones
                              // (layer 1); 2 = the 128-wide tiles only; 1 = the first form on 32x32x16; 0 = off
+    int split_gemm_min_tiles = 128;   // precision 2: strided / 1x1 convolutions take the SPLIT build of gemm_f16.hip from this many 256 x 128 tiles on (below: the exact-fp32 split-K kernel)
     int x3_sk_cap = 0;       // experiments: upper bound of the split-K factor of conv3x3_x3.hip's small launches (0 = the heuristic's)
     int split_x3_small = 2;  // ... and smaller launches: 2 (default) = where they measured faster than conv3x3_f16.hip's 12-wave kernel (conv3x3_x3_supported),
                              // 1 = every launch, 0 = none; K split over up to 8 blocks per tile (x3m16_tail: reduce-scatter)

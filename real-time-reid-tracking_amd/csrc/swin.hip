@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void sfe_norm_kernel(const float* __restrict__
 
 // ---- ShadowFeatureExtraction part 2 (:297-303): MixedNorm + ReLU -> conv2x2 s2 (12 -> 48, bias) -> ReLU -> Linear(48 -> 96)
 // one thread per token; weights in LDS
-__global__ __launch_bounds__(256) void sfe_conv2_fc_kernel(const float* __restrict__ y, const float* __restrict__ ab, int n,
+__global__ __launch_bounds__(256, 3) void sfe_conv2_fc_kernel(const float* __restrict__ y, const float* __restrict__ ab, int n,
                                                            int h1, int w1, const float* __restrict__ w2,
                                                            const float* __restrict__ b2, const float* __restrict__ wf,
                                                            const float* __restrict__ bf, float* __restrict__ tok) {
@@ -128,22 +128,32 @@ __global__ __launch_bounds__(256) void sfe_conv2_fc_kernel(const float* __restri
 #pragma unroll
                 for (int c = 0; c < 12; ++c) in[(kh * 2 + kw) * 12 + c] = fmaxf(src[c] * a[c] + a[12 + c], 0.f);
             }
-        float mid[48];
-#pragma unroll 4
+        // conv2's 48 outputs are consumed as they are produced: out[j] collects swf[j][k] * mid[k] in the k order of the plain
+        // two-loop form (bias first, then k = 0 .. 47), so the sums are the same operations in the same order.  No array is
+        // indexed with a run-time value (a `mid[48]` written in a partly unrolled loop lived in scratch: 208 bytes per lane)
+        float out[96];
+#pragma unroll
+        for (int j = 0; j < 96; ++j) out[j] = sbf[j];
+#pragma unroll 1
         for (int co = 0; co < 48; ++co) {
             float acc = sb2[co];
 #pragma unroll
-            for (int k = 0; k < 48; ++k) acc += sw2[co * 48 + k] * in[k];
-            mid[co] = fmaxf(acc, 0.f);
+            for (int k0 = 0; k0 < 48; k0 += 16) {      // (scheduling barriers: hipcc otherwise requests all 144 LDS words of an iteration up front - 264 registers)
+#pragma unroll
+                for (int k = k0; k < k0 + 16; ++k) acc += sw2[co * 48 + k] * in[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float m = fmaxf(acc, 0.f);
+#pragma unroll
+            for (int j0 = 0; j0 < 96; j0 += 16) {
+#pragma unroll
+                for (int j = j0; j < j0 + 16; ++j) out[j] += swf[j * 48 + co] * m;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         float* o = tok + i * 96;
-#pragma unroll 4
-        for (int co = 0; co < 96; ++co) {
-            float acc = sbf[co];
 #pragma unroll
-            for (int k = 0; k < 48; ++k) acc += swf[co * 48 + k] * mid[k];
-            o[co] = acc;
-        }
+        for (int j = 0; j < 96; j += 4) *(f32x4*)(o + j) = f32x4{out[j], out[j + 1], out[j + 2], out[j + 3]};
     }
 }
 

@@ -363,7 +363,10 @@ struct LnLinearParams {
 };
 
 template <int C, int NW, int GPS>
-__global__ __launch_bounds__(NW * 64, 2) void ln_linear_f16x3_kernel(const LnLinearParams p) {
+// (C = 192 is built for ONE block per CU: held to 256 registers - two blocks - it spilled 172 bytes per lane and re-read token fragments from
+// scratch inside its K loop; reordering the LayerNorm phase, a second read of the row, packing the f16 pairs early and scheduling barriers in
+// both phases all left 168-228 bytes (round 6).  The kernel streams x and qkv at HBM rate either way.)
+__global__ __launch_bounds__(NW * 64, C > 96 ? 1 : 2) void ln_linear_f16x3_kernel(const LnLinearParams p) {
     constexpr int NT = 3 * C / 32, KS1 = 3 * C / 16, KR = 2 * C / 16;
     constexpr int HB = NT * 2048, SB = GPS * HB, PI = SB / 1024, IPW = (PI + NW - 1) / NW;
     static_assert(2 * SB + 8 * C <= 160 * 1024, "LDS budget");

@@ -71,6 +71,16 @@ class Engine:
         """Resets the sticky fault word (an activation outside f16's range in mode 2 / a non-finite embedding)."""
         check(self.lib.reid_ctx_clear_fault(self.h))
 
+    def precision_ok(self, arch, mode):
+        """Can the loaded checkpoint of ``arch`` (0 = ResNet18-IBN-SE family, 1 = Swin) run in ``mode``?  (reid_ctx_precision_ok)"""
+        return self.lib.reid_ctx_precision_ok(self.h, int(arch), int(mode)) == 0
+
+    def fault_bits(self):
+        """The sticky fault word as bits (1 range, 2 non-finite embedding, 4 split-K rendezvous), without synchronising."""
+        b = C.c_int()
+        check(self.lib.reid_ctx_fault_peek(self.h, C.byref(b)))
+        return b.value
+
     def set_stream(self, hip_stream):
         """Run on another HIP stream (0 / None = the context's own).  Work already enqueued on the old stream shares the
         context's workspaces with what follows, so a switch drains the old stream first."""

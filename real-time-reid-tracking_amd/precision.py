@@ -37,8 +37,9 @@ def resolve(precision=None):
 
 def refused(err):
     """True for the two ways the fp32-class mode turns a checkpoint down: weights it cannot split (REID_ERR_ARG from
-    reid_ctx_set_precision) or an activation outside f16's range at run time (REID_ERR_STATE, the sticky fault word)."""
-    return isinstance(err, ReidHipError) and err.status in (-1, -3) and ("fp32-class" in str(err) or "non-finite" in str(err))
+    reid_ctx_set_precision) or an activation outside f16's range at run time (REID_ERR_STATE, bit 0 of the sticky fault word -
+    NOT the "non-finite embedding" fault, which says nothing about the arithmetic)."""
+    return isinstance(err, ReidHipError) and err.status in (-1, -3) and "fp32-class" in str(err)
 
 
 def fallback_to_exact(owner, err, what):
@@ -50,21 +51,37 @@ def fallback_to_exact(owner, err, what):
 def run(owner, eng, what, fn):
     """``fn(eng)`` with the owner's weights bound and the context in ``owner._mode``; the (process-wide, shared) engine gets its
     previous mode back afterwards.  ``owner._needs_bind(eng)`` / ``owner._do_bind(eng)``: the weights are (re)loaded in mode 0,
-    which accepts every checkpoint, then the mode is switched - so a refusal is about THIS checkpoint.  When the fp32-class mode
-    turns it down (at the switch, or through the fault word while running) the owner falls back to exact fp32 for good and the
-    call is repeated once."""
+    which accepts every checkpoint, then the mode is switched.  When the fp32-class mode turns THIS owner's checkpoint down (at the
+    switch, or through the fault word while running) the owner falls back to exact fp32 for good and the call is repeated once.
+    The engine is shared by both backbones: a refusal at the switch that is about the OTHER architecture's checkpoint
+    (``eng.precision_ok(owner arch, 2)`` says this one is fine) costs this call its mode - it runs in exact fp32, logged once per
+    owner - but not the owner's; and a fault word that was already up when the call began belongs to somebody else's work and is
+    re-raised, not cleared."""
+    arch = 1 if getattr(owner, "_arch", "seres18") == "swin" else 0
     for _ in range(2):
         prev = eng.precision
+        fault_before = eng.fault_bits() if hasattr(eng, "fault_bits") else 0
+        mode = owner._mode
         try:
             if owner._needs_bind(eng):
                 if prev != EXACT:
                     eng.set_precision(EXACT)
                 owner._do_bind(eng)
-            if eng.precision != owner._mode:
-                eng.set_precision(owner._mode)
+            if eng.precision != mode:
+                try:
+                    eng.set_precision(mode)
+                except ReidHipError as e:
+                    if mode == F32_CLASS and e.status == -1 and hasattr(eng, "precision_ok") and eng.precision_ok(arch, F32_CLASS):
+                        if not getattr(owner, "_warned_shared", False):
+                            owner._warned_shared = True
+                            log.warning("%s: another model's checkpoint on this engine keeps it out of the fp32-class mode; this model runs in "
+                                        "exact fp32 while that one is loaded (%s)", what, e)
+                        eng.set_precision(EXACT)
+                    else:
+                        raise
             return fn(eng)
         except ReidHipError as e:
-            if owner._mode != F32_CLASS or not refused(e):
+            if owner._mode != F32_CLASS or not refused(e) or (e.status == -3 and (fault_before & 1)):
                 raise
             if e.status == -3:
                 eng.clear_fault()

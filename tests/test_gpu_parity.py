@@ -1635,6 +1635,27 @@ def test_plugin_precision_argument_environment_and_fallback(eng_w0, caplog, monk
         assert len([r for r in caplog.records if "fp32-class" in r.getMessage()]) == 1
         assert np.array_equal(out, out2) and np.array_equal(out, Extractor(hot, precision="f32")(crops))
         eng.sync()                                # no fault left pending
+        # (3) the shared engine holds BOTH backbones' weights: a Swin checkpoint the fp32-class mode refuses must not cost an
+        # extractor with a good ResNet checkpoint its mode for good (round-5 advice) - while the bad Swin weights are loaded the
+        # extractor's calls run in exact fp32 (one log line that says why), its own mode stays "f16x3", and it is back on the
+        # fp32-class arithmetic as soon as a splittable Swin checkpoint replaces the bad one
+        sw_sd = synth.swin_state_dict(0)
+        sw_bad = dict(sw_sd)
+        key = next(k for k in sw_sd if k.endswith("to_qkv.weight"))
+        sw_bad[key] = np.array(sw_sd[key], copy=True)
+        sw_bad[key][0, 0] = 50.0
+        eng.load_swin(*weights.pack_swin(sw_bad)[:2])
+        assert eng.precision_ok(0, 2) and not eng.precision_ok(1, 2)
+        with caplog.at_level(logging.WARNING, logger="root.tracker"):
+            caplog.clear()
+            shared = e2(crops)
+            shared2 = e2(crops)
+        assert e2.precision == "f16x3" and np.array_equal(shared, a0) and np.array_equal(shared2, a0)
+        assert len([r for r in caplog.records if "another model" in r.getMessage()]) == 1
+        eng.load_swin(*weights.pack_swin(sw_sd)[:2])
+        assert np.array_equal(e2(crops), a2)
+        # ... and a fault word that was already up when a call began is not this call's to clear
+        assert eng.fault_bits() == 0
     finally:
         eng.clear_fault()
         eng.set_precision(0)
