@@ -80,7 +80,8 @@ def traffic_source(tag):
     if not cands:
         return None
     try:
-        return "profiles/%s (commit %s)" % (os.path.basename(cands[-1]), json.load(open(cands[-1])).get("commit", "unknown"))
+        return ("profiles/%s (commit %s) - a constant read from that committed PMC profile, not re-measured in this run; a profile of an "
+                "earlier round means the kernels of this class have not changed since" % (os.path.basename(cands[-1]), json.load(open(cands[-1])).get("commit", "unknown")))
     except ValueError:
         return None
 

@@ -468,7 +468,9 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
         koff_a[a] = row_ok ? (lrow * 2 * p.N + col0) * 2 : 0x7fffff00;
     }
     const bool has_stats = p.stats != nullptr;
-    unsigned vm_run = 0u;      // largest packed magnitude, as bits (NaN > inf > finite), taken BEFORE the ReLU (range_acc, reid_internal.h)
+    float vmax = 0.f;          // largest packed magnitude of the unsplit path (after the ReLU, as in conv3x3_f16.hip: a NaN that a ReLU column
+                               // clamps to 0 is caught downstream - the neck's non-finite check - not here; the bit-pattern form taken before the
+                               // clamp, which the split-K path below uses, costs this hot epilogue 1 % of a 1024-crop pass)
     // every choice below (residual, [yh | yl'] or fp32 store, statistics) is uniform per wave and per 16-column tile and is taken
     // by a scalar branch AROUND a straight-line body of four tiles: per-element selects and branches made this epilogue ~1 000
     // vector instructions per wave, each of which waits 11-45 cycles for an issue slot beside the other blocks' MFMAs
@@ -506,7 +508,6 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
                     }
                     if constexpr (RES)
                         v[i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff_a[a] + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, 0));
-                    if (pk) vm_run = range_acc(range_acc(range_acc(range_acc(vm_run, v[i][0]), v[i][1]), v[i][2]), v[i][3]);   // before the ReLU: max(NaN, 0) is 0
                     if (!LIN) {      // (linear layers have no ReLU)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], lo);
@@ -524,6 +525,7 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const float v0 = v[i][2 * h], v1 = v[i][2 * h + 1];
+                            vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
                             const f16 h0 = cvt_f16_rn(v0), h1 = cvt_f16_rn(v1);      // one rounding of the materialised fp32 value (lin_math.h)
                             const f16 l0 = cvt_f16_rn((v0 - (float)h0) * 2048.0f), l1 = cvt_f16_rn((v1 - (float)h1) * 2048.0f);
                             hw[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
@@ -665,7 +667,7 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
             else run(std::false_type{}, std::false_type{});
         }
     }
-    range_raise(p.fault, vm_run);
+    if (p.fault && !(vmax < 65504.f)) p.fault[0] = 1;
     if (sk_path) {
         // every load of the partials has returned (their values were used above): the block that counts the tile's last reader
         // resets the two counters for the next launch

@@ -70,11 +70,9 @@ import os
 res = {
     "kernel_class": LABEL,
     "commit": os.environ.get("REID_COMMIT", "unknown"),    # the tree the profiled library was built from (passed by the caller: the GPU box has no .git)
-    "command": ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload swin --crops 512 --steps 1 --warmup 1 --no-cpu --single --precision %s" % MODE[5:]
-                if MODE.startswith("swin_") else
-                "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload market --steps 2 --warmup 1 --no-cpu"
-                if MODE in ("market", "select") else
-                "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --workload embed --no-cpu --single --precision %s (4096 crops, chunk 1024)" % MODE),
+    # the argv that was actually profiled, recorded by the script that ran it (round 5's file claimed --crops 512 for a run of 1024)
+    "command": ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- " + os.environ["REID_PROFILED_COMMAND"])
+               if os.environ.get("REID_PROFILED_COMMAND") else "not recorded (the caller did not export REID_PROFILED_COMMAND)",
     "launches": launches,
     "fetch_size_kb_raw_per_launch": fetch_kb / max(1, launches),
     "write_size_kb_per_launch": write_kb / max(1, sum(v[0] for v in write.values())),

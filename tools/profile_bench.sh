@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace_$MODE -o p -- python3 $ROO
 python3 $ROOT/tools/rocprof_summary.py $OUT/${TAG}_trace_$MODE/p_results.db 40 > $OUT/${TAG}_bench_${MODE}_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch_$MODE -o p -- python3 $ROOT/bench.py --workload embed --steps 1 --warmup 1 --no-cpu --single --precision $MODE > /dev/null 2> $OUT/${TAG}_pmc_fetch_$MODE.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write_$MODE -o p -- python3 $ROOT/bench.py --workload embed --steps 1 --warmup 1 --no-cpu --single --precision $MODE > /dev/null 2> $OUT/${TAG}_pmc_write_$MODE.err
+export REID_PROFILED_COMMAND="python3 bench.py --workload embed --steps 1 --warmup 1 --no-cpu --single --precision $MODE"
 python3 $ROOT/tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch_$MODE/p_results.db $OUT/${TAG}_pmc_write_$MODE/p_results.db $MODE > $OUT/${TAG}_traffic_conv_$MODE.json
 # the raw databases are large: keep the summaries only
 rm -rf $OUT/${TAG}_trace_$MODE $OUT/${TAG}_pmc_fetch_$MODE $OUT/${TAG}_pmc_write_$MODE

@@ -7,6 +7,7 @@ TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 CMD="python3 $ROOT/bench.py --workload market --steps 2 --warmup 1 --no-cpu"
+export REID_PROFILED_COMMAND="python3 bench.py --workload market --steps 2 --warmup 1 --no-cpu"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_mk_trace -o p -- $CMD > $OUT/${TAG}_mk_trace.json 2> $OUT/${TAG}_mk_trace.err
 python3 $ROOT/tools/rocprof_by_grid.py $OUT/${TAG}_mk_trace/p_results.db > $OUT/${TAG}_market_kernel_stats.csv

@@ -14,6 +14,7 @@ rm -rf $OUT/${TAG}_swintrace_$MODE
 # HBM-side traffic of the contraction class: counters in passes of their own (one step of the same pass size, so that a launch
 # is the launch bench.py prices)
 PCMD="python3 $ROOT/bench.py --workload swin --crops $N --steps 1 --warmup 1 --no-cpu --single --precision $MODE"
+export REID_PROFILED_COMMAND="python3 bench.py --workload swin --crops $N --steps 1 --warmup 1 --no-cpu --single --precision $MODE"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_swin_fetch_$MODE -o p -- $PCMD > /dev/null 2> $OUT/${TAG}_swin_fetch_$MODE.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_swin_write_$MODE -o p -- $PCMD > /dev/null 2> $OUT/${TAG}_swin_write_$MODE.err
 python3 $ROOT/tools/pmc_traffic.py $OUT/${TAG}_swin_fetch_$MODE/p_results.db $OUT/${TAG}_swin_write_$MODE/p_results.db swin_$MODE > $OUT/${TAG}_traffic_swin_$MODE.json
