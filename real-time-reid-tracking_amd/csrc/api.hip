@@ -678,6 +678,92 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
     return launch_gemm_f32(ctx, amode, E_CONV, p, REID_K_CONV_GEMM, flops, bytes);
 }
 
+// precision 2: the [wh 2^11 | wh | wl'] f16 form of a convolution's weights (made once per checkpoint, cached by the blob address)
+static int split_weights_of(reid_ctx* ctx, const float* wgt, int Cout, int taps, int Cin, const _Float16** out) {
+    auto it = ctx->split_w.find(wgt);
+    if (it == ctx->split_w.end()) {
+        void* w16;
+        HIP_TRY(hipMalloc(&w16, (size_t)Cout * taps * ctx->split_terms * Cin * 2));
+        REID_TRY(launch_split_weights(ctx, wgt, Cout, taps, Cin, ctx->split_terms, (_Float16*)w16));
+        it = ctx->split_w.emplace(wgt, w16).first;
+    }
+    *out = (const _Float16*)it->second;
+    return REID_OK;
+}
+
+#ifdef REID_EXPERIMENTS
+// Layer 4 of a small batch as ONE chain launch (conv3x3_x3.hip chain_kernel): conv1 / conv2 / SE tail of blocks 41 and 42, six stages,
+// items ordered stage by stage and image pair by image pair; block 41's 1x1 shortcut convolution was launched before (it reads the
+// layer input only).  Reference: SERes18_IBN.py:96-128 (SEBasicBlock), :223-226 (layer 4: stride forced to 1).
+static int seres18_chain_layer4(reid_ctx* ctx, int n, const Se18Block& ka, const Se18Block& kb, const _Float16* in16, const float* sc,
+                                float* y, float* out_a, float* out, float* stats) {
+    const int H = 16, W = 8, hw = 128, C = 512, SK = 4, nnt = C / 128;
+    const int nmt = (n * hw + 255) / 256;
+    _Float16 *c1_16, *a16;
+    float* skws;
+    int* cnt;
+    REID_TRY(ctx_ws(ctx, "split.c1", (size_t)n * hw * C * 2 * 2, (void**)&c1_16));
+    REID_TRY(ctx_ws(ctx, "chain.a16", (size_t)n * hw * C * 2 * 2, (void**)&a16));
+    const size_t part = (size_t)nmt * nnt * SK * 256 * 128;          // floats of one convolution's split-K partials
+    REID_TRY(ctx_ws(ctx, "chain.splitk", 4 * part * sizeof(float), (void**)&skws));
+    const bool fresh = ctx->ws.find("chain.cnt") == ctx->ws.end();
+    REID_TRY(ctx_ws(ctx, "chain.cnt", (4 * 512 + 64 + 8 * 64) * sizeof(int), (void**)&cnt));
+    if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, (4 * 512 + 64 + 8 * 64) * sizeof(int), ctx->stream));
+    ChainParams cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.n_img = n;
+    cp.flags = ctx->chain;
+    cp.counters = cnt + 4 * 512;
+    cp.fault = ctx->fault;
+    auto conv = [&](int idx, const _Float16* a, int cin, const float* wgt, const float* scale, const float* shift, const float* res, int relu,
+                    float* stats_out, _Float16* pack) -> int {
+        Gemm16Params& q = cp.conv[idx];
+        q.H = H; q.W = W; q.Cin = 3 * cin; q.R = 3; q.S = 3; q.stride = 1; q.pad = 1; q.Ho = H; q.Wo = W;
+        q.M = n * hw; q.N = C; q.K = 9 * 3 * cin; q.ldb = q.K;
+        q.split_terms = 3;
+        q.A = a;
+        REID_TRY(split_weights_of(ctx, wgt, C, 9, cin, &q.B));
+        q.C32 = y; q.ldc = C;
+        q.col_scale = scale; q.col_shift = shift; q.res32 = res; q.relu = relu; q.relu_from = 0;
+        q.stats = stats_out;
+        q.acc_scale = 1.0f / 2048.0f;
+        q.zero_page = ctx->se18.zero_page;
+        q.pack16 = pack; q.pack_from = 0;
+        q.split_k = SK; q.splitk_ws = skws + (size_t)idx * part; q.splitk_cnt = cnt + idx * 512;
+        q.fault = ctx->fault;
+        return REID_OK;
+    };
+    REID_TRY(conv(0, in16, ka.cin, ka.conv1_w, ka.bn1_scale, ka.bn1_shift, nullptr, 1, nullptr, c1_16));
+    REID_TRY(conv(1, c1_16, C, ka.conv2_w, ka.bn2_scale, ka.bn2_shift, nullptr, 0, stats, nullptr));
+    REID_TRY(conv(2, a16, C, kb.conv1_w, kb.bn1_scale, kb.bn1_shift, nullptr, 1, nullptr, c1_16));
+    REID_TRY(conv(3, c1_16, C, kb.conv2_w, kb.bn2_scale, kb.bn2_shift, out_a, 1, stats, nullptr));
+    const int slices = 2;
+    auto se = [&](int idx, const Se18Block& k, const float* shortcut, float* o, _Float16* pk) {
+        ChainElem& e = cp.el[idx];
+        e.x = y; e.stats = stats; e.sc = shortcut; e.g = k.se_w1; e.b = k.se_w2; e.out = o; e.packed = pk;
+        e.c = C; e.half = 0; e.hw = hw; e.tiles = 1; e.mid = k.mid; e.slices = slices;
+    };
+    se(0, ka, sc, out_a, a16);
+    se(1, kb, out_a, out, nullptr);
+    const int conv_items = nmt * nnt * SK, se_items = n * slices;
+    const int kinds[6] = {0, 0, 2, 0, 0, 2}, idxs[6] = {0, 1, 0, 2, 3, 1};
+    const int targets[6] = {0, nnt * SK, nnt * SK, slices, nnt * SK, nnt * SK};
+    int first = 0;
+    for (int s = 0; s < 6; ++s) {
+        ChainStage& st = cp.st[s];
+        st.kind = kinds[s]; st.idx = idxs[s]; st.first = first; st.items = kinds[s] == 0 ? conv_items : se_items;
+        st.dep = s - 1; st.target = targets[s]; st.sk = SK;
+        first += st.items;
+    }
+    cp.n_stages = 6;
+    cp.total_items = first;
+    prof_begin(ctx, REID_K_CONV_GEMM, 2.0 * n * hw * C * 9.0 * (ka.cin + 3.0 * C), 0.0);
+    const int st = launch_chain(ctx, cp, W);
+    prof_end(ctx);
+    return st;
+}
+#endif   // REID_EXPERIMENTS
+
 struct Se18Bufs {
     float *stem, *pool, *t[4], *stats, *a_scale, *a_shift, *se, *gem;
     float* stage[11];
@@ -734,6 +820,23 @@ static int seres18_forward(reid_ctx* ctx, const void* x, bool is_u8, int n, floa
     if (split_mode && !stem_split) REID_TRY(launch_split_pack(ctx, b.pool, (long long)n * 64 * 32, 64, cur16));
     for (int i = 0; i < 8; ++i) {
         const Se18Block& k = w.blk[i];
+#ifdef REID_EXPERIMENTS
+        if (i == 6 && (ctx->chain & 1) && cur16 && !keep && n <= 64 && ctx->pack_epilogue && ctx->split_terms == 3) {
+            // layer 4 of a small batch: block 41's shortcut convolution, then ONE chain launch for everything else (chain_kernel)
+            float* fr[3];
+            int nf = 0;
+            for (int j = 0; j < 4 && nf < 3; ++j)
+                if (tbase + (size_t)j * n * per != cur) fr[nf++] = tbase + (size_t)j * n * per;
+            float *sc = fr[0], *y = fr[1], *out_a = fr[2], *out = const_cast<float*>(cur);   // (the layer input's fp32 form is dead once the shortcut has read it)
+            REID_TRY(conv_gemm(ctx, A_IM2COL, cur, n, H, W, k.cin, k.ds_w, k.c, 1, 1, k.stride, 0, k.cin, nullptr, nullptr, 0, k.ds_scale, k.ds_shift,
+                               nullptr, 0, nullptr, sc, 0, cur16));
+            REID_TRY(seres18_chain_layer4(ctx, n, k, w.blk[7], cur16, sc, y, out_a, out, b.stats));
+            b.stage[8] = out_a;
+            b.stage[9] = out;
+            cur = out;
+            break;
+        }
+#endif
         // four rotating buffers; in debug-keep mode every block gets its own four
         float* tb[4];
         for (int j = 0; j < 4; ++j) tb[j] = tbase + ((size_t)(keep ? i * 4 : 0) + j) * n * per;

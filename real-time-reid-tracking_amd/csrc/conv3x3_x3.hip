@@ -388,7 +388,9 @@ template <int N>
 __device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Everything behind the main loop of the 16x16x32 kernels: split-K reduction (last arriver), fp32 epilogue, statistics.
-template <int TW, int IMGS, int BN, bool LIN = false>
+// COH (chain kernels, below): 16 = every load / store of an activation tensor carries sc1 - written through to / read from the point all
+// XCDs share - because producer and consumer are blocks of ONE launch on different XCDs (no kernel boundary flushes the L2s between them)
+template <int TW, int IMGS, int BN, bool LIN = false, int COH = 0>
 __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4][BN / 16], char* lds, int tid, int wm, int mtile, int n_blk,
                                            int tile_id, int ksplit, int SK) {
     constexpr int TM = 4, TN = BN / 16;
@@ -507,7 +509,7 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
                         v[i] = f32x4{g0.x, g0.y, g1.x, g1.y};
                     }
                     if constexpr (RES)
-                        v[i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff_a[a] + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, 0));
+                        v[i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff_a[a] + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, COH));
                     if (!LIN) {      // (linear layers have no ReLU)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], lo);
@@ -531,14 +533,14 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
                             hw[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
                             lw[h] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
                         }
-                        __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, koff_a[a0 + i] + b * 32, ubase * 2 * p.N * 2, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, koff_a[a0 + i] + b * 32 + p.N * 2, ubase * 2 * p.N * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, koff_a[a0 + i] + b * 32, ubase * 2 * p.N * 2, COH);
+                        __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, koff_a[a0 + i] + b * 32 + p.N * 2, ubase * 2 * p.N * 2, COH);
                     }
                 } else if (!(p.ablate & 64)) {
 #pragma unroll
                     for (int i = 0; i < AB; ++i)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), c_rs, voff_a[a0 + i] + b * 64,
-                                                               (wm * 64 + (TW == 8 ? (a0 + i) * 8 : (a0 + i) * 16)) * ldc * 4, 0);
+                                                               (wm * 64 + (TW == 8 ? (a0 + i) * 8 : (a0 + i) * 16)) * ldc * 4, COH);
                 }
             }
             if constexpr (ST) {   // this wave's column sums of the tile's 64 rows: four DPP adds across the 16 pixel lanes, lane 0 of the row writes
@@ -596,7 +598,7 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
             if constexpr (RES) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
-                    rr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff_a[a] + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, 0));
+                    rr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, voff_a[a] + b * 64, (wm * 64 + (TW == 8 ? a * 8 : a * 16)) * ldc * 4, COH));
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
@@ -620,10 +622,10 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
                         hw[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
                         lw[h] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, koff_a[a] + b * 32, ubase * 2 * p.N * 2, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, koff_a[a] + b * 32 + p.N * 2, ubase * 2 * p.N * 2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, koff_a[a] + b * 32, ubase * 2 * p.N * 2, COH);
+                    __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, koff_a[a] + b * 32 + p.N * 2, ubase * 2 * p.N * 2, COH);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), c_rs, voff_a[a] + b * 64, ubase * ldc * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), c_rs, voff_a[a] + b * 64, ubase * ldc * 4, COH);
                 }
             }
             if constexpr (ST) {
@@ -688,14 +690,24 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
             const int half = t / BN, cc = t - half * BN;
             if (half * 128 >= m_valid || cc < cc_lo || cc >= cc_hi) continue;
             float* o = p.stats + ((long long)(mtile * 2 + half) * p.N + n_blk + cc) * 2;
-            o[0] = stat_lds[((half * 2) * BN + cc) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 0];
-            o[1] = stat_lds[((half * 2) * BN + cc) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 1];
+            const float o0 = stat_lds[((half * 2) * BN + cc) * 2 + 0] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 0];
+            const float o1 = stat_lds[((half * 2) * BN + cc) * 2 + 1] + stat_lds[((half * 2 + 1) * BN + cc) * 2 + 1];
+            if constexpr (COH != 0) {
+                __hip_atomic_store(o, o0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 1, o1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                o[0] = o0;
+                o[1] = o1;
+            }
         }
     }
 }
 
-template <int TW, int IMGS, int BN>
-__global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(const Gemm16Params p) {
+// One output tile (tile_id, split ksplit of SK) of the looped 16x16x32 kernel as a device function: the body of conv3x3_x3m16_kernel, and
+// of the conv items of the chain kernels below (COH = 16: activations through sc1 accesses, the item's dependency wait between its
+// first weight requests and its first halo request).
+template <int TW, int IMGS, int BN, int COH, class WaitFn>
+__device__ __forceinline__ void x3m16_item(const Gemm16Params& p, char* lds, int tile_id, int ksplit, int SK, WaitFn&& wait_deps) {
     constexpr int TH = 256 / (IMGS * TW);
     constexpr int WP = TW + 2, HP = TH + 2;
     constexpr int NPX = IMGS * HP * WP;
@@ -711,7 +723,6 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(co
     constexpr int NS = 4;
     constexpr int NHB = BN == 64 ? 1 : 2;            // halo buffers
     static_assert((BN == 64 ? 4 : 2) * (NHB * HALO_BYTES + NS * B_BYTES) <= 160 * 1024, "blocks per CU");
-    __shared__ __attribute__((aligned(16))) char lds[NHB * HALO_BYTES + NS * B_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -720,16 +731,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(co
     const int nnt = p.N / BN;
     // Split-K (few output tiles - a tracking frame): SK blocks share one output tile, each summing C / SK of the real channels; the
     // one that arrives last adds the fp32 partials in split order (deterministic) and runs the epilogue (as conv3x3_f16.hip).
-    const int SK = p.split_k > 1 ? p.split_k : 1;
-    int mtile, ntile, tile_id, ksplit;
-    {
-        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-        tile_id = L / SK;
-        ksplit = L - tile_id * SK;
-        mtile = tile_id / nnt;
-        ntile = tile_id - mtile * nnt;
-    }
+    const int mtile = tile_id / nnt, ntile = tile_id - mtile * nnt;
     const int n_blk = ntile * BN;
     const int tiles_per_img = p.H / TH;
     const int img0 = IMGS == 2 ? mtile * 2 : mtile / tiles_per_img;
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(co
         const bool ok = hp < NPX && gi < n_img && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         const int cg = (lane & 3) ^ (((hp >> 3) & 1) << 1);
         const f16* src = ok ? p.A + (((long long)gi * p.H + gy) * p.W + gx) * a_cin + vchunk * 32 + cg * 8 : p.zero_page;
-        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(lds + buf * HALO_BYTES + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(lds + buf * HALO_BYTES + q * 1024), 16, 0, COH);
     };
     long long b_base[BJ];
 #pragma unroll
@@ -788,14 +790,25 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(co
     };
 
     if constexpr (BN != 64) {
+    if constexpr (COH != 0) {
+        // chain kernels: the weights of the first three steps do not depend on the producer of this item's input - they are requested
+        // before the item waits for its image(s); the halo follows, and step 0 waits for everything (the counted wait below assumes
+        // the halo pieces were issued first)
+        issue_w(0, 0, 0);
+        issue_w(0, 1, 1);
+        issue_w(0, 2, 2);
+        wait_deps();
+        for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, c0, 0);
+    } else {
     for (int q = wm; q < 24; q += 4) issue_halo_piece(q < NPI ? q : NPI - 1, c0, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
     issue_w(0, 2, 2);
+    }
 
     int c = 0, r = 0, c3 = 0, r3 = 3, h1 = 0, h2 = 0;
     for (int t = 0; t < nt; ++t) {
-        wait_vm(t + 2 >= nt ? 0 : 2 * BJ + h1 + h2);
+        wait_vm((t + 2 >= nt || (COH != 0 && t == 0)) ? 0 : 2 * BJ + h1 + h2);
         RAW_BARRIER();
         if (t + 3 < nt) issue_w(c3, r3, (t + 3) & 3);
         const int hh = (r < 6 || (r >= 18 && r < 24)) ? 1 : 0;
@@ -871,6 +884,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(co
         issue_w(0, 0, 0);
         issue_w(0, 1, 1);
         issue_w(0, 2, 2);
+        if constexpr (COH != 0) wait_deps();     // (chain kernels: the halo of the first phase is requested below, behind the wait)
         int c = 0, r = 0, c3 = 0, r3 = 3;
         for (int t = 0; t < nt; ++t) {
             const bool phase_start = r == 0 || r == 18;
@@ -942,8 +956,241 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(co
             if (++r3 == 27) { r3 = 0; ++c3; }
         }
     }
-    x3m16_tail<TW, IMGS, BN>(p, acc, lds, tid, wm, mtile, n_blk, tile_id, ksplit, SK);
+    x3m16_tail<TW, IMGS, BN, false, COH>(p, acc, lds, tid, wm, mtile, n_blk, tile_id, ksplit, SK);
 }
+
+template <int TW, int IMGS, int BN>
+__global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void conv3x3_x3m16_kernel(const Gemm16Params p) {
+    constexpr int TH = 256 / (IMGS * TW);
+    constexpr int NPI = (IMGS * (TH + 2) * (TW + 2) + 15) / 16;
+    constexpr int NHB = BN == 64 ? 1 : 2;
+    static_assert((BN == 64 ? 4 : 2) * (NHB * NPI * 1024 + 4 * BN * 64) <= 160 * 1024, "blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[NHB * NPI * 1024 + 4 * BN * 64];
+    const int SK = p.split_k > 1 ? p.split_k : 1;
+    int tile_id, ksplit;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        tile_id = L / SK;
+        ksplit = L - tile_id * SK;
+    }
+    x3m16_item<TW, IMGS, BN, 0>(p, lds, tile_id, ksplit, SK, [] {});
+}
+
+#ifdef REID_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------------------------------------
+// Chain kernel: one persistent launch per ResNet layer for a small batch (a tracking frame).  EXPERIMENT BUILDS ONLY (-DREID_EXPERIMENTS, debug
+// switch `chain`): built for layer 4 in round 6, correct at once (4.9e-7 of exact fp32 at 1 / 7 / 30 / 33 crops) and 2.1x SLOWER than the six
+// launches it replaces - 536 us against 255 us at 30 crops (profiles/r06_chain_layer4.txt); DESIGN.md section 8 says why.
+//
+// A 30-crop frame was ~35 launches; every launch is a grid-wide barrier although nothing in the network needs one in eval mode:
+// InstanceNorm and SE are per image (SERes18_IBN.py:32-41,88-93), so conv2 of image i waits for conv1 of image i only.  Here the
+// layer's work - conv tiles (x3m16_item: same tiles, same split-K reduce-scatter), InstanceNorm finishes, SE tails - is ONE ordered list;
+// a block claims the next item with one atomic and waits on the per-image counter of the stage it depends on.  Every item an item can
+// wait for comes EARLIER in the list, so it has been claimed by a block that is already running: forward progress needs no
+// co-residency assumption and there is no grid barrier.  Producer and consumer sit on different XCDs of one launch: activations go
+// through sc1 accesses (COH = 16).  Waits are bounded (fault word bit 2), so a logic error cannot hang the device.
+__device__ __forceinline__ void chain_wait(const int* cnt, int target, int* fault) {
+    int spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1 << 22)) {
+            if (fault) fault[2] = 1;
+            break;
+        }
+    }
+}
+
+__device__ __forceinline__ float chain_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// InstanceNorm finish + [xh | xl'] of the InstanceNorm half of one slice of one image (in_apply_pack_kernel's arithmetic, elementwise.hip)
+__device__ __forceinline__ void chain_in_fin(const ChainElem& e, float* sm, int img, int slice, int tid, int* fault) {
+    float* sa = sm;
+    float* sb = sm + 256;
+    for (int ch = tid; ch < e.half; ch += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = 0; t < e.tiles; ++t) {
+            const float* st = e.stats + (((long long)img * e.tiles + t) * e.c + ch) * 2;
+            s1 += (double)chain_ld(st);
+            s2 += (double)chain_ld(st + 1);
+        }
+        const double mean = s1 / e.hw;
+        double var = s2 / e.hw - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double inv = 1.0 / sqrt(var + 1e-5);
+        sa[ch] = (float)(inv * (double)e.g[ch]);
+        sb[ch] = (float)((double)e.b[ch] - mean * inv * (double)e.g[ch]);
+    }
+    __syncthreads();
+    const int rows = e.hw / e.slices, q = e.half >> 2;
+    const long long pix0 = (long long)img * e.hw + (long long)slice * rows;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(e.x + pix0 * e.c), 0, rows * e.c * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(e.packed + pix0 * 2 * e.c), 0, rows * 2 * e.c * 2, 0x00020000);
+    unsigned vm = 0u;
+    for (int i = tid; i < rows * q; i += 256) {
+        const int row = i / q, cc = i - row * q;
+        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (row * e.c + cc * 4) * 4, 0, 16));
+        const f32x4 a = *(const f32x4*)&sa[cc * 4], b = *(const f32x4*)&sb[cc * 4];
+        v = v * a + b;
+        vm = range_acc(range_acc(range_acc(range_acc(vm, v[0]), v[1]), v[2]), v[3]);
+        u32x2 hw, lw;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float v0 = fmaxf(v[2 * h], 0.f), v1 = fmaxf(v[2 * h + 1], 0.f);
+            const f16 h0 = (f16)v0, h1 = (f16)v1;
+            const f16 l0 = (f16)((v0 - (float)h0) * 2048.0f), l1 = (f16)((v1 - (float)h1) * 2048.0f);
+            hw[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lw[h] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, (row * 2 * e.c + cc * 4) * 2, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, (row * 2 * e.c + e.c + cc * 4) * 2, 0, 16);
+    }
+    range_raise(fault, vm);
+}
+
+// SE gate of one image + out = relu(gate * y + shortcut) over one slice of it (se_tail_kernel's arithmetic, elementwise.hip)
+__device__ __forceinline__ void chain_se(const ChainElem& e, float* sm, int img, int slice, int tid, int* fault) {
+    float* pooled = sm;            // [512]
+    float* gate = sm + 512;        // [512]
+    float* hid = sm + 1024;        // [64]
+    const int lane = tid & 63, wave = tid >> 6, c = e.c, c4v = c >> 2;
+    for (int ch = tid; ch < c; ch += 256) {
+        double acc = 0.0;
+        for (int t = 0; t < e.tiles; ++t) acc += (double)chain_ld(e.stats + (((long long)img * e.tiles + t) * c + ch) * 2);
+        pooled[ch] = (float)(acc / e.hw);
+    }
+    __syncthreads();
+    for (int m = wave; m < e.mid; m += 4) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c4 = lane + 64 * k;
+            if (c4 < c4v) {
+                const f32x4 wv = *(const f32x4*)(e.g + (long long)m * c + c4 * 4), pv = *(const f32x4*)(pooled + c4 * 4);
+                acc += wv[0] * pv[0] + wv[1] * pv[1] + wv[2] * pv[2] + wv[3] * pv[3];
+            }
+        }
+        acc = wsum64(acc);
+        if (lane == 0) hid[m] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 256) {
+        float acc = 0.f;
+        for (int m = 0; m < e.mid; ++m) acc += e.b[m * c + ch] * hid[m];
+        gate[ch] = 1.0f / (1.0f + expf(-acc));
+    }
+    __syncthreads();
+    const int rows = e.hw / e.slices;
+    const long long pix0 = (long long)img * e.hw + (long long)slice * rows;
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(e.x + pix0 * c), 0, rows * c * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t s_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(e.sc + pix0 * c), 0, rows * c * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((e.out ? e.out : (float*)e.x) + pix0 * c), 0, rows * c * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t k_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((e.packed ? e.packed : (f16*)e.x) + pix0 * 2 * c), 0, rows * 2 * c * 2, 0x00020000);
+    unsigned vm = 0u;
+    for (int i = tid; i < rows * c4v; i += 256) {
+        const int row = i / c4v, cc = i - row * c4v;
+        const f32x4 yy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(y_rs, (row * c + cc * 4) * 4, 0, 16));
+        const f32x4 rr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s_rs, (row * c + cc * 4) * 4, 0, 16));
+        const f32x4 ss = *(const f32x4*)&gate[cc * 4];
+        f32x4 o = ss * yy + rr;
+        if (e.packed) vm = range_acc(range_acc(range_acc(range_acc(vm, o[0]), o[1]), o[2]), o[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+        if (e.out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), o_rs, (row * c + cc * 4) * 4, 0, 16);
+        if (e.packed) {
+            u32x2 hw, lw;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float v0 = o[2 * h], v1 = o[2 * h + 1];
+                const f16 h0 = (f16)v0, h1 = (f16)v1;
+                const f16 l0 = (f16)((v0 - (float)h0) * 2048.0f), l1 = (f16)((v1 - (float)h1) * 2048.0f);
+                hw[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                lw[h] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(hw, k_rs, (row * 2 * c + cc * 4) * 2, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b64(lw, k_rs, (row * 2 * c + c + cc * 4) * 2, 0, 16);
+        }
+    }
+    range_raise(fault, vm);
+}
+
+template <int TW, int IMGS, int BN>
+__global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void chain_kernel(const ChainParams cp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TH = 256 / (IMGS * TW);
+    constexpr int NPI = (IMGS * (TH + 2) * (TW + 2) + 15) / 16;
+    constexpr int NHB = BN == 64 ? 1 : 2;
+    constexpr int LDS_BYTES = NHB * NPI * 1024 + 4 * BN * 64;
+    static_assert(LDS_BYTES >= 1088 * 4, "the elementwise items keep up to 1088 floats in LDS");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    __shared__ int s_item;
+    const int tid = threadIdx.x;
+    int* const done = cp.counters + 64;
+    for (;;) {
+        if (tid == 0) s_item = __hip_atomic_fetch_add(cp.counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int item = s_item;
+        __syncthreads();                 // (everybody has read the ticket - and has left the previous item's LDS - before either is reused)
+        if (item >= cp.total_items) break;
+        int s = 0;
+        while (s + 1 < cp.n_stages && item >= cp.st[s + 1].first) ++s;
+        const ChainStage st = cp.st[s];
+        const int li = item - st.first;
+        int img_lo, img_hi;              // the images this item reads and finishes: [img_lo, img_hi)
+        if (st.kind == 0) {
+            const Gemm16Params& p = cp.conv[st.idx];
+            const int nnt = p.N / BN;
+            const int tile_id = li / st.sk, ksplit = li - tile_id * st.sk, mtile = tile_id / nnt;
+            if (IMGS == 2) {
+                img_lo = 2 * mtile;
+                img_hi = img_lo + 2 < cp.n_img ? img_lo + 2 : cp.n_img;
+            } else {
+                img_lo = mtile / (p.H / TH);
+                img_hi = img_lo + 1;
+            }
+            auto wait = [&] {
+                if (st.dep >= 0) {
+                    if (tid == 0)
+                        for (int i = img_lo; i < img_hi; ++i) chain_wait(done + st.dep * 64 + i, st.target, cp.fault);
+                    __syncthreads();
+                }
+            };
+            if (cp.flags & 4) x3m16_item<TW, IMGS, BN, 0>(p, lds, tile_id, ksplit, st.sk, [] {});      // timing experiment (WRONG results): plain loads, no waits
+            else x3m16_item<TW, IMGS, BN, 16>(p, lds, tile_id, ksplit, st.sk, wait);
+        } else {
+            const ChainElem& e = cp.el[st.idx];
+            img_lo = li / e.slices;
+            img_hi = img_lo + 1;
+            if (st.dep >= 0) {
+                if (tid == 0) chain_wait(done + st.dep * 64 + img_lo, st.target, cp.fault);
+                __syncthreads();
+            }
+            if (st.kind == 1) chain_in_fin(e, (float*)lds, img_lo, li - img_lo * e.slices, tid, cp.fault);
+            else chain_se(e, (float*)lds, img_lo, li - img_lo * e.slices, tid, cp.fault);
+        }
+        // the item's stores (sc1: written through) have been acknowledged once vmcnt reaches 0; then its images' counters move
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            for (int i = img_lo; i < img_hi; ++i) __hip_atomic_fetch_add(done + s * 64 + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {      // the last block to leave resets the list for the next launch (stream order: nothing else is in flight then)
+        const int old = __hip_atomic_fetch_add(cp.counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (int)gridDim.x - 1) {
+            for (int i = 0; i < 64 + 8 * 64; ++i) __hip_atomic_store(cp.counters + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#endif
+}
+
+#endif   // REID_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // The 128-wide form with the chunk's 27 tiles UNROLLED.  Why: PMC of conv3x3_x3m16_kernel<8,2,128> (profiles/r05_pmc_waits.txt): matrix
@@ -1481,6 +1728,17 @@ int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p0) {
     LAUNCH_CHECK();
     return REID_OK;
 }
+
+#ifdef REID_EXPERIMENTS
+// ---- chain kernel launcher: W = width of the layer's maps (8: layers 3-4 as image pairs, 128-wide tiles)
+int launch_chain(reid_ctx* ctx, const ChainParams& cp, int W) {
+    ARG_CHECK(cp.n_img >= 1 && cp.n_img <= 64 && cp.n_stages >= 1 && cp.n_stages <= 8 && cp.counters && W == 8);
+    const int blocks = cp.total_items < 512 ? cp.total_items : 512;          // two per CU
+    hipLaunchKernelGGL((chain_kernel<8, 2, 128>), dim3(blocks), dim3(256), 0, ctx->stream, cp);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
+#endif
 
 // ---- dense form (Swin linears, fp32-class mode): launched for EVERY batch size of a layer it supports - which arithmetic a layer runs
 // in must not depend on how many images a pass holds

@@ -379,6 +379,8 @@ struct reid_ctx {
                              // v_mfma_f32_16x16x32_f16, two blocks per CU for the 128-wide tiles (layers 2-4) and FOUR for the 64-wide ones
                              // (layer 1); 2 = the 128-wide tiles only; 1 = the first form on 32x32x16; 0 = off
     int split_gemm_min_tiles = 128;   // precision 2: strided / 1x1 convolutions take the SPLIT build of gemm_f16.hip from this many 256 x 128 tiles on (below: the exact-fp32 split-K kernel)
+    int chain = 0;           // EXPERIMENTS=1 builds only: precision 2, batches of up to 64 crops, layer 4 as ONE chain launch (conv3x3_x3.hip chain_kernel;
+                             // 536 us against 255 us for the six launches it replaces: DESIGN.md section 8); bit 2 = timing variant (wrong results)
     int x3_sk_cap = 0;       // experiments: upper bound of the split-K factor of conv3x3_x3.hip's small launches (0 = the heuristic's)
     int split_x3_small = 2;  // ... and smaller launches: 2 (default) = where they measured faster than conv3x3_f16.hip's 12-wave kernel (conv3x3_x3_supported),
                              // 1 = every launch, 0 = none; K split over up to 8 blocks per tile (x3m16_tail: reduce-scatter)
@@ -471,6 +473,36 @@ inline std::string split_range_violation(const float* blob, const std::map<std::
     }
     return std::string();
 }
+
+// ---- chain kernels (conv3x3_x3.hip, round 6): ONE persistent launch runs all the 3x3 stride-1 convolutions, InstanceNorm finishes
+// and SE tails of a ResNet layer for a small batch.  Work items are claimed in list order with one atomic; an item waits only for
+// counters of ITS OWN image(s) (crops are independent in eval mode: SERes18_IBN.py:32-41,88-93,120-128), never for a grid barrier.
+struct ChainElem {             // an InstanceNorm finish + pack (kind 1) or an SE gate + tail (kind 2) over the images of the batch
+    const float* x;            // kind 1: conv1 output fp32 [n][hw][c] (InstanceNorm half raw); kind 2: conv2 output y fp32
+    const float* stats;        // per-128-row column sums [n * tiles][c][2] of the producing convolution
+    const float* sc;           // kind 2: shortcut fp32 [n][hw][c]
+    const float *g, *b;        // kind 1: IN gamma / beta [half]; kind 2: SE fc1 [mid][c] / fc2^T [mid][c]
+    float* out;                // kind 2: block output fp32 (may be null)
+    _Float16* packed;          // [n][hw][2c] as [xh | xl'] (kind 1: the InstanceNorm half's columns only; kind 2: may be null)
+    int c, half, hw, tiles, mid, slices;
+};
+struct ChainStage {
+    int kind;                  // 0 convolution, 1 InstanceNorm finish + pack, 2 SE tail
+    int idx;                   // index into ChainParams::conv / ::el
+    int first, items;          // range of the stage in the item list
+    int dep;                   // stage this one waits for (per image), -1: its input was ready at launch
+    int target;                // ... until that stage's counter of the image has reached this
+    int sk;                    // convolution: blocks per output tile
+};
+struct ChainParams {
+    int n_img, n_stages, total_items, flags;
+    ChainStage st[8];
+    Gemm16Params conv[4];
+    ChainElem el[4];
+    int* counters;             // [0] next item, [1] blocks that have left, [64 + stage * 64 + image] items of the stage finished for the image
+    int* fault;
+};
+int launch_chain(reid_ctx* ctx, const ChainParams& cp, int W);      // conv3x3_x3.hip
 
 // convolution launchers of the two arithmetic modes (api.hip); also used by the experiment harnesses in debug.hip
 int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int Cin, const float* wgt, int Cout, int R,
