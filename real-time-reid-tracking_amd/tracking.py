@@ -135,6 +135,85 @@ class MultiCameraStream:
                 self.eng.close()
 
 
+class LookaheadCameraStream:
+    """ONE camera stream whose detections are known F frames ahead - a video file or a detection dump (BASELINE configs[3] is one;
+    `track_yolov5.py:178-253` reads its frames from a file and could run its detector a frame ahead): the crops of F consecutive
+    frames go through the network as ONE pass, everything that depends on the tracker's state stays per frame and in order -
+    frame j's costs are computed against the bank as frame j - 1's `commit` left it (`reid_frame_cost_groups` with one group per
+    frame, only frame j's carrying tracks), so features, costs and bank contents are those of the frame-by-frame stream up to the
+    pass-size effect on a crop's embedding (fp32 summation order).  The price is latency: a frame's features exist once the F-th
+    frame of its group has been detected.  `CameraStream` (F = 1) remains the strict real-time form; this is the throughput form.
+
+        s.submit_group([crops_f, crops_f+1, ...])                      # F lists of crops
+        for j in range(F):
+            feats, cost, iou = s.step(j, targets, track_boxes, det_boxes_of_frame_j, next_group=... if j == F - 1 else None)
+            s.commit(j, rows, targets, active_targets)
+    """
+
+    def __init__(self, weights_blob, manifest, frames_per_pass=2, precision=0, max_dist=0.15, budget=100, metric="cosine", device=0,
+                 own_context=True, max_tracks=4096):
+        self._own = bool(own_context)
+        self.eng = Engine(device) if own_context else get_engine(device)
+        self.eng.load_seres18(weights_blob, manifest)
+        self.eng.set_precision(precision)
+        self.max_dist = max_dist
+        self.frames_per_pass = int(frames_per_pass)
+        self.metric = NearestNeighborDistanceMetric(metric, max_dist, budget, max_tracks=max_tracks, engine=self.eng)
+        self._group = 0
+        self._m = {}
+
+    def _submit(self, slot, group):
+        if not 1 <= len(group) <= self.frames_per_pass:
+            raise ValueError("a group holds 1..%d frames, got %d" % (self.frames_per_pass, len(group)))
+        self._m[slot] = [len(c) for c in group]
+        self.eng.frame_submit(slot, [c for fr in group for c in fr])
+
+    def submit_group(self, group):
+        """Queue upload + embedding of the FIRST group of frames (a list of crop lists); later groups ride on the step of the current
+        group's LAST frame (`next_group=`): the stream then holds cost(last) | forward(next group) | update(last) and the device embeds
+        the next group under the host's assignment of that frame (handed over earlier, the next group's forward would sit in the
+        stream in front of the remaining frames' cost stages; moving those stages to a stream of their own was tried and changed
+        nothing: 1.46 k frames/s either way at four frames per pass)."""
+        self._submit(self._group & 1, group)
+
+    def step(self, j, targets, track_boxes, det_boxes, next_group=None):
+        """Frame j of the submitted group: (features[m_j,512], appearance_cost[t,m_j] gated at max_dist, iou_cost[t,m_j] | None) against
+        the confirmed tracks as the previous frame's commit left the bank."""
+        slot = self._group & 1
+        ms = self._m[slot]
+        self.metric._ensure(512)
+        tg = list(targets)
+        slots = self.metric._slots_for(tg, False) if tg else np.empty(0, np.int32)
+        boxes = track_boxes is not None and det_boxes is not None
+        groups = []
+        for f, m in enumerate(ms):
+            mine = f == j
+            groups.append((self.metric._bank, slots if mine else np.empty(0, np.int32),
+                           (track_boxes if mine else np.empty((0, 4))) if boxes else None,
+                           (det_boxes if mine else np.zeros((m, 4))) if boxes else None, m))
+        self.eng.frame_cost_groups(slot, groups, self.metric._metric, self.max_dist)
+        if next_group is not None:
+            self._submit(slot ^ 1, next_group)
+        emb, costs, ious = self.eng.frame_fetch_groups(slot)
+        off = sum(ms[:j])
+        cost = costs[j] if costs[j] is not None else np.zeros((len(tg), ms[j]), np.float32)
+        return emb[off:off + ms[j]], cost.astype(np.float64), ious[j]
+
+    def commit(self, j, rows, targets, active_targets):
+        """partial_fit from frame j's rows of the group; after the group's last frame the stream moves on to the next group."""
+        slot = self._group & 1
+        self.metric.frame_partial_fit(slot, np.asarray(rows, np.int32) + sum(self._m[slot][:j]), targets, active_targets)
+        if j == len(self._m[slot]) - 1:
+            self._group += 1
+
+    def close(self, destroy=False):
+        self.eng.sync()
+        if destroy:
+            self.metric.close()
+            if self._own:
+                self.eng.close()
+
+
 class ShardedCameraStream:
     """One camera stream whose frames are dealt over the ranks of a multi-GPU job (BASELINE configs[3]):
     every rank embeds its round-robin share of a frame's crops (`parallel.round_robin`), ONE device-side all-gather per frame

@@ -1097,6 +1097,51 @@ def test_multi_camera_batched_stream_equals_independent_camera_streams(eng_w0, p
 
 
 @pytest.mark.parametrize("precision", [0, 2])
+def test_lookahead_stream_equals_the_frame_by_frame_stream(eng_w0, precision):
+    """tracking.LookaheadCameraStream - F consecutive frames of ONE camera embedded as one pass, costs and bank updates per frame and
+    in order - against `CameraStream` on the same detection dump: features and gated costs equal to fp32 summation order (a crop's
+    embedding depends on the pass size through tile shapes only), DIoU bit for bit, bank sample counts equal; groups of 3 frames,
+    the last group short, frames without detections."""
+    from reid_amd.tracking import CameraStream, LookaheadCameraStream
+    eng, sd = eng_w0
+    blob, manifest = weights.pack_seres18(sd)[:2]
+    rng = np.random.default_rng(23)
+    pool = synth.ragged_crops_u8(48, seed=14)
+    counts = [6, 0, 9, 4, 11, 2, 5, 7]                       # 8 frames -> groups of 3, 3, 2
+    crops = lambda f: [pool[(7 * f + i) % 48] for i in range(counts[f])]
+    tracks = list(range(5))
+    boxes = rng.uniform(0, 300, (16, 4))
+    boxes[:, 2:] = rng.uniform(10, 90, (16, 2))
+    seeds = rng.normal(size=(15, 512)).astype(np.float32)
+    la = LookaheadCameraStream(blob, manifest, 3, precision)
+    one = CameraStream(blob, manifest, precision)
+    try:
+        for obj in (la.metric, one.metric):
+            obj.partial_fit(seeds, np.repeat(tracks, 3), tracks)
+        groups = [[0, 1, 2], [3, 4, 5], [6, 7]]
+        la.submit_group([crops(f) for f in groups[0]])
+        one.submit(crops(0))
+        for gi, g in enumerate(groups):
+            for j, f in enumerate(g):
+                nxt = [crops(x) for x in groups[gi + 1]] if (j == len(g) - 1 and gi + 1 < len(groups)) else None
+                gf, gc, gi_ = la.step(j, tracks, boxes[:5], boxes[:counts[f]], nxt)
+                feats, cost, iou = one.step(tracks, boxes[:5], boxes[:counts[f]], crops(f + 1) if f + 1 < len(counts) else None)
+                assert gf.shape == (counts[f], 512) and gc.shape == (5, counts[f])
+                if counts[f]:
+                    assert np.abs(gf - feats).max() <= 2e-5 * np.abs(feats).max()
+                    np.testing.assert_allclose(gc, cost, atol=2e-5)
+                    assert np.array_equal(gi_, iou)
+                k = min(counts[f], 5)
+                la.commit(j, np.arange(k), tracks[:k], tracks)
+                one.commit(np.arange(k), tracks[:k], tracks)
+        for t in tracks:
+            assert la.metric.samples_count(t) == one.metric.samples_count(t)
+    finally:
+        la.close(destroy=True)
+        one.close(destroy=True)
+
+
+@pytest.mark.parametrize("precision", [0, 2])
 def test_host_entry_points_pipeline_passes_bit_identically(eng_w0, precision):
     """Host in -> host out, the reference's own shape (feature_extractor.py:48-53 `.to(device)` ... `.cpu().numpy()`,
     image_reid_inference.py:116-122): with more crops than one pass holds the entry points upload pass k + 1 and download pass
