@@ -604,7 +604,7 @@ static bool conv_split_path(reid_ctx* ctx, int n, int H, int W, int Cin, int Cou
     q.Wo = (W + 2 * pad - S) / stride + 1;
     q.M = n * q.Ho * q.Wo; q.N = Cout;
     const bool halo = R == 3 && S == 3 && stride == 1 && pad == 1 && conv3x3_f16_supported(q);
-    const bool enough = halo || (Cout % 128 == 0 && (long long)(q.M / 256) * (Cout / 128) >= ctx->split_gemm_min_tiles);
+    const bool enough = halo || (Cout % 128 == 0 && (long long)(q.M / 256) * (Cout / 128) >= (R == 3 ? ctx->split_gemm_min_tiles * 3 / 4 : ctx->split_gemm_min_tiles));   // (layer 3's strided 3x3 at 120 crops: 107 -> 70 us; at 64 crops 49 against 67: stays)
     return q.M % 128 == 0 && enough;
 }
 

@@ -414,11 +414,20 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
         constexpr int PART_B = 256 * BN * 4;       // bytes of one partial tile
         char* part = (char*)(p.splitk_ws + (long long)tile_id * SK * (256 * BN));
         const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, SK * PART_B, 0x00020000);
+        // ... except the units of this block's OWN column slice: nobody else reads them, so they wait in LDS (the main loop's buffers are free;
+        // behind the 4 KB of the column sums) instead of making the round trip through memory - a quarter of the partial traffic at SK = 4,
+        // half of it at SK = 2.  A lane reads back exactly what it wrote: no barrier.
+        const int nb_own = TN / SK;
+        const unsigned own32 = (unsigned)(uintptr_t)lds + 4096u + (unsigned)tid * 16u;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[a][b]), w_rs, tid * 16, ksplit * PART_B + (a * TN + b) * 4096, 16 /* sc1 */);
+            for (int b = 0; b < TN; ++b) {
+                if (b / nb_own == ksplit)
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(own32 + (unsigned)((a * nb_own + (b - ksplit * nb_own)) * 4096)), "v"(acc[a][b]) : "memory");
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[a][b]), w_rs, tid * 16, ksplit * PART_B + (a * TN + b) * 4096, 16 /* sc1 */);
+            }
         // sc1 stores are written through to the point all XCDs share, sc1 loads bypass this XCD's L2 (conv3x3_f16.hip: no L2 write-back /
         // invalidate fence); acknowledged once vmcnt reaches 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -573,11 +582,20 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
             f32x4 v[TM];
             {
                 u32x4 ld[SKC][TM];
+                const unsigned own32 = (unsigned)(uintptr_t)lds + 4096u + (unsigned)tid * 16u;
 #pragma unroll
                 for (int sidx = 0; sidx < SKC; ++sidx)
 #pragma unroll
-                    for (int a = 0; a < TM; ++a)
-                        ld[sidx][a] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, tid * 16, sidx * PART_B + (a * TN + b) * 4096, 16 /* sc1 */);
+                    for (int a = 0; a < TM; ++a) {
+                        if (sidx == ksplit) {     // this block's own partial of the unit: parked in LDS above
+                            f32x4 t;
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(own32 + (unsigned)((a * NB + bi) * 4096)) : "memory");
+                            ld[sidx][a] = __builtin_bit_cast(u32x4, t);
+                        } else {
+                            ld[sidx][a] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, tid * 16, sidx * PART_B + (a * TN + b) * 4096, 16 /* sc1 */);
+                        }
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the inline ds_read is not counted by the compiler)
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     v[a] = __builtin_bit_cast(f32x4, ld[0][a]);
