@@ -1530,19 +1530,24 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(lds + slot * A_SLOT + (wm * 4 + j) * 1024), 16, av[j], soff, 0, 0);
     };
-    auto issue_w = [&](int c, int r, int slot) __attribute__((always_inline)) {  // step r of chunk c: weight parts 0, 2, 1
+    // Round 6: wh is streamed ONCE per chunk.  The rows [wh 2^11 | wh | wl'] of the weight image serve three products per real chunk -
+    // xh.(wh 2^11), xh.wl', xl'.wh - and the first and third want the same 16 bits up to an exponent: the wh fragments stay in registers
+    // from step 0 to step 2 and step 0 multiplies them by 2^11 on the way into its MFMAs (v_pk_mul_f16, exact: the load-time range check
+    // guarantees |w| 2^11 inside f16, and the stored [wh 2^11] third IS f16(wh) 2^11).  Two weight tiles per chunk instead of three (4 rows
+    // per 32 channels instead of 5: -14 % of the LDS-DMA bytes this kernel is bound by, -8 of 24 fragment reads); same three MFMAs per
+    // accumulator in the same order: bit-identical results.
+    auto issue_w = [&](int c, int kind, int slot) __attribute__((always_inline)) {  // kind 0: the wh tile of chunk c, 1: the wl' tile
         if ((abl & 1) && c > 0) return;
-        const int part = r == 0 ? 0 : r == 1 ? 2 : 1;
+        const int part = kind == 0 ? 1 : 2;
         const int soff = part * Kr * 2 + c * 64;
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, LPTR(lds + 3 * A_SLOT + slot * B_SLOT + (wm * BJ + j) * 1024), 16, wv[j], soff, 0, 0);
     };
-    // prologue = the requests of steps -3, -2, -1
+    // prologue = chunk 0's requests in the order every later chunk's are made: wh, h, wl', l
     issue_w(0, 0, 0);
     issue_a(0, 0);
     issue_w(0, 1, 1);
-    issue_w(0, 2, 2);
     issue_a(1, 1);
 
     const int pj = pi16(l16);
@@ -1557,54 +1562,58 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    half8 fa[TM], fb[TN];
+    half8 fa[TM], fb[TN], fw[TN];                 // fw: the chunk's wh fragments, alive from step 0 to step 2
     int sa_h = 0, sa_l = 1;                       // A slots of this chunk's parts: (2 c) % 3, (2 c + 1) % 3
+    const half8 k2048 = {(f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f};
     for (int c = 0; c < ncr; ++c) {
         const bool last = c + 1 == ncr;
-        const int s0 = c * 3;
+        const int s0 = c * 2;                     // weight tiles 2 c (wh) and 2 c + 1 (wl') in ring slots (tile & 3)
 #define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fb[b]), "v"(fa[a]))   /* weights first: D^T (x3m16_tail) */
-#define LIN_B_READS(ba)                                   \
-    LDS_READ(fb[0], ba, 0);     LDS_READ(fb[1], ba, 1024); \
-    LDS_READ(fb[2], ba, 2048);  LDS_READ(fb[3], ba, 3072); \
-    LDS_READ(fb[4], ba, 4096);  LDS_READ(fb[5], ba, 5120); \
-    LDS_READ(fb[6], ba, 6144);  LDS_READ(fb[7], ba, 7168)
-#define LIN_MM_ALL(a)                \
-    _Pragma("unroll") for (int b = 0; b < TN; ++b) MMA(a, b)
+#define MMAW(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fw[b]), "v"(fa[a]))
+#define LIN_B_READS(f, ba)                              \
+    LDS_READ(f[0], ba, 0);     LDS_READ(f[1], ba, 1024); \
+    LDS_READ(f[2], ba, 2048);  LDS_READ(f[3], ba, 3072); \
+    LDS_READ(f[4], ba, 4096);  LDS_READ(f[5], ba, 5120); \
+    LDS_READ(f[6], ba, 6144);  LDS_READ(f[7], ba, 7168)
         static_assert(TN == 8, "fragment reads below are written for the 128-wide tile");
-        {   // ---- r = 0: xh . wh 2^11
-            wait_vm_imm<(BJ + 4) + BJ>();        // in flight at most: the pieces of steps s - 1 (weights + an A part) and s - 2 (weights)
+        // Requests of a chunk, in order: [wh(c+1) + h(c+1)] at step 0, [wl'(c+1)] at step 1, [l(c+1)] at step 2.  In-order landing: a
+        // step waits until at most the requests made AFTER the ones it needs are in flight.
+        {   // ---- step 0: xh . (wh 2^11); needs wh(c), h(c); behind them: wl'(c) [BJ], l(c) [4]
+            wait_vm_imm<BJ + 4>();
             RAW_BARRIER();
             if (!last) {
-                issue_w(c + 1, 0, (s0 + 3) & 3);
+                issue_w(c + 1, 0, (s0 + 2) & 3);
                 issue_a(2 * c + 2, sa_h == 0 ? 2 : sa_h - 1);     // h(c + 1) -> slot (2 c + 2) % 3 = (sa_h + 2) % 3
             }
             const unsigned ao = (unsigned)(sa_h * A_SLOT), ba = bx + (unsigned)((s0 & 3) * B_SLOT);
             if (!(abl & 4)) {
                 LDS_READ(fa[0], aa[0] + ao, 0);
-                LIN_B_READS(ba);
                 LDS_READ(fa[1], aa[1] + ao, 0);
                 LDS_READ(fa[2], aa[2] + ao, 0);
                 LDS_READ(fa[3], aa[3] + ao, 0);
+                LIN_B_READS(fw, ba);
             }
-            lgkm_wait1<11>(fa[0]);
-            lgkm_wait1<10>(fb[0]); MMA(0, 0);
-            lgkm_wait1<9>(fb[1]);  MMA(0, 1);
-            lgkm_wait1<8>(fb[2]);  MMA(0, 2);
-            lgkm_wait1<7>(fb[3]);  MMA(0, 3);
-            lgkm_wait1<6>(fb[4]);  MMA(0, 4);
-            lgkm_wait1<5>(fb[5]);  MMA(0, 5);
-            lgkm_wait1<4>(fb[6]);  MMA(0, 6);
-            lgkm_wait1<3>(fb[7]);  MMA(0, 7);
-            lgkm_wait1<2>(fa[1]);  LIN_MM_ALL(1);
-            lgkm_wait1<1>(fa[2]);  LIN_MM_ALL(2);
-            lgkm_wait1<0>(fa[3]);  LIN_MM_ALL(3);
+            // column unit by column unit: the scaled copy of a wh fragment lives in fb[b] for its four MFMAs only
+#define STEP0(b, n)                                                                  \
+    do {                                                                             \
+        lgkm_wait1<n>(fw[b]);                                                        \
+        fb[b] = fw[b] * k2048;                                                       \
+        /* the MFMAs are inline asm: hipcc does not see that they read what the v_pk_mul above has just written (VALU write -> MFMA */ \
+        /* operand read needs wait states; without them the MFMAs took stale registers: inf / NaN) */ \
+        asm volatile("s_nop 3" : "+v"(fb[b]));                                       \
+        MMA(0, b); MMA(1, b); MMA(2, b); MMA(3, b);                                  \
+    } while (0)
+            lgkm_wait1<8>(fa[3]);                 // (reads return in order: the four A fragments are in)
+            asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]));
+            STEP0(0, 7); STEP0(1, 6); STEP0(2, 5); STEP0(3, 4); STEP0(4, 3); STEP0(5, 2); STEP0(6, 1); STEP0(7, 0);
+#undef STEP0
         }
-        {   // ---- r = 1: xh . wl' (the xh fragments are in registers)
-            if (last) wait_vm_imm<BJ + 4>(); else wait_vm_imm<2 * (BJ + 4)>();
+        {   // ---- step 1: xh . wl' (the xh fragments are in registers); needs wl'(c); behind it: l(c) [4], wh(c+1) + h(c+1) [BJ + 4]
+            if (last) wait_vm_imm<4>(); else wait_vm_imm<BJ + 8>();
             RAW_BARRIER();
-            if (!last) issue_w(c + 1, 1, (s0 + 4) & 3);
+            if (!last) issue_w(c + 1, 1, (s0 + 3) & 3);
             const unsigned ba = bx + (unsigned)(((s0 + 1) & 3) * B_SLOT);
-            if (!(abl & 4)) { LIN_B_READS(ba); }
+            if (!(abl & 4)) { LIN_B_READS(fb, ba); }
             lgkm_wait1<7>(fb[0]); MMA(0, 0);
             lgkm_wait1<6>(fb[1]); MMA(0, 1);
             lgkm_wait1<5>(fb[2]); MMA(0, 2);
@@ -1613,40 +1622,39 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
             lgkm_wait1<2>(fb[5]); MMA(0, 5);
             lgkm_wait1<1>(fb[6]); MMA(0, 6);
             lgkm_wait1<0>(fb[7]); MMA(0, 7);
-            LIN_MM_ALL(1);
-            LIN_MM_ALL(2);
-            LIN_MM_ALL(3);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(1, b);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(2, b);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(3, b);
         }
-        {   // ---- r = 2: xl' . wh
-            if (last) wait_vm_imm<0>(); else wait_vm_imm<BJ + BJ + 4>();
+        {   // ---- step 2: xl' . wh (the wh fragments are in registers); needs l(c); behind it: wh(c+1) + h(c+1) [BJ + 4], wl'(c+1) [BJ]
+            if (last) wait_vm_imm<0>(); else wait_vm_imm<2 * BJ + 4>();
             RAW_BARRIER();
-            if (!last) {
-                issue_w(c + 1, 2, (s0 + 5) & 3);
-                issue_a(2 * c + 3, sa_h);                          // l(c + 1) -> slot (2 c + 3) % 3 = the slot h(c) just left
-            }
-            const unsigned ao = (unsigned)(sa_l * A_SLOT), ba = bx + (unsigned)(((s0 + 2) & 3) * B_SLOT);
+            if (!last) issue_a(2 * c + 3, sa_h);                   // l(c + 1) -> slot (2 c + 3) % 3 = the slot h(c) just left
+            const unsigned ao = (unsigned)(sa_l * A_SLOT);
             if (!(abl & 4)) {
                 LDS_READ(fa[0], aa[0] + ao, 0);
-                LIN_B_READS(ba);
                 LDS_READ(fa[1], aa[1] + ao, 0);
                 LDS_READ(fa[2], aa[2] + ao, 0);
                 LDS_READ(fa[3], aa[3] + ao, 0);
             }
-            lgkm_wait1<11>(fa[0]);
-            lgkm_wait1<10>(fb[0]); MMA(0, 0);
-            lgkm_wait1<9>(fb[1]);  MMA(0, 1);
-            lgkm_wait1<8>(fb[2]);  MMA(0, 2);
-            lgkm_wait1<7>(fb[3]);  MMA(0, 3);
-            lgkm_wait1<6>(fb[4]);  MMA(0, 4);
-            lgkm_wait1<5>(fb[5]);  MMA(0, 5);
-            lgkm_wait1<4>(fb[6]);  MMA(0, 6);
-            lgkm_wait1<3>(fb[7]);  MMA(0, 7);
-            lgkm_wait1<2>(fa[1]);  LIN_MM_ALL(1);
-            lgkm_wait1<1>(fa[2]);  LIN_MM_ALL(2);
-            lgkm_wait1<0>(fa[3]);  LIN_MM_ALL(3);
+            lgkm_wait1<3>(fa[0]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMAW(0, b);
+            lgkm_wait1<2>(fa[1]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMAW(1, b);
+            lgkm_wait1<1>(fa[2]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMAW(2, b);
+            lgkm_wait1<0>(fa[3]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMAW(3, b);
         }
-#undef LIN_MM_ALL
 #undef LIN_B_READS
+#undef MMAW
 #undef MMA
         // next chunk: h -> (2 c + 2) % 3, l -> (2 c + 3) % 3
         const int nh = sa_h == 0 ? 2 : sa_h - 1;
