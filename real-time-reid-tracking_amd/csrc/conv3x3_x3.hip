@@ -398,6 +398,19 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
     const int l16 = lane & 15, lq = lane >> 4;
     const int pj = pi16(l16);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (inline asm: hipcc does not count their wait states)
+    // ... and nothing tied those wait states to the ACCUMULATORS: to the compiler acc[][] is ready the moment the last MFMA statement ends, so
+    // a read of it may be scheduled in front of the s_nops (a "memory" clobber orders memory, not registers).  asm volatile statements keep
+    // their order among themselves, so an empty one that names every accumulator as in / out pins all later reads behind the wait states.
+    // (Round 5 saw "wrong sums" when the epilogue body was a nested generic lambda and reshaped the code until they went away - the
+    // likeliest cause is exactly such a hoisted read; round 6 met the mirror case, a v_pk_mul feeding an inline-asm MFMA without wait
+    // states in lin_x3_kernel: stale operands.  Both directions are now explicit.)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        if constexpr (TN == 8)
+            asm volatile("" : "+v"(acc[a][0]), "+v"(acc[a][1]), "+v"(acc[a][2]), "+v"(acc[a][3]), "+v"(acc[a][4]), "+v"(acc[a][5]), "+v"(acc[a][6]), "+v"(acc[a][7]));
+        else
+            asm volatile("" : "+v"(acc[a][0]), "+v"(acc[a][1]), "+v"(acc[a][2]), "+v"(acc[a][3]));
+    }
     __syncthreads();
 
     // Split-K (few output tiles: a tracking frame, a pass of a few camera frames) as a REDUCE-SCATTER.  Round 5's form - every block
