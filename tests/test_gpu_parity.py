@@ -1041,6 +1041,34 @@ def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, c
                                     % (unexpected, [float(gap[r]) for r in unexpected]))
 
 
+@pytest.mark.parametrize("n", [1, 3, 7, 30, 33, 48])
+def test_small_pass_split_k_forms_agree_and_are_position_invariant(eng_w0, n):
+    """Round 6: small and mid-size passes run layer 4 (from 24 crops), layer 3 (from ~48) and large-enough 16- / 32-wide maps on
+    conv3x3_x3.hip's kernels with the K loop split over 2-4 blocks per tile, reduced as a reduce-scatter (x3m16_tail: partials as 16-byte
+    units, an arrival counter per tile, every block finishes a column slice, own slice in LDS).  Against the 12-wave forms of
+    conv3x3_f16.hip that served these sizes until round 5 (debug switch split_x3_small = 0): same three products per multiply in another
+    summation order - agreement to 5e-6 of the embedding's scale - and, the property that must hold exactly: copies of a crop inside
+    one pass give bit-identical embeddings wherever they sit (another tile, another column slice, another image pair)."""
+    eng, _ = eng_w0
+    base = synth.smooth_crops_u8(max(2, (n + 1) // 2), 90 + n)
+    ids = np.arange(n) % len(base)                       # every crop at least twice when n >= 2 (odd n: one image pair is ragged)
+    np.random.default_rng(n).shuffle(ids)
+    crops = base[ids]
+    eng.set_precision(2)
+    try:
+        got = eng.embed_u8(crops)
+        first = np.asarray([np.flatnonzero(ids == c)[0] for c in range(len(base)) if (ids == c).any()])
+        lut = {int(ids[f]): got[f] for f in first}
+        assert all(np.array_equal(got[i], lut[int(ids[i])]) for i in range(n))
+        eng.debug_switch("split_x3_small", 0)
+        old = eng.embed_u8(crops)
+        assert np.abs(got - old).max() <= 5e-6 * np.abs(old).max()
+        assert eng.fault_bits() == 0
+    finally:
+        eng.debug_switch("split_x3_small", 2)
+        eng.set_precision(0)
+
+
 @pytest.mark.parametrize("precision", [0, 2])
 def test_multi_camera_batched_stream_equals_independent_camera_streams(eng_w0, precision):
     """tracking.MultiCameraStream - K cameras' crops of a frame time in ONE pass, per-camera banks, per-camera cost blocks
