@@ -862,7 +862,7 @@ def run_all(job, args):
         r32 = run_tracking(job_, a)
         for prec in [q for q in ("f16x3", "f32", "f16") if q != a.precision]:
             a2 = copy.copy(a)
-            a2.precision, a2.no_cpu = prec, True
+            a2.precision, a2.no_cpu, a2.cameras = prec, True, 0      # (camera groups / look-ahead: the headline arithmetic only - run time)
             r2 = run_tracking(job_, a2)
             if r32 is not None:
                 r32[prec + "_path"] = {k: r2[k] for k in ("value", "ms_per_step", "crops_per_s", "ms_per_frame_median", "ms_per_frame_p95",
