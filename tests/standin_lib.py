@@ -158,24 +158,32 @@ class FakeLib:
 
     # ---- feature bank + frame pipeline (csrc/bank.hip semantics)
     def reid_bank_create(self, h, max_tracks, budget, d, out):
-        self.banks[1] = {"budget": budget, "rows": {}}
-        out._obj.value = 1
+        key = len(self.banks) + 1                            # (several banks per context: one per camera of a MultiCameraStream)
+        self.banks[key] = {"budget": budget, "rows": {}}
+        out._obj.value = key
         return 0
 
     def reid_bank_destroy(self, b):
         return 0
 
+    def _bank(self, b):
+        return self.banks[_v(b) or 1]
+
     def reid_bank_update(self, h, b, feats, slots, n):
         f = _mem(feats, n * 2048, np.float32).reshape(n, 512)
         sl = _mem(slots, n * 4, np.int32)
-        bank = self.banks[1]
+        bank = self._bank(b)
         for i in range(n):
             bank["rows"][int(sl[i])] = (bank["rows"].get(int(sl[i]), []) + [f[i].copy()])[-bank["budget"]:]
         return 0
 
     def reid_bank_clear(self, h, b, slots, n):
         for s in _mem(slots, n * 4, np.int32):
-            self.banks[1]["rows"].pop(int(s), None)
+            self._bank(b)["rows"].pop(int(s), None)
+        return 0
+
+    def reid_bank_count(self, b, slot, out):
+        out._obj.value = len(self._bank(b)["rows"].get(int(slot), []))
         return 0
 
     def reid_frame_submit(self, h, slot, packed, offs, hw, n):
@@ -211,13 +219,45 @@ class FakeLib:
             cost = np.empty((t, m), np.float32)
             with np.errstate(invalid="ignore", divide="ignore"):
                 for i in range(t):
-                    cost[i] = onn.nn_cosine_distance(np.stack(self.banks[1]["rows"][int(sl[i])]), emb)
+                    cost[i] = onn.nn_cosine_distance(np.stack(self._bank(bank)["rows"][int(sl[i])]), emb)
             mdist = max_dist.value if hasattr(max_dist, "value") else max_dist
             if mdist >= 0:
                 cost[cost > mdist] = mdist + 1e-5
         if _v(tb) and t and m:
             iou = matching.diou_cost(_mem(tb, t * 32, np.float64).reshape(t, 4), _mem(db, m * 32, np.float64).reshape(m, 4))
         self.out[slot] = (emb.copy(), cost, iou)
+        return 0
+
+    def reid_frame_cost_groups(self, h, slot, groups, banks, t_counts, m_counts, slots, metric, max_dist, tb, db, want_emb):
+        """bank.hip reid_frame_cost_groups step by step: group g's tracks against ITS detections, blocks concatenated."""
+        fr = self.frame[slot]
+        tc, mc = _mem(t_counts, groups * 4, np.int32), _mem(m_counts, groups * 4, np.int32)
+        if int(mc.sum()) != fr["m"]:
+            return -1
+        t_all = int(tc.sum())
+        sl = _mem(slots, t_all * 4, np.int32) if _v(slots) else None
+        tboxes = _mem(tb, t_all * 32, np.float64).reshape(t_all, 4) if _v(tb) else None
+        dboxes = _mem(db, fr["m"] * 32, np.float64).reshape(fr["m"], 4) if _v(db) else None
+        mdist = max_dist.value if hasattr(max_dist, "value") else max_dist
+        costs, ious, t_off, m_off = [], [], 0, 0
+        for g in range(groups):
+            t, m = int(tc[g]), int(mc[g])
+            emb = fr["emb"][m_off:m_off + m]
+            if t and m:
+                if sl is not None and banks is not None:
+                    bank = self._bank(banks[g])
+                    c = np.empty((t, m), np.float32)
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        for i in range(t):
+                            c[i] = onn.nn_cosine_distance(np.stack(bank["rows"][int(sl[t_off + i])]), emb)
+                    if mdist >= 0:
+                        c[c > mdist] = mdist + 1e-5
+                    costs.append(c.reshape(-1))
+                if tboxes is not None and dboxes is not None:
+                    ious.append(matching.diou_cost(tboxes[t_off:t_off + t], dboxes[m_off:m_off + m]).reshape(-1))
+            t_off += t
+            m_off += m
+        self.out[slot] = (fr["emb"][:fr["m"]].copy(), np.concatenate(costs) if costs else None, np.concatenate(ious) if ious else None)
         return 0
 
     def reid_frame_fetch(self, h, slot, emb, cost, iou):

@@ -153,3 +153,94 @@ def test_device_orchestration_with_several_ranks(tmp_path, world):
             np.testing.assert_allclose(z["f%d_cost" % f], cost, atol=2e-6)        # same bank on every rank, frame after frame
             if icost is not None:
                 np.testing.assert_array_equal(z["f%d_icost" % f], icost)
+
+
+# ----------------------------------------------------------------------------- one rank: the batching drivers of round 6
+def _seeded_stream(seed, frames, lo=0, hi=9):
+    rng = np.random.default_rng(seed)
+    return [[rng.integers(0, 256, (int(rng.integers(4, 9)), int(rng.integers(3, 6)), 3), dtype=np.uint8) for _ in range(int(rng.integers(lo, hi)))]
+            for _ in range(frames)]
+
+
+def test_multi_camera_and_lookahead_streams_equal_camera_streams_on_the_stand_in():
+    """Host logic of tracking.MultiCameraStream (K cameras' crops of a frame time in one slot, per-camera banks, the grouped cost
+    stage, slot-wide rows for the bank update) and tracking.LookaheadCameraStream (F frames per slot, one group per frame, costs and
+    updates frame by frame) against plain CameraStreams fed the same crops - on the stand-in library, whose "network" maps a crop to
+    a row regardless of the pass it rides in, so everything must agree EXACTLY: features, gated costs, DIoU costs, bank contents.
+    Covers cameras / frames without detections, a camera without tracks, a short last group.  (The kernels behind the same calls:
+    tests/test_gpu_parity.py::test_multi_camera_batched_stream_..., ::test_lookahead_stream_....)"""
+    from reid_amd.nn_matching import NearestNeighborDistanceMetric
+    from reid_amd.tracking import CameraStream, LookaheadCameraStream, MultiCameraStream
+
+    def stream(cls, *a):
+        obj = cls.__new__(cls)
+        obj._own, obj.eng, obj.max_dist = False, FakeEngine(), 0.3
+        if cls is MultiCameraStream:
+            obj.cameras = a[0]
+            obj.metrics = [NearestNeighborDistanceMetric("cosine", 0.3, 5, max_tracks=32, engine=obj.eng) for _ in range(a[0])]
+            obj._frame, obj._m = 0, {}
+        elif cls is LookaheadCameraStream:
+            obj.frames_per_pass = a[0]
+            obj.metric = NearestNeighborDistanceMetric("cosine", 0.3, 5, max_tracks=32, engine=obj.eng)
+            obj._group, obj._m = 0, {}
+        else:
+            obj.metric = NearestNeighborDistanceMetric("cosine", 0.3, 5, max_tracks=32, engine=obj.eng)
+            obj._frame = 0
+        return obj
+
+    rng = np.random.default_rng(9)
+    K, frames = 3, 7
+    cams = [_seeded_stream(20 + c, frames) for c in range(K)]
+    tracks = [list(range(4)), [7, 9], []]
+    seeds = [rng.normal(size=(len(t) * 2, 512)).astype(np.float32) for t in tracks]
+    boxes = rng.uniform(0, 200, (12, 4))
+    boxes[:, 2:] = rng.uniform(10, 60, (12, 2))
+    mc = stream(MultiCameraStream, K)
+    singles = [stream(CameraStream) for _ in range(K)]
+    for c in range(K):
+        if tracks[c]:
+            for met in (mc.metrics[c], singles[c].metric):
+                met.partial_fit(seeds[c], np.repeat(tracks[c], 2), tracks[c])
+    mc.submit([cams[c][0] for c in range(K)])
+    for c in range(K):
+        singles[c].submit(cams[c][0])
+    for f in range(frames):
+        nxt = f + 1 < frames
+        got = mc.step(tracks, [boxes[:len(t)] for t in tracks], [boxes[:len(cams[c][f])] for c in range(K)],
+                      [cams[c][f + 1] for c in range(K)] if nxt else None)
+        rows, tg = [], []
+        for c in range(K):
+            m = len(cams[c][f])
+            feats, cost, iou = singles[c].step(tracks[c], boxes[:len(tracks[c])], boxes[:m], cams[c][f + 1] if nxt else None)
+            assert np.array_equal(got[c][0], feats) and got[c][1].shape == (len(tracks[c]), m)
+            if tracks[c] and m:
+                assert np.array_equal(got[c][1], cost) and np.array_equal(got[c][2], iou)
+            k = min(m, len(tracks[c]))
+            singles[c].commit(np.arange(k), tracks[c][:k], tracks[c])
+            rows.append(np.arange(k))
+            tg.append(tracks[c][:k])
+        mc.commit(rows, tg, tracks)
+    for c in range(K):
+        for t in tracks[c]:
+            assert mc.metrics[c].samples_count(t) == singles[c].metric.samples_count(t)
+    # look-ahead groups of three frames (7 frames: 3 + 3 + 1) of camera 0
+    la, one = stream(LookaheadCameraStream, 3), stream(CameraStream)
+    for met in (la.metric, one.metric):
+        met.partial_fit(seeds[0], np.repeat(tracks[0], 2), tracks[0])
+    groups = [[0, 1, 2], [3, 4, 5], [6]]
+    la.submit_group([cams[0][f] for f in groups[0]])
+    one.submit(cams[0][0])
+    for gi, g in enumerate(groups):
+        for j, f in enumerate(g):
+            m = len(cams[0][f])
+            nxt = [cams[0][x] for x in groups[gi + 1]] if (j == len(g) - 1 and gi + 1 < len(groups)) else None
+            gf, gc, gio = la.step(j, tracks[0], boxes[:4], boxes[:m], nxt)
+            feats, cost, iou = one.step(tracks[0], boxes[:4], boxes[:m], cams[0][f + 1] if f + 1 < frames else None)
+            assert np.array_equal(gf, feats) and gc.shape == (4, m)
+            if m:
+                assert np.array_equal(gc, cost) and np.array_equal(gio, iou)
+            k = min(m, 4)
+            la.commit(j, np.arange(k), tracks[0][:k], tracks[0])
+            one.commit(np.arange(k), tracks[0][:k], tracks[0])
+    for t in tracks[0]:
+        assert la.metric.samples_count(t) == one.metric.samples_count(t)
