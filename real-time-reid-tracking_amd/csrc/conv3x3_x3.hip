@@ -1678,19 +1678,42 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
 #endif
 }
 
+// few output tiles (a tracking frame, a camera group): the real 32-channel chunks split over sk blocks per tile, up to two blocks for
+// every CU (x3m16_tail hands the tile's sixteen-column units out to the sk blocks: sk divides their number).  Eight ways lose to four -
+// twice the partial traffic: 30 crops 882 -> 1175 us per pass - so four is the cap.
+static int x3_split(const reid_ctx* ctx, int tiles, int ncr, bool wide) {
+    int sk = 1;
+    while (ctx->f16_split_k && tiles * sk * 2 <= 512 && ncr % (sk * 2) == 0 && sk * 2 <= (wide ? 8 : 4)) sk *= 2;
+    const int cap = ctx->x3_sk_cap > 0 ? ctx->x3_sk_cap : 4;
+    return sk > cap ? cap : sk;
+}
+
+// 128- or 64-wide tiles.  64-wide (three to four blocks per CU): layer 1 always; switch x3_narrow: bit 0 = also the 16-wide maps (layer 2:
+// default), bit 1 = every 8-wide one.  Round 6: layer 3 (8-wide maps, 256 channels) takes the 64-wide tile when the 128-wide launch would
+// leave the chip half empty (fewer than 256 blocks: up to ~60 crops) - measured (gpurun_out/r6/timeline_*_nar*, timeline_30_allx3n3): 30 crops 31
+// (12-wave) -> 23 us per convolution, 48: 36 -> 33; at 64 crops (both forms four ways split) the wide tile stays (40 against 44).  Layer 4
+// loses with narrow tiles from 120 crops on and keeps the wide one.
+static bool x3_wide_tiles(const reid_ctx* ctx, const Gemm16Params& p) {
+    if (p.N % 128 != 0 || (p.W == 16 && (ctx->x3_narrow & 1)) || (p.W == 8 && (ctx->x3_narrow & 2))) return false;
+    if (p.W == 8 && p.N == 256 && !(ctx->x3_narrow & 4)) {       // (bit 2: this rule off)
+        const int nmt = (p.M + 255) / 256, ncr = p.Cin / 3 / 32;
+        const int t128 = nmt * 2, t64 = nmt * 4;
+        const int s128 = x3_split(ctx, t128, ncr, true);
+        (void)t64;
+        // (the narrow tile also wins where it needs fewer splits or runs unsplit below 512 blocks - 120 / 200 / 256 / 384 crops: 1 % of a pass -
+        // but there it changes the summation order of passes the config-1 rank vectors are checked at; not worth another sub-noise row)
+        if (t128 * s128 < 256) return false;
+    }
+    return true;
+}
+
 template <int TW, int IMGS>
 int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
     Gemm16Params p = p0;
     const int nmt = (p.M + 255) / 256;
-    // 64-wide tiles (four blocks per CU): layer 1 always; switch x3_narrow: bit 0 = also the 16-wide maps (layer 2: default), bit 1 = the 8-wide ones
-    const bool wide = p.N % 128 == 0 && !((TW == 16 && (ctx->x3_narrow & 1)) || (TW == 8 && (ctx->x3_narrow & 2)));
+    const bool wide = x3_wide_tiles(ctx, p);
     const int tiles = nmt * (wide ? p.N / 128 : p.N / 64);
-    // few output tiles (a tracking frame): split the real 32-channel chunks over sk blocks per tile, up to two blocks for every CU
-    const int ncr = p.Cin / 3 / 32;
-    int sk = 1;
-    // (x3m16_tail hands the tile's sixteen-column units out to the sk blocks: sk divides their number)
-    while (ctx->f16_split_k && tiles * sk * 2 <= 512 && ncr % (sk * 2) == 0 && sk * 2 <= (wide ? 8 : 4)) sk *= 2;
-    if (sk > (ctx->x3_sk_cap > 0 ? ctx->x3_sk_cap : 4)) sk = ctx->x3_sk_cap > 0 ? ctx->x3_sk_cap : 4;   // eight ways: twice the partial traffic, 30 crops 882 -> 1175 us per pass
+    const int sk = x3_split(ctx, tiles, p.Cin / 3 / 32, wide);
     if (sk > 1) {
         float* ws;
         int* cnt;
@@ -1727,8 +1750,7 @@ void launch_x3(reid_ctx* ctx, const Gemm16Params& p) {
 // output tiles of a launch in the width launch_x3m16 picks for it
 static int launch_tiles(const reid_ctx* ctx, const Gemm16Params& p) {
     const int nmt = (p.M + 255) / 256;
-    const bool wide = p.N % 128 == 0 && !((p.W == 16 && (ctx->x3_narrow & 1)) || (p.W == 8 && (ctx->x3_narrow & 2)));
-    return nmt * (wide ? p.N / 128 : p.N / 64);
+    return nmt * (x3_wide_tiles(ctx, p) ? p.N / 128 : p.N / 64);
 }
 
 // Launches of at least two blocks for every CU, and (round 6) the smaller ones listed below; the smallest keep conv3x3_f16.hip's forms.
@@ -1746,10 +1768,10 @@ bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p) {
     // Smaller launches (round 6, split_x3_small = 2): since x3m16_tail reduces split-K partials as a reduce-scatter these kernels beat
     // conv3x3_f16.hip's 12-wave blocks wherever a launch is not tiny - measured per layer at 30 / 64 / 120 / 200 crops
     // (gpurun_out/r6/timeline_*): layer 4 at every size (30 crops: 45.5 / 69 / 70 / 73 -> 40 / 59 / 68 / 61 us, 200 crops: 385 -> 290 us),
-    // layer 3 from ~48 crops on (64 crops: 48 -> 41 us; 30 crops: 31 against 33 - stays), the 16- and 32-wide maps from ~400 tiles on
+    // layer 3 likewise (64 crops: 48 -> 41 us; 30 crops: 31 -> 23 us on 64-wide tiles, x3_wide_tiles), the 16- and 32-wide maps from ~400 tiles on
     // (layer 2 at 120 crops: 65 -> 51 us; at 64 crops 37 against 42 - stays; layer 1 at 30 crops 24 against 31-35 - stays).
     const int tiles = launch_tiles(ctx, p);
-    if (p.W == 8) return (p.N >= 512 && nmt >= 12) || nmt >= 24;     // (20 crops, layer 4: 12-wave forms 788 against 802 us per pass)
+    if (p.W == 8) return nmt >= 12;     // layers 3 and 4 from 24 crops on (20 crops, layer 4: 12-wave forms 788 against 802 us per pass; layer 3 since it takes 64-wide tiles there)
     return tiles >= 384;
 }
 
