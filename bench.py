@@ -689,18 +689,23 @@ def run_tracking(job, args):
                 for g0 in range(first, last, F):
                     for j, f in enumerate(range(g0, min(g0 + F, last))):
                         n = int(counts[f])
-                        la.step(j, tracks, boxes[:40], boxes[:n], grp(g0 + F) if (j == min(F, last - g0) - 1 and g0 + F < last) else None)
+                        ts = time.perf_counter()
+                        la.step(j, tracks, boxes[:40], boxes[:n], grp(g0 + F) if (j == la.handover and g0 + F < last) else None)
+                        step_s[j].append(time.perf_counter() - ts)
                         k = min(n, 40)
                         la.commit(j, np.arange(k), tracks[:k], tracks)
                 la.eng.sync()
+            step_s = [[] for _ in range(F)]
             drive_la(0, 40)
+            step_s = [[] for _ in range(F)]
             t0l = time.perf_counter()
             drive_la(0, frames)
             ell = time.perf_counter() - t0l
             la.close(destroy=True)
-            look["frames_per_pass_%d" % F] = {"frames_per_s": round(frames / ell, 1), "ms_per_frame": round(ell / frames * 1e3, 3)}
+            look["frames_per_pass_%d" % F] = {"frames_per_s": round(frames / ell, 1), "ms_per_frame": round(ell / frames * 1e3, 3),
+                                              "step_ms_by_frame_of_group": [round(float(np.mean(v)) * 1e3, 3) for v in step_s]}
         look["note"] = ("detections known F frames ahead (video file / detection dump): F frames' crops in one pass, costs and bank updates per frame "
-                        "in order; latency = F frame periods.  Not `value`.")
+                        "in order on a stream of their own beside the next group's forward; latency = F frame periods.  Not `value`.")
         out["lookahead"] = look
     if multi is not None:
         stream.metric.close()

@@ -264,6 +264,12 @@ int reid_frame_cost_groups(reid_ctx* ctx, int slot, int groups, reid_bank* const
  * Asynchronous; without a communicator (reid_comm_init) a no-op. */
 int reid_frame_gather(reid_ctx* ctx, int slot, int per);
 int reid_frame_update(reid_ctx* ctx, int slot, reid_bank* bank, const int32_t* rows, const int32_t* slots, int n);
+/* Look-ahead streams (a video file / detection dump whose detections are known F frames ahead: F frames' crops are submitted as one
+ * slot, their cost / update stages follow frame by frame): on != 0 moves the cost and update stages of THIS context's frame pipeline
+ * to a stream of their own, ordered against the forwards by events, so that a group's serial cost -> assign -> update chain runs
+ * beside the next group's forward.  While it is on, the context's banks must be driven through reid_frame_cost* / reid_frame_update
+ * only.  Synchronises the context.  ([external] deep_sort.py DeepSort.update is strictly frame by frame: no counterpart.) */
+int reid_frame_match_stream(reid_ctx* ctx, int on);
 /* retrieval evaluation, reid/evaluate.py:33-105: for every query the ranks of its good gallery items among
  * non-junk items (descending similarity gf@q).  cmc_sum int32[ng] = sum over valid queries of the CMC step,
  * ap double[nq], valid int32[nq] (0 when the query has no good item). */

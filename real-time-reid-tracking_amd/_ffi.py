@@ -81,6 +81,7 @@ _SIGS = {
     "reid_frame_submit": (_i, [_vp, _i, _vp, _vp, _vp, _i]),
     "reid_frame_cost": (_i, [_vp, _i, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _i]),
     "reid_frame_cost_groups": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, C.c_float, _vp, _vp, _i]),
+    "reid_frame_match_stream": (_i, [_vp, _i]),
     "reid_frame_fetch": (_i, [_vp, _i, _vp, _vp, _vp]),
     "reid_frame_gather": (_i, [_vp, _i, _i]),
     "reid_frame_update": (_i, [_vp, _i, _vp, _vp, _vp, _i]),

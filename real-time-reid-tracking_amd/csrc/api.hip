@@ -66,6 +66,12 @@ extern "C" int reid_ctx_destroy(reid_ctx* ctx) {
         if (ctx->frame_ev[i]) hipEventDestroy(ctx->frame_ev[i]);
     if (ctx->copy_ev) hipEventDestroy(ctx->copy_ev);
     for (hipEvent_t e : ctx->pipe_ev) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->fwd_ev[i]) hipEventDestroy(ctx->fwd_ev[i]);
+        if (ctx->match_ev[i]) hipEventDestroy(ctx->match_ev[i]);
+    }
+    if (ctx->join_ev) hipEventDestroy(ctx->join_ev);
+    if (ctx->match_stream) { hipStreamSynchronize(ctx->match_stream); hipStreamDestroy(ctx->match_stream); }
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
     for (auto& kv : ctx->ws) hipFree(kv.second.first);
     for (auto& kv : ctx->split_w) hipFree(kv.second);
@@ -138,6 +144,7 @@ extern "C" int reid_ctx_sync(reid_ctx* ctx) {
     ARG_CHECK(ctx);
     CTX_GUARD(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->match_stream) HIP_TRY(hipStreamSynchronize(ctx->match_stream));
     return ctx_fault_status(ctx);
 }
 

@@ -344,9 +344,31 @@ static int bank_update_impl(reid_ctx* ctx, reid_bank* b, const float* d_feats, c
     return REID_OK;
 }
 
+// The match stream (opt-in, reid_frame_match_stream): cost and update stages run there, ordered against the forwards by two events per
+// slot.  While a stage is queued the context's stream pointer is swapped, so the launchers it calls need not know.  The bank's other
+// entry points (host / device features in, costs out) run there too, so that every access to a bank is ordered on ONE stream: `join`
+// puts them behind what the compute stream holds so far (the caller's device operands), `rejoin` makes the compute stream wait for
+// them (device results the caller goes on to use).
+struct MatchStream {
+    reid_ctx* ctx;
+    hipStream_t saved;
+    bool rejoin;
+    explicit MatchStream(reid_ctx* c, bool join = false, bool rejoin_ = false) : ctx(c), saved(c->stream), rejoin(rejoin_) {
+        if (!on()) return;
+        if (join && hipEventRecord(c->join_ev, saved) == hipSuccess) hipStreamWaitEvent(c->match_stream, c->join_ev, 0);
+        c->stream = c->match_stream;
+    }
+    ~MatchStream() {
+        ctx->stream = saved;
+        if (on() && rejoin && hipEventRecord(ctx->join_ev, ctx->match_stream) == hipSuccess) hipStreamWaitEvent(saved, ctx->join_ev, 0);
+    }
+    bool on() const { return ctx->match_async && ctx->match_stream; }
+};
+
 extern "C" int reid_bank_update_dev(reid_ctx* ctx, reid_bank* b, const float* d_feats, const int32_t* slots, int n) {
     ARG_CHECK(ctx && b && b->ctx == ctx && n >= 0 && (n == 0 || (d_feats && slots)));
     CTX_GUARD(ctx);
+    MatchStream ms(ctx, true);
     return bank_update_impl(ctx, b, d_feats, slots, n);
 }
 
@@ -354,6 +376,7 @@ extern "C" int reid_bank_update(reid_ctx* ctx, reid_bank* b, const float* feats,
     ARG_CHECK(ctx && b && b->ctx == ctx && n >= 0 && (n == 0 || (feats && slots)));
     CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
+    MatchStream ms(ctx, true);
     float* d_f;
     REID_TRY(ctx_ws(ctx, "bank.in", (size_t)n * b->d * 4, (void**)&d_f));
     HIP_TRY(hipMemcpyAsync(d_f, feats, (size_t)n * b->d * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -365,6 +388,7 @@ extern "C" int reid_bank_clear(reid_ctx* ctx, reid_bank* b, const int32_t* slots
     ARG_CHECK(ctx && b && b->ctx == ctx && n >= 0 && (n == 0 || slots));
     CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
+    MatchStream ms(ctx, true);
     std::vector<int32_t> h(2 * n, 0);
     for (int i = 0; i < n; ++i) {
         ARG_CHECK(slots[i] >= 0 && slots[i] < b->max_tracks);
@@ -418,6 +442,7 @@ extern "C" int reid_bank_cost_dev(reid_ctx* ctx, reid_bank* b, const int32_t* sl
     ARG_CHECK(metric == REID_METRIC_COS || metric == REID_METRIC_L2SQR);
     if (t == 0 || m == 0) return REID_OK;
     ARG_CHECK(slots && d_dets && d_out);
+    MatchStream ms(ctx, true, true);
     return bank_cost_impl(ctx, b, slots, t, d_dets, m, metric == REID_METRIC_COS ? 0 : 1, max_dist, d_out);
 }
 
@@ -428,6 +453,7 @@ extern "C" int reid_bank_cost(reid_ctx* ctx, reid_bank* b, const int32_t* slots,
     ARG_CHECK(metric == REID_METRIC_COS || metric == REID_METRIC_L2SQR);
     if (t == 0 || m == 0) return REID_OK;
     ARG_CHECK(slots && dets && out);
+    MatchStream ms(ctx, true);
     float *d_dets, *d_out;
     REID_TRY(ctx_ws(ctx, "bank.dets", (size_t)m * b->d * 4, (void**)&d_dets));
     REID_TRY(ctx_ws(ctx, "bank.out", (size_t)t * m * 4, (void**)&d_out));
@@ -451,10 +477,39 @@ extern "C" int reid_bank_cost(reid_ctx* ctx, reid_bank* b, const int32_t* slots,
 // Two frame slots own their device-side crops and embeddings, so frame f+1 is uploaded and embedded while the host still
 // runs the assignment of frame f.  Small inputs go through pinned staging buffers: a hipMemcpyAsync from pageable memory
 // would block the caller until everything queued before it has finished.
+extern "C" int reid_frame_match_stream(reid_ctx* ctx, int on) {
+    ARG_CHECK(ctx);
+    CTX_GUARD(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->match_stream) HIP_TRY(hipStreamSynchronize(ctx->match_stream));
+    if (on && !ctx->match_stream) {
+        // HIP multiplexes a process's streams onto a few hardware queues per priority level (4 by default): with several contexts alive
+        // the match stream could land in the queue of this context's compute stream and every cost stage would sit behind the forward
+        // it is meant to run beside (seen in bench.py: 1.44 k frames/s instead of 1.95 k).  High priority puts it in a queue pool of its
+        // own - and lets its small kernels in between the forward's.
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&ctx->match_stream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&ctx->fwd_ev[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->match_ev[i], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ctx->match_ev[i], ctx->match_stream));
+        }
+    }
+    ctx->match_async = on ? 1 : 0;
+    return REID_OK;
+}
+
 extern "C" int reid_frame_submit(reid_ctx* ctx, int slot, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int m) {
     ARG_CHECK(ctx && (slot == 0 || slot == 1) && m >= 0 && (m == 0 || (packed && offsets && hw)));
     CTX_ENTER(ctx);
-    if (ctx->frame_pending[slot]) HIP_TRY(hipStreamSynchronize(ctx->stream));   // resubmitted without reid_frame_fetch: its staging is still in use
+    if (ctx->frame_pending[slot]) {   // resubmitted without reid_frame_fetch: its staging is still in use
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->match_stream) HIP_TRY(hipStreamSynchronize(ctx->match_stream));
+    }
+    if (ctx->match_async && ctx->match_stream)   // the slot's buffers are rewritten below: behind the last cost / update stage that read them
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->match_ev[slot], 0));
     ctx->frame_has[slot] = 0;
     ctx->frame_pending[slot] = 0;
     ctx->frame_m[slot] = 0;
@@ -471,6 +526,7 @@ extern "C" int reid_frame_submit(reid_ctx* ctx, int slot, const uint8_t* packed,
     ctx->frame_m[slot] = m;
     ctx->frame_emb[slot] = d_emb;
     ctx->frame_pending[slot] = 1;
+    if (ctx->match_async && ctx->match_stream) HIP_TRY(hipEventRecord(ctx->fwd_ev[slot], ctx->stream));
     return REID_OK;
 }
 
@@ -493,6 +549,8 @@ extern "C" int reid_frame_cost_groups(reid_ctx* ctx, int slot, int groups, reid_
     }
     ARG_CHECK(msum == m);
     const bool want_cost = banks && slots && tm > 0, want_iou = tracks_t4 && dets_m4 && tm > 0;
+    MatchStream ms(ctx);
+    if (ms.on() && m > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->fwd_ev[slot], 0));     // the slot's embeddings
     if (want_cost) {
         ARG_CHECK(metric == REID_METRIC_COS || metric == REID_METRIC_L2SQR);
         for (int g = 0, i = 0; g < groups; ++g) {
@@ -541,6 +599,7 @@ extern "C" int reid_frame_cost_groups(reid_ctx* ctx, int slot, int groups, reid_
         HIP_TRY(hipMemcpyAsync(pin_out + tm * 12, ctx->frame_emb[slot], (size_t)m * 2048, hipMemcpyDeviceToHost, ctx->stream));
     if (!ctx->frame_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->frame_ev[slot], hipEventDisableTiming));
     HIP_TRY(hipEventRecord(ctx->frame_ev[slot], ctx->stream));
+    if (ms.on()) HIP_TRY(hipEventRecord(ctx->match_ev[slot], ctx->stream));
     ctx->frame_tm[slot] = tm;
     ctx->frame_has[slot] = (want_iou ? 1 : 0) | (want_cost ? 2 : 0) | (want_emb && m > 0 ? 4 : 0) | 8;
     ctx->frame_out[slot] = pin_out;
@@ -580,5 +639,8 @@ extern "C" int reid_frame_update(reid_ctx* ctx, int slot, reid_bank* b, const in
     CTX_GUARD(ctx);
     if (n == 0) return REID_OK;
     for (int i = 0; i < n; ++i) ARG_CHECK(rows[i] >= 0 && rows[i] < ctx->frame_m[slot]);
-    return bank_update_impl(ctx, b, ctx->frame_emb[slot], slots, n, rows);
+    MatchStream ms(ctx);      // (behind the slot's cost stage on the same stream, which waited for its forward)
+    REID_TRY(bank_update_impl(ctx, b, ctx->frame_emb[slot], slots, n, rows));
+    if (ms.on()) HIP_TRY(hipEventRecord(ctx->match_ev[slot], ctx->stream));
+    return REID_OK;
 }

@@ -424,6 +424,11 @@ struct reid_ctx {
     int frame_pending[2] = {0, 0}, frame_has[2] = {0, 0};
     size_t frame_tm[2] = {0, 0};        // elements of the cost stage's output (sum over the camera groups of tracks x detections)
     hipEvent_t frame_ev[2] = {nullptr, nullptr};
+    hipStream_t match_stream = nullptr;  // reid_frame_match_stream(ctx, 1): cost / update stages of the frame pipeline on a stream of their own, so that a
+                                         // group of look-ahead frames walks its serial cost -> assign -> update chain beside the next group's forward
+    int match_async = 0;
+    hipEvent_t join_ev = nullptr;        // orders the bank's other entry points between the two streams
+    hipEvent_t fwd_ev[2] = {nullptr, nullptr}, match_ev[2] = {nullptr, nullptr};   // slot's forward queued / its last reader on the match stream queued
     hipStream_t copy_stream = nullptr;   // uploads of the frame pipeline (beside the kernels of the previous frame)
     hipEvent_t copy_ev = nullptr;
     std::vector<hipEvent_t> pipe_ev;     // host_passes (api.hip): "pass k uploaded" / "pass k computed" events of the host-in / host-out entry points

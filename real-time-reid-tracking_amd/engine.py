@@ -329,6 +329,11 @@ class Engine:
         check(self.lib.reid_frame_fetch(self.h, int(slot), _ptr(emb) if m else None, _ptr(cost), _ptr(iou)))
         return emb, cost, iou
 
+    def frame_match_stream(self, on=True):
+        """Cost / update stages of the frame pipeline (and every other access to this context's banks) on a stream of their own
+        (reid_frame_match_stream): a look-ahead group's frame-by-frame chain then runs beside the next group's forward."""
+        check(self.lib.reid_frame_match_stream(self.h, 1 if on else 0))
+
     def frame_cost_groups(self, slot, groups, metric=0, max_dist=-1.0, want_emb=True):
         """Stage 2 for K camera streams batched into one slot (reid_frame_cost_groups): ``groups`` = one (bank, slots, track_boxes,
         det_boxes, m) per camera, in the order their crops were submitted; camera g's tracks meet ITS m detections only."""

@@ -260,6 +260,9 @@ class FakeLib:
         self.out[slot] = (fr["emb"][:fr["m"]].copy(), np.concatenate(costs) if costs else None, np.concatenate(ious) if ious else None)
         return 0
 
+    def reid_frame_match_stream(self, h, on):
+        return 0      # (the stand-in runs every stage when it is called: nothing to order)
+
     def reid_frame_fetch(self, h, slot, emb, cost, iou):
         e, c, i = self.out.pop(slot)
         if _v(emb):

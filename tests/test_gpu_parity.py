@@ -1129,7 +1129,9 @@ def test_lookahead_stream_equals_the_frame_by_frame_stream(eng_w0, precision):
     """tracking.LookaheadCameraStream - F consecutive frames of ONE camera embedded as one pass, costs and bank updates per frame and
     in order - against `CameraStream` on the same detection dump: features and gated costs equal to fp32 summation order (a crop's
     embedding depends on the pass size through tile shapes only), DIoU bit for bit, bank sample counts equal; groups of 3 frames,
-    the last group short, frames without detections."""
+    the last group short, frames without detections.  Both forms of the look-ahead stream - cost / update stages on the match stream
+    with the next group handed over at the group's first frame (reid_frame_match_stream), and everything on one stream - must agree
+    BIT FOR BIT with each other."""
     from reid_amd.tracking import CameraStream, LookaheadCameraStream
     eng, sd = eng_w0
     blob, manifest = weights.pack_seres18(sd)[:2]
@@ -1141,31 +1143,48 @@ def test_lookahead_stream_equals_the_frame_by_frame_stream(eng_w0, precision):
     boxes = rng.uniform(0, 300, (16, 4))
     boxes[:, 2:] = rng.uniform(10, 90, (16, 2))
     seeds = rng.normal(size=(15, 512)).astype(np.float32)
-    la = LookaheadCameraStream(blob, manifest, 3, precision)
+    la = LookaheadCameraStream(blob, manifest, 3, precision)                          # cost / update stages on the match stream
+    la1 = LookaheadCameraStream(blob, manifest, 3, precision, match_stream=False)     # everything on one stream
     one = CameraStream(blob, manifest, precision)
+    assert la.match_stream and not la1.match_stream
     try:
-        for obj in (la.metric, one.metric):
+        for obj in (la.metric, la1.metric, one.metric):
             obj.partial_fit(seeds, np.repeat(tracks, 3), tracks)
         groups = [[0, 1, 2], [3, 4, 5], [6, 7]]
-        la.submit_group([crops(f) for f in groups[0]])
+        for s_ in (la, la1):
+            s_.submit_group([crops(f) for f in groups[0]])
         one.submit(crops(0))
         for gi, g in enumerate(groups):
+            assert la.handover == 0 and la1.handover == len(g) - 1
             for j, f in enumerate(g):
-                nxt = [crops(x) for x in groups[gi + 1]] if (j == len(g) - 1 and gi + 1 < len(groups)) else None
-                gf, gc, gi_ = la.step(j, tracks, boxes[:5], boxes[:counts[f]], nxt)
+                nxt = lambda s_: [crops(x) for x in groups[gi + 1]] if (j == s_.handover and gi + 1 < len(groups)) else None
+                gf, gc, gi_ = la.step(j, tracks, boxes[:5], boxes[:counts[f]], nxt(la))
+                gf1, gc1, gi1 = la1.step(j, tracks, boxes[:5], boxes[:counts[f]], nxt(la1))
                 feats, cost, iou = one.step(tracks, boxes[:5], boxes[:counts[f]], crops(f + 1) if f + 1 < len(counts) else None)
                 assert gf.shape == (counts[f], 512) and gc.shape == (5, counts[f])
+                # the two look-ahead forms run the same passes and the same stages in the same order: bit for bit
+                assert np.array_equal(gf, gf1) and np.array_equal(gc, gc1)
                 if counts[f]:
+                    assert np.array_equal(gi_, gi1)
                     assert np.abs(gf - feats).max() <= 2e-5 * np.abs(feats).max()
                     np.testing.assert_allclose(gc, cost, atol=2e-5)
                     assert np.array_equal(gi_, iou)
                 k = min(counts[f], 5)
                 la.commit(j, np.arange(k), tracks[:k], tracks)
+                la1.commit(j, np.arange(k), tracks[:k], tracks)
                 one.commit(np.arange(k), tracks[:k], tracks)
         for t in tracks:
-            assert la.metric.samples_count(t) == one.metric.samples_count(t)
+            assert la.metric.samples_count(t) == one.metric.samples_count(t) == la1.metric.samples_count(t)
+        # the bank's other entry points while the match stream is on: ordered on it (a clear, then costs from host features)
+        q = rng.normal(size=(4, 512)).astype(np.float32)
+        for s_ in (la, la1, one):
+            s_.metric.partial_fit(q, np.asarray([0, 1, 2, 3]), tracks[:4])        # drops track 4
+        d_la, d_la1, d_one = (s_.metric.distance(q, tracks[:4]) for s_ in (la, la1, one))
+        assert np.array_equal(d_la, d_la1)
+        np.testing.assert_allclose(d_la, d_one, atol=2e-5)
     finally:
         la.close(destroy=True)
+        la1.close(destroy=True)
         one.close(destroy=True)
 
 

@@ -180,7 +180,8 @@ def test_multi_camera_and_lookahead_streams_equal_camera_streams_on_the_stand_in
             obj.metrics = [NearestNeighborDistanceMetric("cosine", 0.3, 5, max_tracks=32, engine=obj.eng) for _ in range(a[0])]
             obj._frame, obj._m = 0, {}
         elif cls is LookaheadCameraStream:
-            obj.frames_per_pass = a[0]
+            obj.frames_per_pass, obj.match_stream = a[0], a[1]
+            obj.eng.frame_match_stream(a[1])
             obj.metric = NearestNeighborDistanceMetric("cosine", 0.3, 5, max_tracks=32, engine=obj.eng)
             obj._group, obj._m = 0, {}
         else:
@@ -223,24 +224,27 @@ def test_multi_camera_and_lookahead_streams_equal_camera_streams_on_the_stand_in
     for c in range(K):
         for t in tracks[c]:
             assert mc.metrics[c].samples_count(t) == singles[c].metric.samples_count(t)
-    # look-ahead groups of three frames (7 frames: 3 + 3 + 1) of camera 0
-    la, one = stream(LookaheadCameraStream, 3), stream(CameraStream)
-    for met in (la.metric, one.metric):
-        met.partial_fit(seeds[0], np.repeat(tracks[0], 2), tracks[0])
-    groups = [[0, 1, 2], [3, 4, 5], [6]]
-    la.submit_group([cams[0][f] for f in groups[0]])
-    one.submit(cams[0][0])
-    for gi, g in enumerate(groups):
-        for j, f in enumerate(g):
-            m = len(cams[0][f])
-            nxt = [cams[0][x] for x in groups[gi + 1]] if (j == len(g) - 1 and gi + 1 < len(groups)) else None
-            gf, gc, gio = la.step(j, tracks[0], boxes[:4], boxes[:m], nxt)
-            feats, cost, iou = one.step(tracks[0], boxes[:4], boxes[:m], cams[0][f + 1] if f + 1 < frames else None)
-            assert np.array_equal(gf, feats) and gc.shape == (4, m)
-            if m:
-                assert np.array_equal(gc, cost) and np.array_equal(gio, iou)
-            k = min(m, 4)
-            la.commit(j, np.arange(k), tracks[0][:k], tracks[0])
-            one.commit(np.arange(k), tracks[0][:k], tracks[0])
-    for t in tracks[0]:
-        assert la.metric.samples_count(t) == one.metric.samples_count(t)
+    # look-ahead groups of three frames (7 frames: 3 + 3 + 1) of camera 0; the next group handed over at the last frame (one stream)
+    # or at the first one (match stream)
+    for match_stream in (False, True):
+        la, one = stream(LookaheadCameraStream, 3, match_stream), stream(CameraStream)
+        for met in (la.metric, one.metric):
+            met.partial_fit(seeds[0], np.repeat(tracks[0], 2), tracks[0])
+        groups = [[0, 1, 2], [3, 4, 5], [6]]
+        la.submit_group([cams[0][f] for f in groups[0]])
+        assert la.handover == (0 if match_stream else 2)
+        one.submit(cams[0][0])
+        for gi, g in enumerate(groups):
+            for j, f in enumerate(g):
+                m = len(cams[0][f])
+                nxt = [cams[0][x] for x in groups[gi + 1]] if (j == la.handover and gi + 1 < len(groups)) else None
+                gf, gc, gio = la.step(j, tracks[0], boxes[:4], boxes[:m], nxt)
+                feats, cost, iou = one.step(tracks[0], boxes[:4], boxes[:m], cams[0][f + 1] if f + 1 < frames else None)
+                assert np.array_equal(gf, feats) and gc.shape == (4, m)
+                if m:
+                    assert np.array_equal(gc, cost) and np.array_equal(gio, iou)
+                k = min(m, 4)
+                la.commit(j, np.arange(k), tracks[0][:k], tracks[0])
+                one.commit(np.arange(k), tracks[0][:k], tracks[0])
+        for t in tracks[0]:
+            assert la.metric.samples_count(t) == one.metric.samples_count(t)
