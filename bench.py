@@ -459,7 +459,7 @@ def run_tracking(job, args):
     counts = np.clip(rng.poisson(30, frames), 1, 80)
     pool = synth.ragged_crops_u8(256, seed=3)
     from reid_amd.tracking import ShardedCameraStream
-    stream = ShardedCameraStream(eng, comm, 0.15, 100)                   # MAX_DIST / NN_BUDGET, deep_sort.yaml:3,9
+    stream = ShardedCameraStream(eng, comm, 0.15, 100, match_stream=bool(args.match_stream))    # MAX_DIST / NN_BUDGET, deep_sort.yaml:3,9
     metric = stream.metric
     tracks = list(range(40))
     metric.partial_fit(rng.normal(size=(40 * 100, 512)).astype(np.float32), np.repeat(tracks, 100), tracks)
@@ -604,12 +604,6 @@ def run_tracking(job, args):
         import threading
         from reid_amd.tracking import CameraStream
         blob, manifest = weights.pack_seres18(sd)[:2]
-        cams = []
-        for c in range(args.cameras):
-            cs = CameraStream(blob, manifest, {"f32": 0, "f16": 1, "f16x3": 2}[args.precision])
-            cs.metric.partial_fit(rng.normal(size=(40 * 100, 512)).astype(np.float32), np.repeat(tracks, 100), tracks)
-            cams.append(cs)
-
         def drive(cs, c, first, last):
             cr = lambda f: [pool[(f * 7 + i + 31 * c) % 256] for i in range(int(counts[f]))]
             cs.submit(cr(first))
@@ -620,17 +614,28 @@ def run_tracking(job, args):
                 cs.commit(np.arange(k), tracks[:k], tracks)
             cs.close()
 
-        for c, cs in enumerate(cams):
-            drive(cs, c, 0, 40)
-        th = [threading.Thread(target=drive, args=(cs, c, 0, frames)) for c, cs in enumerate(cams)]
-        t0m = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        elm = time.perf_counter() - t0m
-        for cs in cams:
-            cs.close(destroy=True)
+        def threads_form(two_streams):
+            cams = []
+            for c in range(args.cameras):
+                cs = CameraStream(blob, manifest, {"f32": 0, "f16": 1, "f16x3": 2}[args.precision], match_stream=two_streams)
+                cs.metric.partial_fit(rng.normal(size=(40 * 100, 512)).astype(np.float32), np.repeat(tracks, 100), tracks)
+                cams.append(cs)
+            for c, cs in enumerate(cams):
+                drive(cs, c, 0, 40)
+            th = [threading.Thread(target=drive, args=(cs, c, 0, frames)) for c, cs in enumerate(cams)]
+            t0m = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            el = time.perf_counter() - t0m
+            for cs in cams:
+                cs.close(destroy=True)
+            return el
+        # K contexts as in rounds 2-5: everything of a camera on its one compute stream; and with each camera's cost / update stages on
+        # a second, high-priority stream (the default of a single CameraStream: with K contexts it is 2K + K copy streams on the device's
+        # few hardware queues, and the cross-stream waits stall on queue switches)
+        elm, elm2 = threads_form(False), threads_form(True)
         # the same K cameras batched into ONE pass per frame time (tracking.MultiCameraStream: one context, one host thread, per-camera
         # banks and per-camera cost blocks) - the mapping that pays: a pass of ~30 K crops runs its convolutions as proper tiles
         from reid_amd.tracking import MultiCameraStream
@@ -660,7 +665,8 @@ def run_tracking(job, args):
                  "mode": "batched: the K cameras' crops of a frame time in ONE pass (tracking.MultiCameraStream), per-camera banks and cost blocks, one host thread",
                  "threads": {"frames_per_s_total": round(K * frames / elm, 1), "frames_per_s_per_camera": round(frames / elm, 1),
                              "ms_per_frame_per_camera": round(elm / frames * 1e3, 3),
-                             "mode": "K contexts, K host threads, one pass per camera frame (rounds 2-5)"}}
+                             "mode": "K contexts, K host threads, one pass per camera frame, match_stream=False (rounds 2-5)",
+                             "frames_per_s_total_with_match_streams": round(K * frames / elm2, 1)}}
     out = {"metric": "frames/sec, per-frame crop batches embedded + gathered + matched (ResNet18-SE 128x256)", "value": round(frames / elapsed, 1),
             "unit": "frames/s", "n_gpus": world, "steps": frames, "warmup": TRACK_WARMUP, "ms_per_step": round(elapsed * 1e3 / frames, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
@@ -713,6 +719,7 @@ def run_tracking(job, args):
         out["camera_streams"] = multi
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    eng.frame_match_stream(False)
     return out
 
 
@@ -1026,6 +1033,8 @@ def main(argv=None):
                          "host = configs[1] in the headline arithmetic only + the host_path sub-object (Extractor on host crops)")
     ap.add_argument("--crops", type=int, default=4096, help="crops (images) per GPU per step (BASELINE config 2 / 3: 4096)")
     ap.add_argument("--frames", type=int, default=600, help="--workload tracking: frames of the stream")
+    ap.add_argument("--match-stream", type=int, default=1,
+                    help="tracking: 0 = cost / update stages of the frame pipeline on the compute stream (rounds 3-5) instead of a stream of their own")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "1024")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cameras", type=int, default=2, help="--workload tracking, one GPU: also run this many concurrent camera streams")

@@ -232,7 +232,10 @@ extern "C" int reid_frame_gather(reid_ctx* ctx, int slot, int per) {
     // address it - parallel.frame_rows never does - but a cost matrix over the whole slot must not meet NaNs)
     if (mine < per) HIP_TRY(hipMemsetAsync(d_loc + (size_t)mine * 512, 0, (size_t)(per - mine) * 2048, ctx->stream));
     REID_TRY(ctx_ws(ctx, (tag + ".all").c_str(), (size_t)world * per * 2048, (void**)&d_all));
+    const bool two_streams = ctx->match_async && ctx->match_stream;      // reid_frame_match_stream: the slot's readers are on the other stream
+    if (two_streams) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->match_ev[slot], 0));
     REID_TRY(reid_allgather_dev(ctx, d_loc, d_all, (size_t)per * 2048));
+    if (two_streams) HIP_TRY(hipEventRecord(ctx->fwd_ev[slot], ctx->stream));   // the slot's embeddings are the gathered ones
     ctx->frame_emb[slot] = d_all;
     ctx->frame_m[slot] = world * per;
     ctx->frame_pending[slot] = 1;
