@@ -1704,6 +1704,21 @@ static bool x3_wide_tiles(const reid_ctx* ctx, const Gemm16Params& p) {
         // but there it changes the summation order of passes the config-1 rank vectors are checked at; not worth another sub-noise row)
         if (t128 * s128 < 256) return false;
     }
+    // Layer 4 (8-wide maps of image pairs, 512 channels), round 6 - pass sizes where the 128-wide launch fills the chip unevenly
+    // (tools/probes/small_sweep.py over 8 .. 520 crops, switch x3_l4_narrow_nmt = 0 / 1000):
+    //  * 33 .. 62 crops: four ways split, 272 .. 496 blocks for 256 CUs - the CUs that get two blocks set the time (78 us per convolution
+    //    for every size in the range, 58 at 32 crops); 64-wide tiles (three blocks per CU, two ways split) are 12 .. 75 us per pass faster.
+    //    Not at 63 / 64 crops (32 tile rows): passes of 64 keep the form the config-1 rank vectors were checked with.
+    //  * unsplit launches whose last layer of 256 blocks covers at most half the CUs (129 .. 192, 257 .. 320, 385 .. 448 crops): the
+    //    narrow tile halves that tail: -100 .. -160 us per pass (2.32 -> 2.20 ms at 129 crops); past half a layer the wide tile wins by
+    //    as much.  Same K order per output element: bit-identical to the wide launch.
+    //  * two ways split (65 .. 128 crops): no difference, stays wide.
+    if (p.W == 8 && p.N == 512 && ctx->x3_l4_narrow_nmt > 0) {
+        const int nmt = (p.M + 255) / 256, ncr = p.Cin / 3 / 32;
+        const int t128 = nmt * 4, s128 = x3_split(ctx, t128, ncr, true);
+        if (s128 == 4 && t128 * s128 > 256 && nmt <= ctx->x3_l4_narrow_nmt) return false;
+        if (s128 == 1 && t128 % 256 != 0 && t128 % 256 <= 128) return false;
+    }
     return true;
 }
 
@@ -1770,8 +1785,15 @@ bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p) {
     // (gpurun_out/r6/timeline_*): layer 4 at every size (30 crops: 45.5 / 69 / 70 / 73 -> 40 / 59 / 68 / 61 us, 200 crops: 385 -> 290 us),
     // layer 3 likewise (64 crops: 48 -> 41 us; 30 crops: 31 -> 23 us on 64-wide tiles, x3_wide_tiles), the 16- and 32-wide maps from ~400 tiles on
     // (layer 2 at 120 crops: 65 -> 51 us; at 64 crops 37 against 42 - stays; layer 1 at 30 crops 24 against 31-35 - stays).
+    // Second pass over every pass size of a tracking stream (tools/probes/small_sweep.py, timelines at 20 / 28 / 33 crops with and without
+    // split_x3_small = 1): (i) layers 3 and 4 at EVERY size - 20 crops: layer 3 29-31 -> 21-22 us per convolution, layer 4 36 / 57 / 57 / 58 ->
+    // 33 / 54 / 52 / 54; the whole pass 8-22 crops: -30 .. -85 us (21-22 crops had been slower than 23: 762 against 671 us); (ii) layer 1 as
+    // soon as the 12-wave kernel's tiles (256 pixels, one block per CU) no longer fit ONE round of the chip - 33 crops: 264 blocks in two
+    // rounds 40-43 us against 28-30 us for the 64-wide form at three blocks per CU; up to 32 crops the 12-wave kernel stays (28 crops: 22-24
+    // against 25-27).  Layer 2 is a wash either way (+-2 us per convolution at 20 / 28 / 33 crops) and keeps the 12-wave kernel below ~400 tiles.
     const int tiles = launch_tiles(ctx, p);
-    if (p.W == 8) return nmt >= 12;     // layers 3 and 4 from 24 crops on (20 crops, layer 4: 12-wave forms 788 against 802 us per pass; layer 3 since it takes 64-wide tiles there)
+    if (p.W == 8) return true;
+    if (p.W == 32) return p.M / 256 > 256 || tiles >= 384;
     return tiles >= 384;
 }
 

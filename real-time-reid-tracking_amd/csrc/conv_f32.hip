@@ -628,7 +628,9 @@ void launch_bn(reid_ctx* ctx, const GemmParams& p0) {
     if (BN == 64 && ctx->f32_split_k && !p.a_scale && ctx->f32_conv != 2 && conv_f32_dma_supported(p) && !p.diag) {
         const int nk = p.R * p.S * (p.Cin / BK);
         int sk = 1;
-        while (sk < 4 && grid * sk * 2 <= 512 && nk % (sk * 2) == 0 && nk / (sk * 2) >= 8) sk *= 2;
+        // (round 6: up to 768 blocks - three fit a CU; at 512, a frame of 33 crops ran its two strided 3x3 convolutions as 264 unsplit blocks,
+        // 42-45 us each against 29-30 us for the 512 half-length blocks of 32 crops.  Launches of 256 and 512 tiles split as before.)
+        while (sk < 4 && grid * sk * 2 <= 768 && nk % (sk * 2) == 0 && nk / (sk * 2) >= 8) sk *= 2;
         // between the powers of two: three ways where two leave a third of the block slots empty, and a split for launches of
         // 257 .. 511 tiles, which used to run unsplit at full K length (a frame of 33 crops took 2.12 ms against 1.29 ms for 32).
         // Launches of exactly 256 or 512 tiles (passes of 64 crops) keep the form they had.

@@ -384,6 +384,7 @@ struct reid_ctx {
     int x3_sk_cap = 0;       // experiments: upper bound of the split-K factor of conv3x3_x3.hip's small launches (0 = the heuristic's)
     int split_x3_small = 2;  // ... and smaller launches: 2 (default) = where they measured faster than conv3x3_f16.hip's 12-wave kernel (conv3x3_x3_supported),
                              // 1 = every launch, 0 = none; K split over up to 8 blocks per tile (x3m16_tail: reduce-scatter)
+    int x3_l4_narrow_nmt = 31;  // conv3x3_x3.hip x3_wide_tiles: layer 4 on 64-wide tiles where its 128-wide launch fills the chip unevenly (0: never; split launches up to this many tile rows)
     int x3_narrow = 1;       // conv3x3_x3.hip, 64-wide tiles (four blocks per CU) beyond layer 1: bit 0 = the 16-wide maps (layer 2: 14.03 -> 13.87 ms per
                              // 1024-crop pass; default), bit 1 = the 8-wide ones (layers 3-4: 14.03 -> 14.70, off)
     int x3_unroll = 3;       // conv3x3_x3.hip: the form with a chunk's 27 steps unrolled (addresses, DMA offsets made once, waits immediates): 1 = the

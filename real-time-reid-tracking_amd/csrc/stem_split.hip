@@ -46,7 +46,7 @@ __device__ __forceinline__ unsigned split_pair(float x) {     // low 16 bits: xh
 template <bool U8>
 __global__ __launch_bounds__(512, 1) void stem_split_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            int tiles_per_block, float* __restrict__ out, f16* __restrict__ packed,
+                                                            int nseg, float* __restrict__ out, f16* __restrict__ packed,
                                                             int* __restrict__ fault) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const img_h = smem;                            // [RING][144] pixels of 4 f16
@@ -58,9 +58,10 @@ __global__ __launch_bounds__(512, 1) void stem_split_kernel(const void* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int cw = wave & 3, cb = wave >> 2;
-    const int nseg = (OUT_H / 2) / tiles_per_block;
+    // strips of an image: nseg of them, tiles [seg 64 / nseg, (seg + 1) 64 / nseg) - any nseg in 1 .. 64 (round 6: the launcher sizes the
+    // strips so that the blocks fill ONE round of the chip where they can)
     const int img = blockIdx.x / nseg, seg = blockIdx.x - img * nseg;
-    const int t0 = seg * tiles_per_block;
+    const int t0 = seg * (OUT_H / 2) / nseg, t1 = (seg + 1) * (OUT_H / 2) / nseg;
 
     for (int i = tid; i < 2 * RING * PITCH / 16; i += 512) ((uint4*)smem)[i] = uint4{0u, 0u, 0u, 0u};   // borders stay zero for good
     __syncthreads();
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void stem_split_kernel(const void* __restri
 
     // a strip that does not start at the top of the image first computes the tile above it, for its second row only
     const int t_first = t0 > 0 ? t0 - 1 : t0;
-    const int ntile = t0 + tiles_per_block - t_first;
+    const int ntile = t1 - t_first;
     float prev[8], pend = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) prev[e] = -INFINITY;                 // row -1 of the image: MaxPool2d pads with -inf
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void stem_split_kernel(const void* __restri
         commit(j, raw_a);
     }
     const int t_last = t_first + ntile - 1;
-    fetch(t_first + 2, raw_a);            // ntile >= 8
+    fetch(t_first + 2, raw_a);            // (a group past a short strip is fetched and never committed)
     __syncthreads();
     // the MFMAs of a tile: v = folded-BatchNorm output of this lane's 16 pixels (:252-253, no ReLU)
     auto mma = [&](int t) __attribute__((always_inline)) -> f32x16 {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void stem_split_kernel(const void* __restri
     }
     if (defer) epilogue(t_last, vkeep);
     __syncthreads();
-    finish_first_column(t0 + tiles_per_block - 1);
+    finish_first_column(t1 - 1);
     range_raise(fault, vmag);
 }
 
@@ -267,23 +268,31 @@ constexpr int SMEM = 2 * RING * PITCH + 2 * 64 * WROW + 2 * 4 * 64 * 4;
 int launch_stem_split(reid_ctx* ctx, const void* x, bool is_u8, int n, const float* wgt, const float* scale, const float* shift, float* out,
                       _Float16* packed) {
     ARG_CHECK(n >= 1);
-    // a block walks tiles_per_block tiles of one image (and redoes the tile above its strip): enough blocks for every CU when
-    // there are few images
-    int tpb = 64;
-    while (tpb > 8 && (long long)n * (64 / tpb) < 256) tpb >>= 1;
-    // just past a full round (33 .. 63 images at eight strips each: 264-504 blocks on 256 CUs, one block per CU) the second round is
-    // nearly empty: strips of four tiles (five with the redone one) in three rounds are 15 tile times against 18 (36 crops: 75 -> 6x us)
-    if (tpb == 8 && (long long)n * 8 > 256 && (long long)n * 16 <= 768) tpb = 4;
-    const int grid = n * (64 / tpb);
+    // A block walks one strip of one image (and redoes the tile above its strip), one block per CU.  Cost of a launch in fifths of a
+    // tile time (measured at 20-33 crops: a tile ~4.4 us when the chip is this empty, a block's prologue ~0.6 of one):
+    // rounds x (3 + 5 (strip length [+ 1 redone])).  Strips of ANY length (round 6; until then 64 / 2^k tiles): the strip count that
+    // minimises that cost, i.e. for a tracking-sized batch the largest one whose blocks still fit one round - 33 crops: 7 strips = 231
+    // blocks in one round instead of 16 = 528 in three (73.7 -> 46.8 us); 30 crops: 8 strips (42.5 us) cost what 16 did (42.0).
+    // The tiles are the same tiles: bit-identical output (tools/probes/embed_hash.py against the previous build, 12 pass sizes).
+    int nseg = 1;
+    if (n < 256) {
+        long long best = -1;
+        for (int s = 1; s <= 64; ++s) {
+            const long long rounds = ((long long)n * s + 255) / 256;
+            const long long cost = rounds * (3 + 5 * ((64 + s - 1) / s + (s > 1 ? 1 : 0)));
+            if (best < 0 || cost < best) { best = cost; nseg = s; }
+        }
+    }
+    const int grid = n * nseg;
     // per device, so not cached in a static: contexts of one process may sit on different GPUs
     if (is_u8) HIP_TRY(hipFuncSetAttribute((const void*)stem_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     else HIP_TRY(hipFuncSetAttribute((const void*)stem_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     const double flops = 2.0 * n * OUT_H * OUT_W * 64 * 147.0;
     const double bytes = (double)n * IMG_H * IMG_W * 3 * (is_u8 ? 1.0 : 4.0) + (double)n * OUT_H * OUT_W * 64 * (packed ? 2.0 : 1.0) + 64 * 147 * 4.0;
     prof_begin(ctx, REID_K_CONV_GEMM, flops, bytes);
-    if (is_u8) hipLaunchKernelGGL((stem_split_kernel<true>), dim3(grid), dim3(512), SMEM, ctx->stream, x, wgt, scale, shift, tpb, out, packed,
+    if (is_u8) hipLaunchKernelGGL((stem_split_kernel<true>), dim3(grid), dim3(512), SMEM, ctx->stream, x, wgt, scale, shift, nseg, out, packed,
                                   ctx->fault);
-    else hipLaunchKernelGGL((stem_split_kernel<false>), dim3(grid), dim3(512), SMEM, ctx->stream, x, wgt, scale, shift, tpb, out, packed, ctx->fault);
+    else hipLaunchKernelGGL((stem_split_kernel<false>), dim3(grid), dim3(512), SMEM, ctx->stream, x, wgt, scale, shift, nseg, out, packed, ctx->fault);
     prof_end(ctx);
     LAUNCH_CHECK();
     return REID_OK;
