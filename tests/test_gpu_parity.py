@@ -1041,14 +1041,19 @@ def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, c
                                     % (unexpected, [float(gap[r]) for r in unexpected]))
 
 
-@pytest.mark.parametrize("n", [1, 3, 7, 30, 33, 48])
+@pytest.mark.parametrize("n", [1, 3, 7, 21, 30, 33, 48, 62, 66, 130])
 def test_small_pass_split_k_forms_agree_and_are_position_invariant(eng_w0, n):
     """Round 6: small and mid-size passes run layer 4 (from 24 crops), layer 3 (from ~48) and large-enough 16- / 32-wide maps on
     conv3x3_x3.hip's kernels with the K loop split over 2-4 blocks per tile, reduced as a reduce-scatter (x3m16_tail: partials as 16-byte
     units, an arrival counter per tile, every block finishes a column slice, own slice in LDS).  Against the 12-wave forms of
     conv3x3_f16.hip that served these sizes until round 5 (debug switch split_x3_small = 0): same three products per multiply in another
     summation order - agreement to 5e-6 of the embedding's scale - and, the property that must hold exactly: copies of a crop inside
-    one pass give bit-identical embeddings wherever they sit (another tile, another column slice, another image pair)."""
+    one pass give bit-identical embeddings wherever they sit (another tile, another column slice, another image pair).
+    The sizes sit on both sides of the steps of the pass-size staircase (profiles/r06_pass_size_sweep_8_64.txt) where the launch rules
+    change form: 21 / 30 (layers 3-4 on these kernels at every size), 33 / 48 / 62 (layer 1 leaves the 12-wave kernel, the stem's strips
+    fill one round, layer 4 takes 64-wide tiles), 66 (two ways split, wide again), 130 (unsplit, 64-wide because the last layer of
+    128-wide blocks would cover 4 of 256 CUs).  Layer 4's tile width (switch x3_l4_narrow_nmt = 0: always 128 wide) must not change a
+    bit where the K loop is not split, and stays within 5e-6 where the two widths split differently."""
     eng, _ = eng_w0
     base = synth.smooth_crops_u8(max(2, (n + 1) // 2), 90 + n)
     ids = np.arange(n) % len(base)                       # every crop at least twice when n >= 2 (odd n: one image pair is ragged)
@@ -1060,11 +1065,19 @@ def test_small_pass_split_k_forms_agree_and_are_position_invariant(eng_w0, n):
         first = np.asarray([np.flatnonzero(ids == c)[0] for c in range(len(base)) if (ids == c).any()])
         lut = {int(ids[f]): got[f] for f in first}
         assert all(np.array_equal(got[i], lut[int(ids[i])]) for i in range(n))
+        eng.debug_switch("x3_l4_narrow_nmt", 0)
+        wide = eng.embed_u8(crops)
+        if n > 128:
+            assert np.array_equal(got, wide)
+        else:
+            assert np.abs(got - wide).max() <= 5e-6 * np.abs(wide).max()
+        eng.debug_switch("x3_l4_narrow_nmt", 31)
         eng.debug_switch("split_x3_small", 0)
         old = eng.embed_u8(crops)
         assert np.abs(got - old).max() <= 5e-6 * np.abs(old).max()
         assert eng.fault_bits() == 0
     finally:
+        eng.debug_switch("x3_l4_narrow_nmt", 31)
         eng.debug_switch("split_x3_small", 2)
         eng.set_precision(0)
 
