@@ -714,13 +714,13 @@ static int seres18_chain_layer4(reid_ctx* ctx, int n, const Se18Block& ka, const
     const size_t part = (size_t)nmt * nnt * SK * 256 * 128;          // floats of one convolution's split-K partials
     REID_TRY(ctx_ws(ctx, "chain.splitk", 4 * part * sizeof(float), (void**)&skws));
     const bool fresh = ctx->ws.find("chain.cnt") == ctx->ws.end();
-    REID_TRY(ctx_ws(ctx, "chain.cnt", (4 * 512 + 64 + 8 * 64) * sizeof(int), (void**)&cnt));
-    if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, (4 * 512 + 64 + 8 * 64) * sizeof(int), ctx->stream));
+    REID_TRY(ctx_ws(ctx, "chain.cnt", (4 * 1024 + 64 + 8 * 64) * sizeof(int), (void**)&cnt));
+    if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, (4 * 1024 + 64 + 8 * 64) * sizeof(int), ctx->stream));
     ChainParams cp;
     memset(&cp, 0, sizeof(cp));
     cp.n_img = n;
     cp.flags = ctx->chain;
-    cp.counters = cnt + 4 * 512;
+    cp.counters = cnt + 4 * 1024;
     cp.fault = ctx->fault;
     auto conv = [&](int idx, const _Float16* a, int cin, const float* wgt, const float* scale, const float* shift, const float* res, int relu,
                     float* stats_out, _Float16* pack) -> int {
@@ -736,7 +736,7 @@ static int seres18_chain_layer4(reid_ctx* ctx, int n, const Se18Block& ka, const
         q.acc_scale = 1.0f / 2048.0f;
         q.zero_page = ctx->se18.zero_page;
         q.pack16 = pack; q.pack_from = 0;
-        q.split_k = SK; q.splitk_ws = skws + (size_t)idx * part; q.splitk_cnt = cnt + idx * 512;
+        q.split_k = SK; q.splitk_ws = skws + (size_t)idx * part; q.splitk_cnt = cnt + idx * 1024;      // x3m16_tail: [tile] arrivals, [512 + tile] readers done
         q.fault = ctx->fault;
         return REID_OK;
     };

@@ -706,10 +706,10 @@ __device__ __forceinline__ void x3m16_tail(const Gemm16Params& p, f32x4 (&acc)[4
         // resets the two counters for the next launch
         __syncthreads();
         if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(p.splitk_cnt + 256 + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int old = __hip_atomic_fetch_add(p.splitk_cnt + 512 + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == SK - 1) {
                 __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.splitk_cnt + 256 + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.splitk_cnt + 512 + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1681,9 +1681,9 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
 // few output tiles (a tracking frame, a camera group): the real 32-channel chunks split over sk blocks per tile, up to two blocks for
 // every CU (x3m16_tail hands the tile's sixteen-column units out to the sk blocks: sk divides their number).  Eight ways lose to four -
 // twice the partial traffic: 30 crops 882 -> 1175 us per pass - so four is the cap.
-static int x3_split(const reid_ctx* ctx, int tiles, int ncr, bool wide) {
+static int x3_split(const reid_ctx* ctx, int tiles, int ncr, bool wide, int slots = 512) {
     int sk = 1;
-    while (ctx->f16_split_k && tiles * sk * 2 <= 512 && ncr % (sk * 2) == 0 && sk * 2 <= (wide ? 8 : 4)) sk *= 2;
+    while (ctx->f16_split_k && tiles * sk * 2 <= slots && ncr % (sk * 2) == 0 && sk * 2 <= (wide ? 8 : 4)) sk *= 2;
     const int cap = ctx->x3_sk_cap > 0 ? ctx->x3_sk_cap : 4;
     return sk > cap ? cap : sk;
 }
@@ -1718,9 +1718,16 @@ static bool x3_wide_tiles(const reid_ctx* ctx, const Gemm16Params& p) {
         const int t128 = nmt * 4, s128 = x3_split(ctx, t128, ncr, true);
         if (s128 == 4 && t128 * s128 > 256 && nmt <= ctx->x3_l4_narrow_nmt) return false;
         if (s128 == 1 && t128 % 256 != 0 && t128 % 256 <= 128) return false;
+        // 65 .. 96 crops: two ways split the 128-wide launch has 264 .. 384 blocks of eight chunks (140 us per convolution at 66 crops against
+        // 110 at 64, where 512 blocks of four chunks fill every CU twice); 64-wide tiles two ways split are 528 .. 768 blocks of the same
+        // four-chunk size, three to a CU (x3_l4_slots) - same K halves per output element
+        if (s128 == 2 && t128 > 128 && t128 * 4 <= 768) return false;
     }
     return true;
 }
+
+// block slots the split count may fill: two blocks per CU for the 128-wide tile, and for layer 4's 64-wide tile three (x3_wide_tiles)
+static int x3_slots(const Gemm16Params& p, bool wide) { return (!wide && p.W == 8 && p.N == 512) ? 768 : 512; }
 
 template <int TW, int IMGS>
 int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
@@ -1728,14 +1735,15 @@ int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {
     const int nmt = (p.M + 255) / 256;
     const bool wide = x3_wide_tiles(ctx, p);
     const int tiles = nmt * (wide ? p.N / 128 : p.N / 64);
-    const int sk = x3_split(ctx, tiles, p.Cin / 3 / 32, wide);
+    const int sk = x3_split(ctx, tiles, p.Cin / 3 / 32, wide, x3_slots(p, wide));
     if (sk > 1) {
         float* ws;
         int* cnt;
         const bool fresh = ctx->ws.find("x3.splitk_cnt") == ctx->ws.end();
+        ARG_CHECK(tiles <= 512);      // [tile] arrivals, [512 + tile] readers done: a split launch has at most 768 / 2 tiles (x3_slots)
         REID_TRY(ctx_ws(ctx, "x3.splitk_ws", (size_t)tiles * sk * 256 * (wide ? 128 : 64) * sizeof(float), (void**)&ws));
-        REID_TRY(ctx_ws(ctx, "x3.splitk_cnt", 512 * sizeof(int), (void**)&cnt));   // [tile] arrivals, [256 + tile] readers done (tiles <= 128 here)
-        if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, 512 * sizeof(int), ctx->stream));
+        REID_TRY(ctx_ws(ctx, "x3.splitk_cnt", 1024 * sizeof(int), (void**)&cnt));
+        if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, 1024 * sizeof(int), ctx->stream));
         p.split_k = sk; p.splitk_ws = ws; p.splitk_cnt = cnt;
     } else {
         p.split_k = 1;
@@ -1794,7 +1802,9 @@ bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p) {
     const int tiles = launch_tiles(ctx, p);
     if (p.W == 8) return true;
     if (p.W == 32) return p.M / 256 > 256 || tiles >= 384;
-    return tiles >= 384;
+    // layer 2 (16-wide maps): the 12-wave kernel splits K two ways up to 128 tiles (64 crops: 39 us against 42 here); past that it runs
+    // unsplit on half the chip - 66 / 80 crops: 55-59 us per convolution against 43-44 here (96 crops and up were here already)
+    return p.M / 256 > 128 || tiles >= 384;
 }
 
 int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p0) {
