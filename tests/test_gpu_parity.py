@@ -983,7 +983,7 @@ def test_f16_path_small_and_odd_batches(eng_w0, n):
 #              summation order than conv3x3_f16.hip's 12-wave kernel that served them before)
 # Every other combination reproduces all 256 rows.
 CONFIG1_RAND0_KNOWN_SUBNOISE_ROWS = {(0, 1024): {84}, (2, 64): {84}}
-@pytest.mark.parametrize("chunk", [64, 1024])   # four passes of 64 crops (the library default of rounds 1-3) / one pass of 256
+@pytest.mark.parametrize("chunk", [40, 64, 130, 1024])   # passes of 40 (+ 16) and 130 + 126 crops: the small- and mid-size launch rules of round 6; four passes of 64 (the library default of rounds 1-3); one pass of 256
 @pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("tag,crops_fn,seed", [("rand0", synth.crops_u8, 0), ("smooth5", synth.smooth_crops_u8, 5)])
 def test_config1_against_reference_vectors(eng_w0, golden_dir, precision, tag, crops_fn, seed, chunk):
