@@ -459,7 +459,7 @@ def run_tracking(job, args):
     counts = np.clip(rng.poisson(30, frames), 1, 80)
     pool = synth.ragged_crops_u8(256, seed=3)
     from reid_amd.tracking import ShardedCameraStream
-    stream = ShardedCameraStream(eng, comm, 0.15, 100, match_stream=bool(args.match_stream))    # MAX_DIST / NN_BUDGET, deep_sort.yaml:3,9
+    stream = ShardedCameraStream(eng, comm, 0.15, 100, match_stream=bool(args.match_stream) and world == 1)    # MAX_DIST / NN_BUDGET, deep_sort.yaml:3,9
     metric = stream.metric
     tracks = list(range(40))
     metric.partial_fit(rng.normal(size=(40 * 100, 512)).astype(np.float32), np.repeat(tracks, 100), tracks)

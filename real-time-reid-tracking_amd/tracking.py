@@ -258,10 +258,13 @@ class ShardedCameraStream:
     arguments and results are in DETECTION order, the mapping to rows of the gathered slot (`parallel.frame_rows`) stays inside.
     `engine` carries the rank's communicator (`RcclComm`); with world 1 this is `CameraStream` on an existing engine."""
 
-    def __init__(self, engine, comm, max_dist=0.15, budget=100, metric="cosine", max_tracks=4096, match_stream=True):
+    def __init__(self, engine, comm, max_dist=0.15, budget=100, metric="cosine", max_tracks=4096, match_stream=None):
         self.eng, self.rank, self.world = engine, int(comm.rank), int(comm.world)
         self._own = False
-        _two_streams(self, match_stream)      # (the all-gather stays on the compute stream, behind the forward; the slot's readers wait for it)
+        # match_stream=None: on for one rank.  With several ranks the all-gather stays on the compute stream, behind the forward, and the
+        # slot's readers wait for it (reid_frame_gather re-records the slot's event) - exercised with loop-back ranks on one device
+        # (tests/test_gpu_parity.py), never yet on several physical GPUs, so it is opt-in there.
+        _two_streams(self, self.world == 1 if match_stream is None else match_stream)
         self.max_dist = max_dist
         self.metric = NearestNeighborDistanceMetric(metric, max_dist, budget, max_tracks=max_tracks, engine=engine)
         self._frame = 0

@@ -1494,7 +1494,8 @@ def test_loopback_ranks_tracking_frames(eng_w0, world):
             one.metric.close()
 
         def rank_fn(r):
-            st = ShardedCameraStream(engs[r], parallel.RcclComm.attach(engs[r]), 0.4, budget=3, max_tracks=16)
+            st = ShardedCameraStream(engs[r], parallel.RcclComm.attach(engs[r]), 0.4, budget=3, max_tracks=16,
+                                      match_stream=(r % 2 == 0))     # both forms of the cost / update stages behind the all-gather
             try:
                 return drive(st, lambda s, n, nxt: s.step(n, tracks, boxes[:4], boxes[:n], nxt))
             finally:
