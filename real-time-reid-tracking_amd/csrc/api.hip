@@ -612,6 +612,10 @@ static bool conv_split_path(reid_ctx* ctx, int n, int H, int W, int Cin, int Cou
     q.M = n * q.Ho * q.Wo; q.N = Cout;
     const bool halo = R == 3 && S == 3 && stride == 1 && pad == 1 && conv3x3_f16_supported(q);
     const bool enough = halo || (Cout % 128 == 0 && (long long)(q.M / 256) * (Cout / 128) >= (R == 3 ? ctx->split_gemm_min_tiles * 3 / 4 : ctx->split_gemm_min_tiles));   // (layer 3's strided 3x3 at 120 crops: 107 -> 70 us; at 64 crops 49 against 67: stays)
+    if (q.M % 128 == 0 && !enough && !halo && ctx->conv_x3s == 2) {      // experiment (switch conv_x3s = 2): the small launches too on conv_x3s_kernel, so
+        q.split_terms = ctx->split_terms; q.ldb = (long long)R * S * q.Cin; q.ldc = Cout;   // that a layer's arithmetic does not depend on the batch size - a 30-crop
+        return conv_x3s_supported(ctx, q);                                                 // frame pays 8 us for it (1x1: 13-20 us against 7-15 in exact fp32)
+    }
     return q.M % 128 == 0 && enough;
 }
 
@@ -677,8 +681,11 @@ int conv_gemm(reid_ctx* ctx, int amode, const void* x, int n, int H, int W, int 
                 q.pack_from = pack_from;
                 *packed_written = true;
             }
-            return halo ? launch_conv3x3_split(ctx, q, REID_K_CONV_GEMM, flops, bytes)
-                        : launch_gemm_f16_split(ctx, q, REID_K_CONV_GEMM, flops, bytes);
+            if (halo) return launch_conv3x3_split(ctx, q, REID_K_CONV_GEMM, flops, bytes);
+            // strided 3x3 / 1x1: conv_x3s_kernel (round 6) wherever gemm_f16.hip's SPLIT build served - 1024 crops: 440 / 109 / 349 / 76 / 219 ->
+            // 333 / 103 / 246 / 60 / 156 us for the five launches of a pass, 120 crops: 185 -> 180 us in total
+            if (conv_x3s_supported(ctx, q)) return launch_conv_x3s(ctx, q, REID_K_CONV_GEMM, flops, bytes);
+            return launch_gemm_f16_split(ctx, q, REID_K_CONV_GEMM, flops, bytes);
         }
     }
     if (amode == A_IM2COL && ctx->f32_conv && conv_f32_supported(p)) return launch_conv_f32(ctx, p, REID_K_CONV_GEMM, flops, bytes);

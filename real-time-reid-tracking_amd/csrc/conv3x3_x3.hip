@@ -1678,6 +1678,215 @@ __global__ __launch_bounds__(256, 2) void lin_x3_kernel(const Gemm16Params p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Strided 3x3 and 1x1 convolutions of the fp32-class mode (SERes18_IBN.py:120-128 conv1 of a down-sampling block, :250-276 the shortcut
+// convolutions) - round 6.  They have no halo a block could keep: an output pixel's taps are other pixels' taps only every second
+// column.  Until now they ran as gemm_f16.hip's SPLIT im2col build (12 waves, 32x32x16 MFMAs, no split-K form: pipe busy 0.245 at 1024
+// crops) and, for tracking-sized batches, on the EXACT-fp32 kernel (a layer's arithmetic depended on the batch size; 5 of a 30-crop
+// frame's 35 launches, 103 us).  Here: lin_x3_kernel's block - 256 x 128 tile, four waves, two blocks per CU, three A slots and four
+// weight slots three steps ahead, wh fragments kept for the third product - with the A rows GATHERED: row m of the tile is output pixel
+// (img, oy, ox), step (tap, chunk) reads 64 bytes of input pixel (oy st + r - pad, ox st + s - pad) of the packed [xh | xl'] image; the
+// per-lane part of the address is the pixel of tap (0, 0), the tap and chunk offsets are scalar, a tap outside the image is an offset
+// past the descriptor (zeros).  K order: taps outer, 32-channel chunks inner, the three products of a chunk in lin_x3's order.
+// Split-K over the (tap, chunk) steps with x3m16_tail's reduce-scatter; the convolution epilogue (folded BatchNorm, ReLU from
+// relu_from, column sums, [yh | yl'] store from pack_from) is x3m16_tail<16, 1, BN, false>: rows in natural NHWC order.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_x3s_kernel(const Gemm16Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = 4, TN = BN / 16, BJ = BN / 64;
+    constexpr int A_SLOT = 256 * 64, B_SLOT = BN * 64;
+    static_assert(2 * (3 * A_SLOT + 4 * B_SLOT) <= 160 * 1024, "two blocks per CU");
+    static_assert(TN == 8, "fragment reads below are written for the 128-wide tile");
+    __shared__ __attribute__((aligned(16))) char lds[3 * A_SLOT + 4 * B_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int nnt = p.N / BN;
+    const int SK = p.split_k > 1 ? p.split_k : 1;
+    int mtile, ntile, tile_id, ksplit;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        tile_id = L / SK;
+        ksplit = L - tile_id * SK;
+        mtile = tile_id / nnt;
+        ntile = tile_id - mtile * nnt;
+    }
+    const int m_blk = mtile * 256, n_blk = ntile * BN;
+    const int m_valid = p.M - m_blk < 256 ? p.M - m_blk : 256;
+    const int C = p.Cin / 3;                      // real input channels; a pixel of A is [xh (C) | xl' (C)], a tap of a weight row [wh 2^11 | wh | wl'] (C each)
+    const int ncr = C / 32;
+    const int nq = p.R * p.S * ncr;               // (tap, chunk) steps of the whole K loop; this block: [q0, q1)
+    const int q0 = ksplit * nq / SK, q1 = (ksplit + 1) * nq / SK;      // (nq need not divide: shares differ by one step)
+    const int pix_b = 2 * C * 2;                  // bytes of an input pixel
+    const unsigned a32 = (unsigned)(uintptr_t)lds, b32 = a32 + 3 * A_SLOT;
+
+    const int n_img = p.M / (p.Ho * p.Wo);
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((long long)n_img * p.H * p.W * pix_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long long)n_blk * p.ldb), 0, (int)((long long)BN * p.ldb * 2), 0x00020000);
+    int av[4], rmask[4], cmask[4], wv[BJ];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                 // this wave's A pieces: rows (4 wm + j) 16 .. + 16 of the tile, four lanes per row
+        const int row = (wm * 4 + j) * 16 + (lane >> 2);
+        const int cg = (lane & 3) ^ (((row >> 3) & 1) << 1);
+        const int m = m_blk + row;
+        const int img = m / (p.Ho * p.Wo), rem = m - img * (p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        av[j] = ((img * p.H + iy0) * p.W + ix0) * pix_b + cg * 16;          // tap (0, 0); may lie outside (then its mask bit is clear)
+        int rm = 0, cm = 0;
+        if (row < m_valid) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                rm |= ((unsigned)(iy0 + t) < (unsigned)p.H && t < p.R) ? 1 << t : 0;
+                cm |= ((unsigned)(ix0 + t) < (unsigned)p.W && t < p.S) ? 1 << t : 0;
+            }
+        }
+        rmask[j] = rm; cmask[j] = cm;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (wm * BJ + j) * 16 + (lane >> 2);
+        const int cg = (lane & 3) ^ (((row >> 3) & 1) << 1);
+        wv[j] = (int)(((long long)row * p.ldb + cg * 8) * 2);
+    }
+    // step q = (tap t = (r, s), chunk c): scalar state of the NEXT request, advanced as requests are made (A parts and weight tiles of a
+    // step are requested in the order wh, h, wl', l as in lin_x3_kernel, so one running (t, r, s, c) serves all four)
+    auto issue_a = [&](int r, int s, int c, int part, int slot) __attribute__((always_inline)) {      // part 0: xh, 1: xl'
+        const int tap_b = (r * p.W + s) * pix_b, soff = part * C * 2 + c * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = ((rmask[j] >> r) & 1) && ((cmask[j] >> s) & 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, LPTR(lds + slot * A_SLOT + (wm * 4 + j) * 1024), 16, in ? av[j] + tap_b : 0x7fffff00, soff, 0, 0);
+        }
+    };
+    auto issue_w = [&](int t, int c, int kind, int slot) __attribute__((always_inline)) {   // kind 0: the wh tile, 1: the wl' tile
+        const int soff = (t * 3 + (kind == 0 ? 1 : 2)) * C * 2 + c * 64;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, LPTR(lds + 3 * A_SLOT + slot * B_SLOT + (wm * BJ + j) * 1024), 16, wv[j], soff, 0, 0);
+    };
+    int nt = q0 / ncr, nc = q0 - nt * ncr, nr = nt / p.S, ns = nt - nr * p.S;        // the step whose operands are requested next
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (++nc == ncr) {
+            nc = 0; ++nt;
+            if (++ns == p.S) { ns = 0; ++nr; }
+        }
+    };
+    issue_w(nt, nc, 0, 0);
+    issue_a(nr, ns, nc, 0, 0);
+    issue_w(nt, nc, 1, 1);
+    issue_a(nr, ns, nc, 1, 1);
+    advance();
+
+    const int pj = pi16(l16);
+    const unsigned swz = (unsigned)((lq ^ (((pj >> 3) & 1) << 1)) * 16);
+    unsigned aa[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) aa[a] = a32 + (unsigned)((wm * 64 + a * 16 + pj) * 64) + swz;
+    const unsigned bx = b32 + (unsigned)(pj * 64) + swz;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    half8 fa[TM], fb[TN], fw[TN];
+    int sa_h = 0, sa_l = 1;
+    const half8 k2048 = {(f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f, (f16)2048.0f};
+    for (int q = q0; q < q1; ++q) {
+        const bool last = q + 1 == q1;
+        const int s0 = (q - q0) * 2;              // weight tiles 2 i (wh) and 2 i + 1 (wl') of this block's step i in ring slots (tile & 3)
+#define MMA(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fb[b]), "v"(fa[a]))   /* weights first: D^T (x3m16_tail) */
+#define MMAW(a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(fw[b]), "v"(fa[a]))
+#define LIN_B_READS(f, ba)                              \
+    LDS_READ(f[0], ba, 0);     LDS_READ(f[1], ba, 1024); \
+    LDS_READ(f[2], ba, 2048);  LDS_READ(f[3], ba, 3072); \
+    LDS_READ(f[4], ba, 4096);  LDS_READ(f[5], ba, 5120); \
+    LDS_READ(f[6], ba, 6144);  LDS_READ(f[7], ba, 7168)
+        {   // ---- product 0: xh . (wh 2^11); needs wh(q), h(q); behind them: wl'(q) [BJ], l(q) [4]
+            wait_vm_imm<BJ + 4>();
+            RAW_BARRIER();
+            if (!last) {
+                issue_w(nt, nc, 0, (s0 + 2) & 3);
+                issue_a(nr, ns, nc, 0, sa_h == 0 ? 2 : sa_h - 1);
+            }
+            const unsigned ao = (unsigned)(sa_h * A_SLOT), ba = bx + (unsigned)((s0 & 3) * B_SLOT);
+            LDS_READ(fa[0], aa[0] + ao, 0);
+            LDS_READ(fa[1], aa[1] + ao, 0);
+            LDS_READ(fa[2], aa[2] + ao, 0);
+            LDS_READ(fa[3], aa[3] + ao, 0);
+            LIN_B_READS(fw, ba);
+#define STEP0(b, n)                                                                  \
+    do {                                                                             \
+        lgkm_wait1<n>(fw[b]);                                                        \
+        fb[b] = fw[b] * k2048;                                                       \
+        asm volatile("s_nop 3" : "+v"(fb[b]));   /* VALU write -> inline-asm MFMA read: wait states the compiler does not count (lin_x3_kernel) */ \
+        MMA(0, b); MMA(1, b); MMA(2, b); MMA(3, b);                                  \
+    } while (0)
+            lgkm_wait1<8>(fa[3]);
+            asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]));
+            STEP0(0, 7); STEP0(1, 6); STEP0(2, 5); STEP0(3, 4); STEP0(4, 3); STEP0(5, 2); STEP0(6, 1); STEP0(7, 0);
+#undef STEP0
+        }
+        {   // ---- product 1: xh . wl'; needs wl'(q); behind it: l(q) [4], wh(q+1) + h(q+1) [BJ + 4]
+            if (last) wait_vm_imm<4>(); else wait_vm_imm<BJ + 8>();
+            RAW_BARRIER();
+            if (!last) issue_w(nt, nc, 1, (s0 + 3) & 3);
+            const unsigned ba = bx + (unsigned)(((s0 + 1) & 3) * B_SLOT);
+            LIN_B_READS(fb, ba);
+            lgkm_wait1<7>(fb[0]); MMA(0, 0);
+            lgkm_wait1<6>(fb[1]); MMA(0, 1);
+            lgkm_wait1<5>(fb[2]); MMA(0, 2);
+            lgkm_wait1<4>(fb[3]); MMA(0, 3);
+            lgkm_wait1<3>(fb[4]); MMA(0, 4);
+            lgkm_wait1<2>(fb[5]); MMA(0, 5);
+            lgkm_wait1<1>(fb[6]); MMA(0, 6);
+            lgkm_wait1<0>(fb[7]); MMA(0, 7);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(1, b);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(2, b);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMA(3, b);
+        }
+        {   // ---- product 2: xl' . wh (the wh fragments are in registers); needs l(q); behind it: wh(q+1) + h(q+1) [BJ + 4], wl'(q+1) [BJ]
+            if (last) wait_vm_imm<0>(); else wait_vm_imm<2 * BJ + 4>();
+            RAW_BARRIER();
+            if (!last) {
+                issue_a(nr, ns, nc, 1, sa_h);
+                advance();
+            }
+            const unsigned ao = (unsigned)(sa_l * A_SLOT);
+            LDS_READ(fa[0], aa[0] + ao, 0);
+            LDS_READ(fa[1], aa[1] + ao, 0);
+            LDS_READ(fa[2], aa[2] + ao, 0);
+            LDS_READ(fa[3], aa[3] + ao, 0);
+            lgkm_wait1<3>(fa[0]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMAW(0, b);
+            lgkm_wait1<2>(fa[1]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMAW(1, b);
+            lgkm_wait1<1>(fa[2]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMAW(2, b);
+            lgkm_wait1<0>(fa[3]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) MMAW(3, b);
+        }
+#undef LIN_B_READS
+#undef MMAW
+#undef MMA
+        const int nh = sa_h == 0 ? 2 : sa_h - 1;
+        sa_l = sa_h;
+        sa_h = nh;
+    }
+    x3m16_tail<16, 1, BN, false>(p, acc, lds, tid, wm, mtile, n_blk, tile_id, ksplit, SK);
+#endif
+}
+
 // few output tiles (a tracking frame, a camera group): the real 32-channel chunks split over sk blocks per tile, up to two blocks for
 // every CU (x3m16_tail hands the tile's sixteen-column units out to the sk blocks: sk divides their number).  Eight ways lose to four -
 // twice the partial traffic: 30 crops 882 -> 1175 us per pass - so four is the cap.
@@ -1832,6 +2041,42 @@ int launch_chain(reid_ctx* ctx, const ChainParams& cp, int W) {
     return REID_OK;
 }
 #endif
+
+// ---- strided 3x3 / 1x1 convolutions (conv_x3s_kernel)
+bool conv_x3s_supported(const reid_ctx* ctx, const Gemm16Params& p) {
+    if (!ctx->conv_x3s || ctx->split_x3 < 2 || p.split_terms != 3 || p.Cin % 96 != 0 || p.N % 128 != 0 || p.M % 128 != 0) return false;
+    if (!((p.R == 1 || p.R == 3) && p.S == p.R && p.pad == (p.R - 1) / 2 && (p.stride == 1 || p.stride == 2))) return false;
+    if (p.R == 3 && p.stride == 1) return false;                       // the halo kernels' case
+    if (p.relu_from % 16 != 0 || (p.pack16 && p.pack_from % 32 != 0)) return false;
+    const long long a_bytes = (long long)(p.M / (p.Ho * p.Wo)) * p.H * p.W * (p.Cin / 3) * 4;
+    return a_bytes < 0x7f000000ll && 128ll * p.ldb * 2 < 0x7f000000ll && 256ll * p.ldc * 4 < 0x7f000000ll && (long long)p.M * 2 < 0x7f000000ll;
+}
+
+int launch_conv_x3s(reid_ctx* ctx, const Gemm16Params& p0, int kind, double flops, double bytes) {
+    Gemm16Params p = p0;
+    p.fault = ctx->fault;
+    p.ablate = 0;
+    const int tiles = ((p.M + 255) / 256) * (p.N / 128), nq = p.R * p.S * (p.Cin / 3 / 32);
+    int sk = 1;                      // (tap, chunk) steps split over up to x3s_sk_cap blocks per tile while the launch fits the 512 block slots
+    while (ctx->f16_split_k && tiles * sk * 2 <= 512 && nq / (sk * 2) >= 2 && sk * 2 <= ctx->x3s_sk_cap) sk *= 2;
+    if (sk > 1) {
+        float* ws;
+        int* cnt;
+        const bool fresh = ctx->ws.find("x3.splitk_cnt") == ctx->ws.end();
+        ARG_CHECK(tiles <= 512);
+        REID_TRY(ctx_ws(ctx, "x3.splitk_ws", (size_t)tiles * sk * 256 * 128 * sizeof(float), (void**)&ws));
+        REID_TRY(ctx_ws(ctx, "x3.splitk_cnt", 1024 * sizeof(int), (void**)&cnt));
+        if (fresh) HIP_TRY(hipMemsetAsync(cnt, 0, 1024 * sizeof(int), ctx->stream));
+        p.split_k = sk; p.splitk_ws = ws; p.splitk_cnt = cnt;
+    } else {
+        p.split_k = 1;
+    }
+    prof_begin(ctx, kind, flops, bytes);
+    hipLaunchKernelGGL((conv_x3s_kernel<128>), dim3(tiles * sk), dim3(256), 0, ctx->stream, p);
+    prof_end(ctx);
+    LAUNCH_CHECK();
+    return REID_OK;
+}
 
 // ---- dense form (Swin linears, fp32-class mode): launched for EVERY batch size of a layer it supports - which arithmetic a layer runs
 // in must not depend on how many images a pass holds

@@ -22,7 +22,7 @@ const Switch kSwitches[] = {
     {"swin_attn_split", &reid_ctx::swin_attn_split}, {"swin_two_linear", &reid_ctx::swin_two_linear},
     {"f16_loader_waves", &reid_ctx::f16_loader_waves}, {"f16_halo", &reid_ctx::f16_halo}, {"f16_stem_fused", &reid_ctx::f16_stem_fused},
     {"f16_se_tail", &reid_ctx::f16_se_tail}, {"f16_c64", &reid_ctx::f16_c64}, {"swin_chunk_cap", &reid_ctx::swin_chunk_cap},
-    {"split_x3", &reid_ctx::split_x3}, {"x3_ablate", &reid_ctx::x3_ablate}, {"x3_unroll", &reid_ctx::x3_unroll}, {"x3_narrow", &reid_ctx::x3_narrow}, {"x3_l4_narrow_nmt", &reid_ctx::x3_l4_narrow_nmt}, {"split_x3_small", &reid_ctx::split_x3_small}, {"split_x3_min_blocks", &reid_ctx::split_x3_min_blocks}, {"f32_dist_bk16", &reid_ctx::f32_dist_bk16}, {"lin_x3", &reid_ctx::lin_x3},
+    {"split_x3", &reid_ctx::split_x3}, {"x3_ablate", &reid_ctx::x3_ablate}, {"x3_unroll", &reid_ctx::x3_unroll}, {"x3_narrow", &reid_ctx::x3_narrow}, {"conv_x3s", &reid_ctx::conv_x3s}, {"x3s_sk_cap", &reid_ctx::x3s_sk_cap}, {"x3_l4_narrow_nmt", &reid_ctx::x3_l4_narrow_nmt}, {"split_x3_small", &reid_ctx::split_x3_small}, {"split_x3_min_blocks", &reid_ctx::split_x3_min_blocks}, {"f32_dist_bk16", &reid_ctx::f32_dist_bk16}, {"lin_x3", &reid_ctx::lin_x3},
     {"host_pipeline", &reid_ctx::host_pipeline}, {"x3_sk_cap", &reid_ctx::x3_sk_cap}, {"chain", &reid_ctx::chain}, {"split_gemm_min_tiles", &reid_ctx::split_gemm_min_tiles},
 };
 }  // namespace

@@ -199,6 +199,8 @@ bool conv3x3_x3_supported(const reid_ctx* ctx, const Gemm16Params& p);   // conv
 int launch_conv3x3_x3(reid_ctx* ctx, const Gemm16Params& p);
 bool lin_x3_supported(const reid_ctx* ctx, const Gemm16Params& p);        // conv3x3_x3.hip: the dense form (Swin linears of stages 3-4, fp32-class mode)
 int launch_lin_x3(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);
+bool conv_x3s_supported(const reid_ctx* ctx, const Gemm16Params& p);      // conv3x3_x3.hip: strided 3x3 / 1x1 convolutions, fp32-class mode
+int launch_conv_x3s(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);
 int launch_gemm_f16_split(reid_ctx* ctx, const Gemm16Params& p, int kind, double flops, double bytes);   // SPLIT build of gemm_f16 (im2col: strided / 1x1)
 bool two_linear_supported(const reid_ctx*, long long T, int C, int hid);
 int launch_two_linear(reid_ctx*, const _Float16* a16, long long T, int C, int hid, const float* w1, const float* b1, const float* w2,
@@ -384,6 +386,8 @@ struct reid_ctx {
     int x3_sk_cap = 0;       // experiments: upper bound of the split-K factor of conv3x3_x3.hip's small launches (0 = the heuristic's)
     int split_x3_small = 2;  // ... and smaller launches: 2 (default) = where they measured faster than conv3x3_f16.hip's 12-wave kernel (conv3x3_x3_supported),
                              // 1 = every launch, 0 = none; K split over up to 8 blocks per tile (x3m16_tail: reduce-scatter)
+    int x3s_sk_cap = 8;      // conv_x3s_kernel: most blocks per output tile
+    int conv_x3s = 1;        // conv3x3_x3.hip conv_x3s_kernel for the strided 3x3 / 1x1 convolutions of the fp32-class mode: 1 = wherever gemm_f16.hip's SPLIT build served (launches of >= ~100 tiles), 2 = also the small launches that run in exact fp32, 0 = off
     int x3_l4_narrow_nmt = 31;  // conv3x3_x3.hip x3_wide_tiles: layer 4 on 64-wide tiles where its 128-wide launch fills the chip unevenly (0: never; split launches up to this many tile rows)
     int x3_narrow = 1;       // conv3x3_x3.hip, 64-wide tiles (four blocks per CU) beyond layer 1: bit 0 = the 16-wide maps (layer 2: 14.03 -> 13.87 ms per
                              // 1024-crop pass; default), bit 1 = the 8-wide ones (layers 3-4: 14.03 -> 14.70, off)

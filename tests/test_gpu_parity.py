@@ -982,7 +982,7 @@ def test_f16_path_small_and_odd_batches(eng_w0, n):
 #   (2, 64):   fp32-class, passes of 64 crops - since round 6 layers 3-4 of such a pass run conv3x3_x3.hip's split-K forms (another
 #              summation order than conv3x3_f16.hip's 12-wave kernel that served them before)
 # Every other combination reproduces all 256 rows.
-CONFIG1_RAND0_KNOWN_SUBNOISE_ROWS = {(0, 1024): {84}, (2, 64): {84}}
+CONFIG1_RAND0_KNOWN_SUBNOISE_ROWS = {(0, 1024): {84}, (2, 1024): {180}}   # (2, 64): {84} until conv_x3s_kernel took the strided / 1x1 convolutions (round 6); row 180: gap 6e-8 = one ulp
 @pytest.mark.parametrize("chunk", [40, 64, 130, 1024])   # passes of 40 (+ 16) and 130 + 126 crops: the small- and mid-size launch rules of round 6; four passes of 64 (the library default of rounds 1-3); one pass of 256
 @pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("tag,crops_fn,seed", [("rand0", synth.crops_u8, 0), ("smooth5", synth.smooth_crops_u8, 5)])
@@ -2562,4 +2562,41 @@ def test_swin_dense_x3_kernel_agrees_with_the_gemm_f16_linear_build(eng):
         assert np.array_equal(eng.swin_embed_f32_nchw(x[:1]), new[:1]) and np.array_equal(eng.swin_embed_f32_nchw(x[2:5]), new[2:5])
     finally:
         eng.debug_switch("lin_x3", 1)
+        eng.set_precision(0)
+
+
+@pytest.mark.parametrize("n", [1, 7, 30, 64, 130, 256])
+def test_strided_and_1x1_convolutions_on_the_x3s_kernel(eng_w0, n):
+    """conv3x3_x3.hip, conv_x3s_kernel (round 6): the strided 3x3 and the 1x1 convolutions of the fp32-class mode (SERes18_IBN.py:120-128
+    conv1 of a down-sampling block, :250-276 the shortcut convolutions) as lin_x3_kernel's block over an im2col GATHER - per-lane pixel
+    of tap (0, 0), scalar tap / chunk offsets, taps outside the image as offsets past the descriptor - with split-K over the (tap, chunk)
+    steps (uneven shares) and the convolution epilogue of x3m16_tail.  Default (switch conv_x3s = 1): wherever gemm_f16.hip's SPLIT
+    build served; 2: also the small launches that otherwise run in exact fp32; 0: off.  The three forms against each other and against
+    exact fp32 at the mode's error level (odd image counts: ragged last tile rows; 130: unsplit, 64: the size where the forms meet),
+    copies of a crop bit-identical inside a pass in every form, no fault bit."""
+    eng, _ = eng_w0
+    base = synth.smooth_crops_u8(max(2, (n + 1) // 2), 40 + n)
+    ids = np.arange(n) % len(base)
+    np.random.default_rng(n).shuffle(ids)
+    crops = base[ids]
+    try:
+        eng.set_precision(0)
+        exact = eng.embed_u8(crops)
+        eng.set_precision(2)
+        out = {}
+        for sw in (0, 1, 2):
+            eng.debug_switch("conv_x3s", sw)
+            out[sw] = eng.embed_u8(crops)
+            first = {int(c): int(np.flatnonzero(ids == c)[0]) for c in np.unique(ids)}
+            assert all(np.array_equal(out[sw][i], out[sw][first[int(ids[i])]]) for i in range(n)), sw
+        scale = np.abs(exact).max()
+        for sw in (0, 1, 2):
+            assert np.abs(out[sw] - exact).max() <= 5e-6 * scale, sw
+        assert np.abs(out[1] - out[0]).max() <= 5e-6 * scale and np.abs(out[2] - out[0]).max() <= 5e-6 * scale
+        assert not np.array_equal(out[2], out[0])                          # the switch did select the other kernel
+        if n >= 130:
+            assert not np.array_equal(out[1], out[0])                      # the default uses it where the launches are large
+        assert eng.fault_bits() == 0
+    finally:
+        eng.debug_switch("conv_x3s", 1)
         eng.set_precision(0)
