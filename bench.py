@@ -253,7 +253,7 @@ def run_embed(job, args):
             "whole_net_fraction_of_hbm_roofline": round(FUSED_BYTES_PER_CROP * (0.5 if f16 else 1.0) * n / (embed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": {
                 "kernel": ("convolution kernels of the fp16 path, v_mfma_f32_32x32x16_f16: conv3x3_f16 (LDS halo, layers 2-4), conv3x3_c64_f16 (layer 1, weights in registers), stem_pool_f16 (7x7 + BN + maxpool), gemm_f16 (strided / 1x1)" if f16 else
-                           "convolution kernels of the fp32-class path, hi/lo-split f16 operands (x.w = xh.wh + (xl.wh + xh.wl), three matrix-core products per multiply, fp32 accumulate; peak = 2.5 PF / 3 per algorithmic flop): conv3x3_x3u (3x3 stride-1: LDS halo, v_mfma_f32_16x16x32_f16, two / three 4-wave blocks per CU, a chunk's 27 steps unrolled; small launches: conv3x3_f16 SPLIT build), gemm_f16 SPLIT build (stride-2, 1x1), stem_split (7x7 + BN + max-pool), both on v_mfma_f32_32x32x16_f16" if x3 else
+                           "convolution kernels of the fp32-class path, hi/lo-split f16 operands (x.w = xh.wh + (xl.wh + xh.wl), three matrix-core products per multiply, fp32 accumulate; peak = 2.5 PF / 3 per algorithmic flop): conv3x3_x3u (3x3 stride-1: LDS halo, v_mfma_f32_16x16x32_f16, two / three 4-wave blocks per CU, a chunk's 27 steps unrolled; small launches: conv3x3_f16 SPLIT build), conv_x3s (stride-2 3x3 and 1x1: the same block over an im2col gather), stem_split (7x7 + BN + max-pool, v_mfma_f32_32x32x16_f16)" if x3 else
                            "convolution kernels of the fp32 path, v_mfma_f32_32x32x2_f32 (exact fp32): conv_f32_dma_kernel (implicit GEMM, LDS-DMA staging, all 3x3 / 1x1 convs) + the 7x7 stem"),
                 "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(conv_tflops / peak, 4), "traffic": traffic_from_profile("conv_f16" if f16 else "conv_f16x3" if x3 else "conv_f32"),

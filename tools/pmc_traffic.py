@@ -18,8 +18,8 @@ if MODE == "f32":   # convolution class of the exact-fp32 path: conv_f32.hip ker
     CONV = re.compile(r"conv_f32_dma_kernel|conv_f32_kernel|stem_f32_kernel|gemm_f32_kernel<[123],|gemm_f32_kernelILi[123]E")
     LABEL = "convolution kernels of the fp32 path (conv_f32_dma, conv_f32, 7x7 stem)"
 elif MODE == "f16x3":      # convolution class of the fp32-class path: SPLIT builds on the f16 pipe + the fp32 stem (+ small fp32 leftovers)
-    CONV = re.compile(r"conv3x3_x3|conv3x3_f16_kernel|gemm_f16_kernel|stem_split_kernel|stem_f32_kernel|conv_f32_dma_kernel")
-    LABEL = "convolution kernels of the fp32-class path (conv3x3_x3 two-blocks-per-CU halo kernel, conv3x3_f16 / gemm_f16 SPLIT builds, stem_split)"
+    CONV = re.compile(r"conv3x3_x3|conv_x3s_kernel|conv3x3_f16_kernel|gemm_f16_kernel|stem_split_kernel|stem_f32_kernel|conv_f32_dma_kernel")
+    LABEL = "convolution kernels of the fp32-class path (conv3x3_x3 two-blocks-per-CU halo kernel, conv_x3s strided / 1x1, conv3x3_f16 / gemm_f16 SPLIT builds, stem_split)"
 elif MODE == "swin_f32":   # Swin contractions in exact fp32: dense LDS-DMA GEMM + general conv kernel
     CONV = re.compile(r"gemm_f32_dma_kernel|conv_f32_dma_kernel|gemm_f32_kernel")
     LABEL = "Swin Linear / conv contractions of the fp32 path (gemm_f32_dma, conv_f32_dma general variant)"
