@@ -459,7 +459,10 @@ def run_tracking(job, args):
     counts = np.clip(rng.poisson(30, frames), 1, 80)
     pool = synth.ragged_crops_u8(256, seed=3)
     from reid_amd.tracking import ShardedCameraStream
-    stream = ShardedCameraStream(eng, comm, 0.15, 100, match_stream=bool(args.match_stream) and world == 1)    # MAX_DIST / NN_BUDGET, deep_sort.yaml:3,9
+    # MAX_DIST / NN_BUDGET, deep_sort.yaml:3,9.  The match stream only where no collective runs (tracking.ShardedCameraStream: beside
+    # librccl's streams it costs more than half the rate); --match-stream 2 forces it for that A/B
+    two = args.match_stream == 2 or (bool(args.match_stream) and world == 1 and not getattr(comm, "active", False))
+    stream = ShardedCameraStream(eng, comm, 0.15, 100, match_stream=two)
     metric = stream.metric
     tracks = list(range(40))
     metric.partial_fit(rng.normal(size=(40 * 100, 512)).astype(np.float32), np.repeat(tracks, 100), tracks)
@@ -1034,7 +1037,7 @@ def main(argv=None):
     ap.add_argument("--crops", type=int, default=4096, help="crops (images) per GPU per step (BASELINE config 2 / 3: 4096)")
     ap.add_argument("--frames", type=int, default=600, help="--workload tracking: frames of the stream")
     ap.add_argument("--match-stream", type=int, default=1,
-                    help="tracking: 0 = cost / update stages of the frame pipeline on the compute stream (rounds 3-5) instead of a stream of their own")
+                    help="tracking: 0 = cost / update stages of the frame pipeline on the compute stream (rounds 3-5) instead of a stream of their own; 2 = on their own stream even beside a communicator")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("REID_CHUNK", "1024")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cameras", type=int, default=2, help="--workload tracking, one GPU: also run this many concurrent camera streams")

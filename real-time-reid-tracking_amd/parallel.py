@@ -107,6 +107,7 @@ class RcclComm:
             raise ValueError("RcclComm: world > 1 needs the communicator id of rank 0")
         buf = (C.c_char * _ffi.COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes)) if id_bytes is not None else None
         check(engine.lib.reid_comm_init(engine.h, self.rank, self.world, buf))
+        self.active = id_bytes is not None        # collectives go through librccl (false: world 1 without a communicator - local copies)
 
     @staticmethod
     def unique_id():
@@ -159,6 +160,7 @@ class RcclComm:
         rank, world = C.c_int(), C.c_int()
         check(engine.lib.reid_comm_info(engine.h, C.byref(rank), C.byref(world)))
         self.engine, self.rank, self.world = engine, rank.value, world.value
+        self.active = True
         return self
 
     def close(self):

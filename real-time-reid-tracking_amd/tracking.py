@@ -261,10 +261,14 @@ class ShardedCameraStream:
     def __init__(self, engine, comm, max_dist=0.15, budget=100, metric="cosine", max_tracks=4096, match_stream=None):
         self.eng, self.rank, self.world = engine, int(comm.rank), int(comm.world)
         self._own = False
-        # match_stream=None: on for one rank.  With several ranks the all-gather stays on the compute stream, behind the forward, and the
-        # slot's readers wait for it (reid_frame_gather re-records the slot's event) - exercised with loop-back ranks on one device
-        # (tests/test_gpu_parity.py), never yet on several physical GPUs, so it is opt-in there.
-        _two_streams(self, self.world == 1 if match_stream is None else match_stream)
+        # match_stream=None: on where no collective runs (one rank, no communicator).  With a communicator the all-gather stays on the
+        # compute stream, behind the forward, and the slot's readers wait for it (reid_frame_gather re-records the slot's event) - correct
+        # (loop-back ranks and a real 1-rank RCCL communicator, tests/test_gpu_parity.py) but SLOW beside librccl's own streams: with a real
+        # 1-rank communicator the stream fell from 1 120 to 460 frames/s (bench.py --workload tracking, REID_BENCH_COMM1=1,
+        # --match-stream 1 against 0) - the cross-stream waits stall on hardware-queue switches, as with K contexts.  Opt-in there.
+        if match_stream is None:
+            match_stream = self.world == 1 and not getattr(comm, "active", False)
+        _two_streams(self, match_stream)
         self.max_dist = max_dist
         self.metric = NearestNeighborDistanceMetric(metric, max_dist, budget, max_tracks=max_tracks, engine=engine)
         self._frame = 0
