@@ -2600,3 +2600,22 @@ def test_strided_and_1x1_convolutions_on_the_x3s_kernel(eng_w0, n):
     finally:
         eng.debug_switch("conv_x3s", 1)
         eng.set_precision(0)
+
+
+def test_fp32_class_mode_is_run_to_run_deterministic_across_launch_forms(eng_w0):
+    """A race in a split-K rendezvous, a gather or an LDS-DMA wait shows as a run-to-run difference: every launch form of the
+    fp32-class mode sums in a fixed order (reduce-scatter partials in split order, conv_x3s shares in step order), so repeats of the
+    same pass must be bit-identical - at the pass sizes on both sides of the steps where the forms change (7: everything split; 33 / 48:
+    layer 1 and the stem change form, layer 4 on 64-wide tiles; 66: two ways split; 130: unsplit, conv_x3s for the strided
+    convolutions; 300: two passes' worth of tiles)."""
+    eng, _ = eng_w0
+    crops = synth.smooth_crops_u8(300, 33)
+    eng.set_precision(2)
+    try:
+        for n in (7, 33, 48, 66, 130, 300):
+            first = eng.embed_u8(crops[:n])
+            for _ in range(3):
+                assert np.array_equal(eng.embed_u8(crops[:n]), first), n
+        assert eng.fault_bits() == 0
+    finally:
+        eng.set_precision(0)
