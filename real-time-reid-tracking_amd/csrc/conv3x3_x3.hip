@@ -1935,8 +1935,10 @@ static bool x3_wide_tiles(const reid_ctx* ctx, const Gemm16Params& p) {
     return true;
 }
 
-// block slots the split count may fill: two blocks per CU for the 128-wide tile, and for layer 4's 64-wide tile three (x3_wide_tiles)
-static int x3_slots(const Gemm16Params& p, bool wide) { return (!wide && p.W == 8 && p.N == 512) ? 768 : 512; }
+// block slots the split count may fill: two blocks per CU, and three for layer 4's 64-wide tile at 65 .. 96 crops (x3_wide_tiles).  NOT for its
+// 64-wide launches at 33 .. 62 crops: with 768 slots those split four ways (544 .. 768 blocks) instead of two and a pass of 33 .. 47 crops
+// took 100 us longer (the pass-size sweep caught it: Poisson(30) mean 772 -> 808 us).
+static int x3_slots(const Gemm16Params& p, bool wide) { return (!wide && p.W == 8 && p.N == 512 && (p.M + 255) / 256 > 32) ? 768 : 512; }
 
 template <int TW, int IMGS>
 int launch_x3m16(reid_ctx* ctx, const Gemm16Params& p0) {

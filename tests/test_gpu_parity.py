@@ -1049,7 +1049,7 @@ def test_small_pass_split_k_forms_agree_and_are_position_invariant(eng_w0, n):
     conv3x3_f16.hip that served these sizes until round 5 (debug switch split_x3_small = 0): same three products per multiply in another
     summation order - agreement to 5e-6 of the embedding's scale - and, the property that must hold exactly: copies of a crop inside
     one pass give bit-identical embeddings wherever they sit (another tile, another column slice, another image pair).
-    The sizes sit on both sides of the steps of the pass-size staircase (profiles/r06_pass_size_sweep_8_64.txt) where the launch rules
+    The sizes sit on both sides of the steps of the pass-size staircase (profiles/r06_pass_size_sweep_8_100.txt) where the launch rules
     change form: 21 / 30 (layers 3-4 on these kernels at every size), 33 / 48 / 62 (layer 1 leaves the 12-wave kernel, the stem's strips
     fill one round, layer 4 takes 64-wide tiles), 66 (two ways split, wide again), 130 (unsplit, 64-wide because the last layer of
     128-wide blocks would cover 4 of 256 CUs).  Layer 4's tile width (switch x3_l4_narrow_nmt = 0: always 128 wide) must not change a
