@@ -2619,3 +2619,71 @@ def test_fp32_class_mode_is_run_to_run_deterministic_across_launch_forms(eng_w0)
         assert eng.fault_bits() == 0
     finally:
         eng.set_precision(0)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_match_stream_random_operation_sequences_are_bit_identical_to_one_stream(eng_w0, seed):
+    """reid_frame_match_stream under operation orders the streams' normal flow does not produce: the SAME random sequence of frame
+    steps (with and without a next frame riding on them, frames without detections, tracks that die and come back), direct bank
+    operations between frames (distance / partial_fit from host features, which join the two streams) and re-submissions of a slot
+    runs on two CameraStreams - cost / update stages on the match stream, and everything on one stream.  Every result must be
+    bit-identical: the second stream changes when things run, never what they compute."""
+    from reid_amd.tracking import CameraStream
+    eng, sd = eng_w0
+    blob, manifest = weights.pack_seres18(sd)[:2]
+    rng = np.random.default_rng(100 + seed)
+    pool = synth.ragged_crops_u8(40, seed=30 + seed)
+    boxes = rng.uniform(0, 300, (16, 4))
+    boxes[:, 2:] = rng.uniform(10, 90, (16, 2))
+    a = CameraStream(blob, manifest, 2, match_stream=True)
+    b = CameraStream(blob, manifest, 2, match_stream=False)
+    assert a.match_stream and not b.match_stream
+    try:
+        tracks = list(range(6))
+        seeds = rng.normal(size=(12, 512)).astype(np.float32)
+        for s_ in (a, b):
+            s_.metric.partial_fit(seeds, np.repeat(tracks, 2), tracks)
+        frame = lambda: [pool[int(i)] for i in rng.integers(0, 40, int(rng.integers(0, 12)))]
+        known = list(tracks)                                         # tracks that have samples (the reference's `samples` keys)
+        cur = frame()
+        for s_ in (a, b):
+            s_.submit(cur)
+        for it in range(25):
+            op = int(rng.integers(0, 10))
+            if op == 0:                                              # direct bank operations between two frames
+                q = rng.normal(size=(int(rng.integers(1, 6)), 512)).astype(np.float32)
+                da, db = a.metric.distance(q, known), b.metric.distance(q, known)
+                assert np.array_equal(da, db), it
+                k = min(len(q), len(tracks))
+                revived = sorted(set(known) | set(tracks[:k]))       # dead tracks come back with a sample from the host
+                for s_ in (a, b):
+                    s_.metric.partial_fit(q[:k], tracks[:k], revived)
+                known = revived
+                continue
+            if op == 1:                                              # the pending frame is replaced before anyone asked for it
+                cur = frame()
+                for s_ in (a, b):
+                    s_.submit(cur)
+                continue
+            nxt = frame() if op < 9 else None                        # (op 9: no next frame rides on this step)
+            alive = [t for t in known if rng.random() > 0.15] or known[:1]
+            ra = a.step(alive, boxes[:len(alive)], boxes[:len(cur)], nxt)
+            rb = b.step(alive, boxes[:len(alive)], boxes[:len(cur)], nxt)
+            for x, y in zip(ra, rb):
+                assert (x is None and y is None) or np.array_equal(x, y), it
+            k = min(len(cur), len(alive))
+            rows = rng.permutation(len(cur))[:k]
+            for s_ in (a, b):
+                s_.commit(rows, alive[:k], alive)                    # tracks outside `alive` are forgotten here, and come back later
+            known = list(alive)
+            if nxt is None:
+                nxt = frame()
+                for s_ in (a, b):
+                    s_.submit(nxt)
+            cur = nxt
+        for t in known:
+            assert a.metric.samples_count(t) == b.metric.samples_count(t)
+        assert a.eng.fault_bits() == 0 and b.eng.fault_bits() == 0
+    finally:
+        a.close(destroy=True)
+        b.close(destroy=True)
